@@ -1,0 +1,136 @@
+"""ctypes front end of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  Nothing under defslam_amd/ imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+TRACE_STRIDE = 8
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "_build", "libdefslam_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "_build", "libdefslam_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.sft_oracle_solve.restype = C.c_int
+        _LIB.tmpl_oracle_build.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+@dataclass
+class TemplateConsts:
+    n: int
+    xyz0: np.ndarray
+    facets: np.ndarray          # sorted (F,3)
+    E: int
+    edge_nodes: np.ndarray
+    edge_L0: np.ndarray
+    nbr_ptr: np.ndarray
+    nbr_idx: np.ndarray
+    nbr_w: np.ndarray
+    inc_ptr: np.ndarray
+    inc_edge: np.ndarray
+    boundary: np.ndarray
+    k0: np.ndarray
+    lap0: np.ndarray
+    median_L: float
+
+
+def template_build(xyz0: np.ndarray, facets: np.ndarray) -> TemplateConsts:
+    L = lib()
+    xyz0 = np.ascontiguousarray(xyz0, dtype=np.float64)
+    facets = np.ascontiguousarray(facets, dtype=np.int32)
+    n, F = xyz0.shape[0], facets.shape[0]
+    edge_nodes = np.zeros((3 * F, 2), np.int32)
+    edge_L0 = np.zeros(3 * F)
+    nbr_ptr = np.zeros(n + 1, np.int32)
+    nbr_idx = np.zeros(6 * F, np.int32)
+    nbr_w = np.zeros(6 * F)
+    inc_ptr = np.zeros(n + 1, np.int32)
+    inc_edge = np.zeros(6 * F, np.int32)
+    boundary = np.zeros(n, np.uint8)
+    k0 = np.zeros(n)
+    fs = np.zeros((F, 3), np.int32)
+    lap0 = np.zeros((n, 3))
+    med = C.c_double(0)
+    E = L.tmpl_oracle_build(n, _p(xyz0, C.c_double), F, _p(facets, C.c_int32), _p(edge_nodes, C.c_int32), _p(edge_L0, C.c_double),
+                            _p(nbr_ptr, C.c_int32), _p(nbr_idx, C.c_int32), _p(nbr_w, C.c_double), _p(inc_ptr, C.c_int32),
+                            _p(inc_edge, C.c_int32), _p(boundary, C.c_uint8), _p(k0, C.c_double), _p(fs, C.c_int32),
+                            _p(lap0, C.c_double), C.byref(med))
+    nn = nbr_ptr[n]
+    return TemplateConsts(n, xyz0, fs, E, edge_nodes[:E].copy(), edge_L0[:E].copy(), nbr_ptr, nbr_idx[:nn].copy(), nbr_w[:nn].copy(),
+                          inc_ptr, inc_edge[:inc_ptr[n]].copy(), boundary, k0, lap0, med.value)
+
+
+@dataclass
+class SftResult:
+    ret: int
+    Tcw: np.ndarray
+    pose7: np.ndarray
+    xyz: np.ndarray
+    chi2_obs: np.ndarray
+    outlier: np.ndarray
+    rep_error: float
+    iters: int
+    trials: int
+    trace: np.ndarray
+    dims: np.ndarray
+
+
+def sft_solve(tc: TemplateConsts, Tcw, K, n_frame, obs_nodes, obs_bary, obs_uv, obs_invsig2, xyz,
+              reg_lap, reg_inex, reg_temp, layers=1, max_iters=50, ldlt_mode=0) -> SftResult:
+    L = lib()
+    M = int(obs_nodes.shape[0])
+    Tcw = np.ascontiguousarray(Tcw, dtype=np.float32)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    obs_nodes = np.ascontiguousarray(obs_nodes, dtype=np.int32)
+    obs_bary = np.ascontiguousarray(obs_bary, dtype=np.float64)
+    obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64)
+    obs_invsig2 = np.ascontiguousarray(obs_invsig2, dtype=np.float64)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    Tout = np.zeros((4, 4), np.float32)
+    pose7 = np.zeros(7)
+    xyz_out = np.zeros_like(xyz)
+    chi2 = np.zeros(M)
+    outl = np.zeros(M, np.uint8)
+    rep = C.c_double(0)
+    it = C.c_int32(0)
+    tr = C.c_int32(0)
+    trace = np.zeros((max(max_iters, 1), TRACE_STRIDE))
+    dims = np.zeros(6, np.int32)
+    D = C.c_double
+    ret = L.sft_oracle_solve(
+        tc.n, _p(tc.xyz0, D), _p(tc.boundary, C.c_uint8), _p(tc.nbr_ptr, C.c_int32), _p(tc.nbr_idx, C.c_int32), _p(tc.nbr_w, D),
+        _p(tc.k0, D), tc.E, _p(tc.edge_nodes, C.c_int32), _p(tc.edge_L0, D), _p(tc.inc_ptr, C.c_int32), _p(tc.inc_edge, C.c_int32),
+        D(tc.median_L), _p(Tcw, C.c_float), _p(K, D), int(n_frame), M, _p(obs_nodes, C.c_int32), _p(obs_bary, D), _p(obs_uv, D),
+        _p(obs_invsig2, D), _p(xyz, D), D(reg_lap), D(reg_inex), D(reg_temp), int(layers), int(max_iters), int(ldlt_mode),
+        _p(Tout, C.c_float), _p(pose7, D), _p(xyz_out, D), _p(chi2, D), _p(outl, C.c_uint8), C.byref(rep), C.byref(it), C.byref(tr),
+        _p(trace, D), _p(dims, C.c_int32))
+    return SftResult(ret, Tout, pose7, xyz_out, chi2, outl, rep.value, it.value, tr.value, trace[:it.value].copy(), dims)
