@@ -1,0 +1,108 @@
+"""ctypes binding of libdefslam_hip.so (the C ABI in include/defslam_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C defslam_amd/csrc`.
+There is no CPU fallback: if the shared object is missing, importing a symbol raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdefslam_hip.so")
+
+DSH_OK = 0
+DSH_TRACE_STRIDE = 8
+DSH_MAX_ITERS = 64
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_i32_p = C.POINTER(C.c_int32)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class SftFrameC(C.Structure):
+    _fields_ = [
+        ("Tcw", c_float_p),
+        ("K", C.c_double * 4),
+        ("n_frame", C.c_int32),
+        ("M", C.c_int32),
+        ("obs_nodes", c_i32_p),
+        ("obs_bary", c_double_p),
+        ("obs_uv", c_double_p),
+        ("obs_invsig2", c_double_p),
+        ("xyz", c_double_p),
+        ("reg_lap", C.c_double),
+        ("reg_inex", C.c_double),
+        ("reg_temp", C.c_double),
+        ("neighbour_layers", C.c_int32),
+        ("max_iters", C.c_int32),
+    ]
+
+
+class SftResultC(C.Structure):
+    _fields_ = [
+        ("Tcw", c_float_p),
+        ("pose7", c_double_p),
+        ("xyz", c_double_p),
+        ("chi2_obs", c_double_p),
+        ("outlier", c_u8_p),
+        ("mappoint_xyz", c_float_p),
+        ("rep_error", C.c_double),
+        ("inliers", C.c_int32),
+        ("iters", C.c_int32),
+        ("trials", C.c_int32),
+        ("dim", C.c_int32),
+        ("half_bandwidth", C.c_int32),
+        ("status", C.c_int32),
+        ("trace", c_double_p),
+    ]
+
+
+# Every symbol include/defslam_hip.h declares (checked by tests/test_abi.py).
+EXPORTED_SYMBOLS = [
+    "dsh_create", "dsh_destroy", "dsh_last_error", "dsh_stream", "dsh_synchronize",
+    "dsh_template_build", "dsh_template_set", "dsh_template_dims", "dsh_template_get", "dsh_template_embed",
+    "dsh_sft_solve", "dsh_sft_batch_upload", "dsh_sft_batch_run", "dsh_sft_batch_download",
+    "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises OSError when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(or `make -C defslam_amd/csrc`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.dsh_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.dsh_destroy.argtypes = [vp]
+    L.dsh_last_error.argtypes = [vp]
+    L.dsh_last_error.restype = C.c_char_p
+    L.dsh_stream.argtypes = [vp]
+    L.dsh_stream.restype = vp
+    L.dsh_synchronize.argtypes = [vp]
+    L.dsh_template_build.argtypes = [vp, C.c_int, c_double_p, C.c_int, c_i32_p]
+    L.dsh_template_set.argtypes = [vp, C.c_int, c_double_p, c_u8_p, c_i32_p, c_i32_p, c_double_p, c_double_p, C.c_int, c_i32_p,
+                                   c_double_p, C.c_double]
+    L.dsh_template_dims.argtypes = [vp, c_i32_p, c_i32_p, c_i32_p]
+    L.dsh_template_get.argtypes = [vp, c_u8_p, c_i32_p, c_i32_p, c_double_p, c_double_p, c_i32_p, c_double_p, c_double_p]
+    L.dsh_template_embed.argtypes = [vp, C.c_int, c_float_p, c_i32_p, c_i32_p, c_float_p]
+    L.dsh_sft_solve.argtypes = [vp, C.POINTER(SftFrameC), C.POINTER(SftResultC)]
+    L.dsh_sft_batch_upload.argtypes = [vp, C.c_int, C.POINTER(SftFrameC)]
+    L.dsh_sft_batch_run.argtypes = [vp]
+    L.dsh_sft_batch_download.argtypes = [vp, C.c_int, C.POINTER(SftResultC)]
+    L.dsh_sft_batch_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.dsh_sft_batch_problem_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), c_i32_p]
+    L.dsh_sft_debug_system.argtypes = [vp, C.c_int, C.c_int32, c_double_p, c_double_p, c_double_p]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("dsh_last_error", "dsh_stream"):
+            fn.restype = C.c_int
+    _lib = L
+    return L

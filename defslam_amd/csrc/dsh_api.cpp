@@ -1,0 +1,617 @@
+// C ABI of libdefslam_hip.so: context, template, SfT pack / upload / run / download.
+// Declared in include/defslam_hip.h.  Compiled with hipcc (host side).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/defslam_hip.h"
+#include "dsh_template.h"
+#include "sft_problem.h"
+
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, hipStream_t stream);
+extern "C" size_t sft_lm_kernel_lds_bytes(int kd);
+
+namespace {
+
+constexpr int kNB = 32;  // must match NB in sft_kernels.hip
+
+// ---- pose conversions at the float32 boundary (Converter.cc:35-66, se3quat.h:58-64,269-285) -------
+void pose7_from_Tcw(const float* T, double* p) {
+  double R[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = (double)T[4 * i + j];
+  double q[4];
+  double tr = R[0] + R[4] + R[8];
+  if (tr > 0.0) {
+    double t = std::sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t;
+    q[1] = (R[2] - R[6]) * t;
+    q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+  }
+  if (q[3] < 0)
+    for (double& c : q) c = -c;
+  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (double& c : q) c /= nrm;
+  p[0] = (double)T[3];
+  p[1] = (double)T[7];
+  p[2] = (double)T[11];
+  p[3] = q[0];
+  p[4] = q[1];
+  p[5] = q[2];
+  p[6] = q[3];
+}
+
+void Tcw_from_pose7(const double* p, float* T) {
+  const double x = p[3], y = p[4], z = p[5], w = p[6];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T[4 * i + j] = (float)R[3 * i + j];
+    T[4 * i + 3] = (float)p[i];
+  }
+  T[12] = T[13] = T[14] = 0.f;
+  T[15] = 1.f;
+}
+
+// ---- one packed problem on the host ---------------------------------------------------------------
+struct Packed {
+  SftDev h{};                   // sizes + scalars (pointers filled at upload)
+  std::vector<int32_t> act, obs_nodes, ref_node, star_node, str_nodes, blk_rc, blk_ptr;
+  std::vector<uint32_t> contrib;
+  std::vector<double> obs_bary, obs_uv, obs_w, star_sL, str_L0, xyz_init;
+  double pose_init[7];
+  int n_curv_ref = 0;           // curvature edges in the reference's (unfused) count
+  int max_iters = 0;
+  std::vector<int32_t> actnode; // compact index -> node
+};
+
+struct Arena {  // byte layout of a device allocation, 256-byte aligned slices
+  size_t size = 0;
+  size_t take(size_t bytes) {
+    const size_t off = size;
+    size += (bytes + 255) & ~size_t(255);
+    return off;
+  }
+};
+
+}  // namespace
+
+struct dsh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  dsh::TemplateHost tmpl;
+  // device copy of the template
+  char* d_tmpl = nullptr;
+  size_t d_tmpl_bytes = 0;
+  struct {
+    const double *xyz0, *nbr_w, *nbr_c, *nbr_sumw, *k0;
+    const int32_t *nbr_ptr, *nbr_idx;
+  } dt{};
+  // batch
+  int B = 0;
+  std::vector<Packed> packed;
+  char* d_batch = nullptr;
+  size_t d_batch_cap = 0;
+  SftDev* d_probs = nullptr;       // inside d_batch
+  std::vector<SftDev> h_probs;     // host mirror with device pointers
+  std::vector<char> stage;         // host staging of the read-only part
+  size_t ro_bytes = 0;             // leading read-only bytes of d_batch (uploaded)
+  int max_kd = 0;
+  bool ran = false;
+};
+
+namespace {
+
+int fail(dsh_ctx* c, int code, const std::string& m) {
+  if (c) c->err = m;
+  return code;
+}
+#define HIPCHK(c, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e__ = (call);                                                                         \
+    if (e__ != hipSuccess) return fail(c, DSH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+int upload_template(dsh_ctx* c) {
+  const dsh::TemplateHost& t = c->tmpl;
+  Arena a;
+  const size_t o_xyz0 = a.take(sizeof(double) * 3 * t.n);
+  const size_t o_ptr = a.take(sizeof(int32_t) * (t.n + 1));
+  const size_t o_idx = a.take(sizeof(int32_t) * t.nbr_idx.size());
+  const size_t o_w = a.take(sizeof(double) * t.nbr_w.size());
+  const size_t o_c = a.take(sizeof(double) * t.nbr_c.size());
+  const size_t o_sw = a.take(sizeof(double) * t.n);
+  const size_t o_k0 = a.take(sizeof(double) * t.n);
+  if (c->d_tmpl) { (void)hipFree(c->d_tmpl); c->d_tmpl = nullptr; }
+  HIPCHK(c, hipMalloc((void**)&c->d_tmpl, a.size));
+  c->d_tmpl_bytes = a.size;
+  std::vector<char> st(a.size, 0);
+  std::memcpy(&st[o_xyz0], t.xyz0.data(), sizeof(double) * 3 * t.n);
+  std::memcpy(&st[o_ptr], t.nbr_ptr.data(), sizeof(int32_t) * (t.n + 1));
+  std::memcpy(&st[o_idx], t.nbr_idx.data(), sizeof(int32_t) * t.nbr_idx.size());
+  std::memcpy(&st[o_w], t.nbr_w.data(), sizeof(double) * t.nbr_w.size());
+  std::memcpy(&st[o_c], t.nbr_c.data(), sizeof(double) * t.nbr_c.size());
+  std::memcpy(&st[o_sw], t.nbr_sumw.data(), sizeof(double) * t.n);
+  std::memcpy(&st[o_k0], t.k0.data(), sizeof(double) * t.n);
+  HIPCHK(c, hipMemcpy(c->d_tmpl, st.data(), a.size, hipMemcpyHostToDevice));
+  c->dt.xyz0 = (const double*)(c->d_tmpl + o_xyz0);
+  c->dt.nbr_ptr = (const int32_t*)(c->d_tmpl + o_ptr);
+  c->dt.nbr_idx = (const int32_t*)(c->d_tmpl + o_idx);
+  c->dt.nbr_w = (const double*)(c->d_tmpl + o_w);
+  c->dt.nbr_c = (const double*)(c->d_tmpl + o_c);
+  c->dt.nbr_sumw = (const double*)(c->d_tmpl + o_sw);
+  c->dt.k0 = (const double*)(c->d_tmpl + o_k0);
+  c->B = 0;
+  c->ran = false;
+  return DSH_OK;
+}
+
+// Build the graph of DefOptimizer.cc:293-507 as flat arrays + per-block gather lists.
+int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, std::string& err) {
+  const int n = t.n, M = f.M;
+  if (M <= 0 || !f.obs_nodes || !f.obs_bary || !f.obs_uv || !f.obs_invsig2 || !f.xyz || !f.Tcw) { err = "empty or null frame"; return DSH_ERR_ARG; }
+  if (f.n_frame <= 0 || f.max_iters < 0 || f.max_iters > DSH_MAX_ITERS) { err = "bad n_frame/max_iters"; return DSH_ERR_ARG; }
+  for (int i = 0; i < 3 * M; i++)
+    if (f.obs_nodes[i] < 0 || f.obs_nodes[i] >= n) { err = "observation node id out of range"; return DSH_ERR_ARG; }
+  std::vector<uint8_t> viewed(n, 0), opt(n, 0);
+  for (int i = 0; i < 3 * M; i++) viewed[f.obs_nodes[i]] = 1;
+  opt = viewed;
+  if (f.neighbour_layers >= 1)  // always the 1-ring of the viewed set (DefOptimizer.cc:388-406)
+    for (int i = 0; i < n; i++)
+      if (viewed[i])
+        for (int p = t.nbr_ptr[i]; p < t.nbr_ptr[i + 1]; p++) opt[t.nbr_idx[p]] = 1;
+  P.act.assign(n, -1);
+  P.actnode.clear();
+  for (int i = 0; i < n; i++)
+    if (opt[i]) { P.act[i] = (int)P.actnode.size(); P.actnode.push_back(i); }
+  const int nA = (int)P.actnode.size();
+
+  P.obs_nodes.assign(f.obs_nodes, f.obs_nodes + 3 * M);
+  P.obs_bary.assign(f.obs_bary, f.obs_bary + 3 * M);
+  P.obs_uv.assign(f.obs_uv, f.obs_uv + 2 * M);
+  P.obs_w.resize(M);
+  for (int i = 0; i < M; i++) P.obs_w[i] = f.obs_invsig2[i] / (double)f.n_frame;  // DefOptimizer.cc:340
+  P.ref_node.clear();
+  for (int i = 0; i < n; i++)
+    if (viewed[i]) P.ref_node.push_back(i);
+  // curvature "stars": the reference adds deg(i) copies of the same residual divided by the incident
+  // edge lengths (DefOptimizer.cc:427-461); they are fused here into one record with sum(1/L^2).
+  P.star_node.clear();
+  P.star_sL.clear();
+  P.n_curv_ref = 0;
+  for (int i = 0; i < n; i++)
+    if (opt[i] && !t.boundary[i]) {
+      double s = 0.0;
+      for (int p = t.inc_ptr[i]; p < t.inc_ptr[i + 1]; p++) { const double il = 1.0 / t.edge_L0[t.inc_edge[p]]; s += il * il; P.n_curv_ref++; }
+      if (t.nbr_ptr[i + 1] - t.nbr_ptr[i] > 14) { err = "node degree > 14 unsupported"; return DSH_ERR_ARG; }
+      P.star_node.push_back(i);
+      P.star_sL.push_back(s);
+    }
+  // stretch edges: mesh edges incident to an active node, creation order (DefOptimizer.cc:468-507)
+  P.str_nodes.clear();
+  P.str_L0.clear();
+  for (int e = 0; e < t.E; e++) {
+    const int a = t.edge_nodes[2 * e], b = t.edge_nodes[2 * e + 1];
+    if (opt[a] || opt[b]) { P.str_nodes.push_back(a); P.str_nodes.push_back(b); P.str_L0.push_back(t.edge_L0[e]); }
+  }
+  const int V = (int)P.ref_node.size(), S = (int)P.star_node.size(), Es = (int)P.str_L0.size();
+
+  // ---- block pattern + gather lists ---------------------------------------------------------
+  // per block row: sorted list of block columns (<= row) with contribution counts
+  struct Col { int c; int cnt; int off; };
+  std::vector<std::vector<Col>> rows(nA);
+  auto touch = [&](int bi, int bj) -> Col& {
+    auto& r = rows[bi];
+    for (auto& cc : r)
+      if (cc.c == bj) return cc;
+    r.push_back({bj, 0, 0});
+    return r.back();
+  };
+  // pass over every edge twice: count, then fill (the emission order is the reference's edge order:
+  // observations, temporal, curvature, stretching -- DefOptimizer.cc:293-507)
+  auto for_each_contrib = [&](auto&& emit) {
+    for (int m = 0; m < M; m++) {
+      int a[3];
+      for (int s = 0; s < 3; s++) a[s] = P.act[P.obs_nodes[3 * m + s]];
+      for (int s = 0; s < 3; s++)
+        for (int u = 0; u < 3; u++)
+          if (a[s] >= 0 && a[u] >= 0 && (a[s] > a[u] || (s == u))) emit(a[s], a[u], SFT_REC(SFT_KIND_OBS, s, u, m));
+    }
+    for (int v = 0; v < V; v++) { const int a = P.act[P.ref_node[v]]; emit(a, a, SFT_REC(SFT_KIND_REF, 0, 0, v)); }
+    for (int s = 0; s < S; s++) {
+      const int nd = P.star_node[s];
+      const int deg = t.nbr_ptr[nd + 1] - t.nbr_ptr[nd];
+      int a[16];
+      a[0] = P.act[nd];
+      for (int j = 0; j < deg; j++) a[1 + j] = P.act[t.nbr_idx[t.nbr_ptr[nd] + j]];
+      for (int p = 0; p <= deg; p++)
+        for (int q = 0; q <= deg; q++)
+          if (a[p] >= 0 && a[q] >= 0 && (a[p] > a[q] || p == q)) emit(a[p], a[q], SFT_REC(SFT_KIND_STAR, p, q, s));
+    }
+    for (int e = 0; e < Es; e++) {
+      const int a[2] = {P.act[P.str_nodes[2 * e]], P.act[P.str_nodes[2 * e + 1]]};
+      for (int p = 0; p < 2; p++)
+        for (int q = 0; q < 2; q++)
+          if (a[p] >= 0 && a[q] >= 0 && (a[p] > a[q] || p == q)) emit(a[p], a[q], SFT_REC(SFT_KIND_STR, p, q, e));
+    }
+  };
+  for (int a = 0; a < nA; a++) touch(a, a);  // every active node owns a diagonal block
+  for_each_contrib([&](int bi, int bj, uint32_t) { touch(bi, bj).cnt++; });
+  int nblk = 0, bwn = 0;
+  size_t total = 0;
+  for (int a = 0; a < nA; a++) {
+    std::sort(rows[a].begin(), rows[a].end(), [](const Col& x, const Col& y) { return x.c < y.c; });
+    for (auto& cc : rows[a]) { cc.off = (int)total; total += cc.cnt; cc.cnt = 0; nblk++; bwn = std::max(bwn, a - cc.c); }
+  }
+  if (total >= (1u << 22) * 64ull) { err = "too many contributions"; return DSH_ERR_ARG; }
+  if ((size_t)std::max(M, std::max(S, Es)) >= (1u << 22)) { err = "edge index exceeds 22 bits"; return DSH_ERR_ARG; }
+  P.contrib.assign(total, 0u);
+  for_each_contrib([&](int bi, int bj, uint32_t rec) {
+    auto& r = rows[bi];
+    // rows are sorted now; binary search
+    int lo = 0, hi = (int)r.size() - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (r[mid].c < bj) lo = mid + 1; else hi = mid; }
+    Col& cc = r[lo];
+    P.contrib[cc.off + cc.cnt++] = rec;
+  });
+  P.blk_rc.clear();
+  P.blk_ptr.clear();
+  for (int a = 0; a < nA; a++)
+    for (auto& cc : rows[a]) { P.blk_rc.push_back(a); P.blk_rc.push_back(cc.c); P.blk_ptr.push_back(cc.off); }
+  P.blk_ptr.push_back((int)total);
+
+  P.xyz_init.assign(f.xyz, f.xyz + 3 * (size_t)n);
+  pose7_from_Tcw(f.Tcw, P.pose_init);
+  SftDev& h = P.h;
+  h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
+  h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
+  h.fx = f.K[0]; h.fy = f.K[1]; h.cx = f.K[2]; h.cy = f.K[3];
+  h.w_ref = f.reg_temp / std::pow(t.median_L, 2);              // DefOptimizer.cc:378
+  h.w_curv = f.reg_lap / (double)nA;                           // :458  (|OptLap|)
+  h.w_str = Es > 0 ? f.reg_inex / (double)Es : 0.0;            // :497  (|medges|)
+  const float deltaMono = (float)std::sqrt(5.991);             // :286
+  h.hub_delta = (double)deltaMono;
+  h.hub_dsqr = h.hub_delta * h.hub_delta;
+  P.max_iters = f.max_iters;
+  return DSH_OK;
+}
+
+template <class T>
+size_t put(std::vector<char>& st, Arena& a, const std::vector<T>& v) {
+  const size_t off = a.take(sizeof(T) * v.size());
+  if (st.size() < a.size) st.resize(a.size);
+  if (!v.empty()) std::memcpy(&st[off], v.data(), sizeof(T) * v.size());
+  return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsh_create(dsh_ctx** out, int device) {
+  if (!out) return DSH_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DSH_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return DSH_ERR_ARG;
+  dsh_ctx* c = new dsh_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return DSH_ERR_HIP;
+  }
+  *out = c;
+  return DSH_OK;
+}
+
+int dsh_destroy(dsh_ctx* c) {
+  if (!c) return DSH_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->d_tmpl) (void)hipFree(c->d_tmpl);
+  if (c->d_batch) (void)hipFree(c->d_batch);
+  delete c;
+  return DSH_OK;
+}
+
+const char* dsh_last_error(const dsh_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void* dsh_stream(dsh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int dsh_synchronize(dsh_ctx* c) {
+  if (!c) return DSH_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DSH_OK;
+}
+
+int dsh_template_build(dsh_ctx* c, int n, const double* xyz0, int F, const int32_t* facets) {
+  if (!c || n <= 0 || F <= 0 || !xyz0 || !facets) return fail(c, DSH_ERR_ARG, "dsh_template_build: bad argument");
+  for (int i = 0; i < 3 * F; i++)
+    if (facets[i] < 0 || facets[i] >= n) return fail(c, DSH_ERR_ARG, "dsh_template_build: facet index out of range");
+  (void)hipSetDevice(c->device);
+  c->tmpl.build(n, xyz0, F, facets);
+  return upload_template(c);
+}
+
+int dsh_template_set(dsh_ctx* c, int n, const double* xyz0, const uint8_t* boundary, const int32_t* rp, const int32_t* col, const double* w,
+                     const double* k0, int E, const int32_t* en, const double* eL, double median_L) {
+  if (!c || n <= 0 || E < 0 || !xyz0 || !boundary || !rp || !col || !w || !k0 || !en || !eL) return fail(c, DSH_ERR_ARG, "dsh_template_set: bad argument");
+  (void)hipSetDevice(c->device);
+  c->tmpl.set(n, xyz0, boundary, rp, col, w, k0, E, en, eL, median_L);
+  return upload_template(c);
+}
+
+int dsh_template_dims(const dsh_ctx* c, int32_t* n, int32_t* E, int32_t* nnz) {
+  if (!c || !c->tmpl.valid) return DSH_ERR_STATE;
+  if (n) *n = c->tmpl.n;
+  if (E) *E = c->tmpl.E;
+  if (nnz) *nnz = (int32_t)c->tmpl.nbr_idx.size();
+  return DSH_OK;
+}
+
+int dsh_template_get(const dsh_ctx* c, uint8_t* boundary, int32_t* rp, int32_t* col, double* w, double* k0, int32_t* en, double* eL, double* med) {
+  if (!c || !c->tmpl.valid) return DSH_ERR_STATE;
+  const dsh::TemplateHost& t = c->tmpl;
+  if (boundary) std::memcpy(boundary, t.boundary.data(), t.n);
+  if (rp) std::memcpy(rp, t.nbr_ptr.data(), sizeof(int32_t) * (t.n + 1));
+  if (col) std::memcpy(col, t.nbr_idx.data(), sizeof(int32_t) * t.nbr_idx.size());
+  if (w) std::memcpy(w, t.nbr_w.data(), sizeof(double) * t.nbr_w.size());
+  if (k0) std::memcpy(k0, t.k0.data(), sizeof(double) * t.n);
+  if (en) std::memcpy(en, t.edge_nodes.data(), sizeof(int32_t) * 2 * t.E);
+  if (eL) std::memcpy(eL, t.edge_L0.data(), sizeof(double) * t.E);
+  if (med) *med = t.median_L;
+  return DSH_OK;
+}
+
+int dsh_template_embed(const dsh_ctx* c, int P, const float* pts, int32_t* facet_id, int32_t* nodes, float* bary) {
+  if (!c || !c->tmpl.valid || c->tmpl.F <= 0) return DSH_ERR_STATE;
+  if (P < 0 || !pts || !facet_id || !nodes || !bary) return DSH_ERR_ARG;
+  c->tmpl.embed(P, pts, facet_id, nodes, bary);
+  return DSH_OK;
+}
+
+int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
+  if (!c || B <= 0 || !frames) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_upload: bad argument");
+  if (!c->tmpl.valid) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_upload: no template");
+  (void)hipSetDevice(c->device);
+  c->packed.assign(B, Packed());
+  for (int b = 0; b < B; b++) {
+    std::string e;
+    const int rc = pack_problem(c->tmpl, frames[b], c->packed[b], e);
+    if (rc != DSH_OK) return fail(c, rc, "problem " + std::to_string(b) + ": " + e);
+  }
+  // ---- layout: [SftDev table][read-only arrays of every problem] | [workspace of every problem]
+  Arena a;
+  std::vector<char>& st = c->stage;
+  st.clear();
+  const size_t o_tab = a.take(sizeof(SftDev) * B);
+  st.resize(a.size);
+  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, contrib, xyz_init, pose_init; };
+  std::vector<Offs> ro(B);
+  for (int b = 0; b < B; b++) {
+    Packed& P = c->packed[b];
+    Offs& o = ro[b];
+    o.act = put(st, a, P.act); o.obs_nodes = put(st, a, P.obs_nodes); o.obs_bary = put(st, a, P.obs_bary); o.obs_uv = put(st, a, P.obs_uv);
+    o.obs_w = put(st, a, P.obs_w); o.ref = put(st, a, P.ref_node); o.star = put(st, a, P.star_node); o.sL = put(st, a, P.star_sL);
+    o.strn = put(st, a, P.str_nodes); o.strL = put(st, a, P.str_L0); o.rc = put(st, a, P.blk_rc); o.ptr = put(st, a, P.blk_ptr);
+    o.contrib = put(st, a, P.contrib); o.xyz_init = put(st, a, P.xyz_init);
+    std::vector<double> pi(P.pose_init, P.pose_init + 7);
+    o.pose_init = put(st, a, pi);
+  }
+  c->ro_bytes = a.size;
+  struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, x, chi2, ferr, trace, info, dbg; };
+  std::vector<WOffs> wo(B);
+  int max_kd = 0;
+  for (int b = 0; b < B; b++) {
+    const SftDev& h = c->packed[b].h;
+    const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
+    WOffs& w = wo[b];
+    w.xyz = a.take(8 * 3 * (size_t)h.n); w.bak = a.take(8 * 3 * (size_t)h.n); w.pose = a.take(8 * 8);
+    w.Jobs = a.take(8 * (size_t)h.M * SFT_JOBS_STRIDE); w.Jstar = a.take(8 * 4 * (size_t)h.S); w.Jstr = a.take(8 * 4 * (size_t)h.Es); w.Jref = a.take(8 * 4 * (size_t)h.V);
+    w.Hb = a.take(8 * Dnp * h.ldh); w.Hbord = a.take(8 * SFT_BORDER * Dnp); w.Hc = a.take(8 * 56);
+    w.Lb = a.take(8 * Dnp * h.ldh); w.Lbord = a.take(8 * SFT_BORDER * Dnp); w.Lc = a.take(8 * 56);
+    w.x = a.take(8 * (Dnp + 8)); w.chi2 = a.take(8 * (size_t)h.M); w.ferr = a.take(8 * (size_t)h.M);
+    w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(64);
+    max_kd = std::max(max_kd, h.kd);
+  }
+  if (sft_lm_kernel_lds_bytes(max_kd) > 160 * 1024) return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel");
+  if (a.size > c->d_batch_cap) {
+    if (c->d_batch) { (void)hipFree(c->d_batch); c->d_batch = nullptr; c->d_batch_cap = 0; }
+    HIPCHK(c, hipMalloc((void**)&c->d_batch, a.size));
+    c->d_batch_cap = a.size;
+  }
+  char* base = c->d_batch;
+  c->h_probs.resize(B);
+  for (int b = 0; b < B; b++) {
+    SftDev h = c->packed[b].h;
+    const Offs& o = ro[b];
+    const WOffs& w = wo[b];
+    h.xyz0 = c->dt.xyz0; h.nbr_ptr = c->dt.nbr_ptr; h.nbr_idx = c->dt.nbr_idx; h.nbr_w = c->dt.nbr_w; h.nbr_c = c->dt.nbr_c; h.nbr_sumw = c->dt.nbr_sumw; h.k0 = c->dt.k0;
+    h.act = (const int32_t*)(base + o.act); h.obs_nodes = (const int32_t*)(base + o.obs_nodes); h.obs_bary = (const double*)(base + o.obs_bary);
+    h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w); h.ref_node = (const int32_t*)(base + o.ref);
+    h.star_node = (const int32_t*)(base + o.star); h.star_sL = (const double*)(base + o.sL); h.str_nodes = (const int32_t*)(base + o.strn);
+    h.str_L0 = (const double*)(base + o.strL); h.blk_rc = (const int32_t*)(base + o.rc); h.blk_ptr = (const int32_t*)(base + o.ptr);
+    h.contrib = (const uint32_t*)(base + o.contrib); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
+    h.xyz = (double*)(base + w.xyz); h.xyz_bak = (double*)(base + w.bak); h.pose = (double*)(base + w.pose);
+    h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
+    h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
+    h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc);
+    h.x = (double*)(base + w.x); h.chi2_obs = (double*)(base + w.chi2); h.final_err = (double*)(base + w.ferr);
+    h.trace = (double*)(base + w.trace); h.info = (int32_t*)(base + w.info); h.dbg = (double*)(base + w.dbg);
+    c->h_probs[b] = h;
+  }
+  std::memcpy(&st[o_tab], c->h_probs.data(), sizeof(SftDev) * B);
+  HIPCHK(c, hipMemcpyAsync(base, st.data(), c->ro_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(base + c->ro_bytes, 0, a.size - c->ro_bytes, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->d_probs = (SftDev*)(base + o_tab);
+  c->B = B;
+  c->max_kd = max_kd;
+  c->ran = false;
+  return DSH_OK;
+}
+
+int dsh_sft_batch_run(dsh_ctx* c) {
+  if (!c) return DSH_ERR_ARG;
+  if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->stream));
+  c->ran = true;
+  return DSH_OK;
+}
+
+int dsh_sft_batch_counts(dsh_ctx* c, int64_t* iters, int64_t* trials) {
+  if (!c || c->B <= 0 || !c->ran) return DSH_ERR_STATE;
+  (void)hipSetDevice(c->device);
+  int64_t it = 0, tr = 0;
+  for (int b = 0; b < c->B; b++) {
+    int32_t info[4];
+    HIPCHK(c, hipMemcpy(info, c->h_probs[b].info, sizeof(info), hipMemcpyDeviceToHost));
+    it += info[0];
+    tr += info[1];
+  }
+  if (iters) *iters = it;
+  if (trials) *trials = tr;
+  return DSH_OK;
+}
+
+int dsh_sft_batch_problem_info(dsh_ctx* c, int b, int64_t* bytes, int32_t* counts) {
+  if (!c || b < 0 || b >= c->B) return DSH_ERR_ARG;
+  const Packed& P = c->packed[b];
+  const SftDev& h = P.h;
+  // materialised-Jacobian convention, reference edge counts (curvature unfused)
+  const int64_t M = h.M, n = h.n, C = P.n_curv_ref, E = h.Es, V = h.V;
+  const int64_t reads = 60 * M + 24 * n + 88 + 92 * C + 16 * E + 28 * V;
+  const int64_t writes = 8 * (30 * M + 21 * C + 6 * E + 9 * V) + 8 * (2 * M + C + E + 3 * V) + 8 * M;
+  if (bytes) *bytes = reads + writes;
+  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; }
+  return DSH_OK;
+}
+
+int dsh_sft_batch_download(dsh_ctx* c, int B, dsh_sft_result* res) {
+  if (!c || !res || B != c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_download: bad argument");
+  if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_download: no run");
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int b = 0; b < B; b++) {
+    const SftDev& h = c->h_probs[b];
+    const Packed& P = c->packed[b];
+    dsh_sft_result& r = res[b];
+    std::vector<double> xyz(3 * (size_t)h.n), chi2(h.M), ferr(h.M);
+    double pose[8];
+    int32_t info[4];
+    HIPCHK(c, hipMemcpy(xyz.data(), h.xyz, 8 * xyz.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(chi2.data(), h.chi2_obs, 8 * (size_t)h.M, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ferr.data(), h.final_err, 8 * (size_t)h.M, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pose, h.pose, 8 * 7, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(info, h.info, sizeof(info), hipMemcpyDeviceToHost));
+    if (r.trace) HIPCHK(c, hipMemcpy(r.trace, h.trace, 8 * DSH_TRACE_STRIDE * (size_t)std::max(P.max_iters, 0), hipMemcpyDeviceToHost));
+    // classification + statistics exactly as DefOptimizer.cc:515-559 (float chi2, sequential sums)
+    int nbad = 0;
+    double sum = 0.0;
+    unsigned cnt = 0;
+    for (int m = 0; m < h.M; m++) {
+      const float cf = (float)chi2[m];
+      const bool bad = cf > 5.991;
+      if (r.outlier) r.outlier[m] = bad ? 1 : 0;
+      if (bad) nbad++;
+      else { sum += ferr[m]; cnt++; }
+    }
+    r.rep_error = sum / cnt;
+    r.inliers = h.M - nbad;
+    r.iters = info[0];
+    r.trials = info[1];
+    r.status = info[2];
+    r.dim = 6 + h.Dn;
+    r.half_bandwidth = h.kd;
+    if (r.chi2_obs) std::memcpy(r.chi2_obs, chi2.data(), 8 * (size_t)h.M);
+    if (r.xyz) std::memcpy(r.xyz, xyz.data(), 8 * xyz.size());
+    if (r.pose7) std::memcpy(r.pose7, pose, 8 * 7);
+    if (r.Tcw) Tcw_from_pose7(pose, r.Tcw);
+    if (r.mappoint_xyz)  // DefMapPoint::RecalculatePosition (DefMapPoint.cc:129-147)
+      for (int m = 0; m < h.M; m++)
+        for (int k = 0; k < 3; k++) {
+          const int32_t* nd = &P.obs_nodes[3 * m];
+          const double* bb = &P.obs_bary[3 * m];
+          r.mappoint_xyz[3 * m + k] = (float)(bb[0] * xyz[3 * nd[0] + k] + bb[1] * xyz[3 * nd[1] + k] + bb[2] * xyz[3 * nd[2] + k]);
+        }
+  }
+  return DSH_OK;
+}
+
+int dsh_sft_solve(dsh_ctx* c, const dsh_sft_frame* frame, dsh_sft_result* result) {
+  if (!c || !frame || !result) return fail(c, DSH_ERR_ARG, "dsh_sft_solve: bad argument");
+  int rc = dsh_sft_batch_upload(c, 1, frame);
+  if (rc != DSH_OK) return rc;
+  rc = dsh_sft_batch_run(c);
+  if (rc != DSH_OK) return rc;
+  return dsh_sft_batch_download(c, 1, result);
+}
+
+int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, double* chi2) {
+  if (!c || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: bad argument");
+  (void)hipSetDevice(c->device);
+  SftDev h = c->h_probs[b];
+  if (D != 6 + h.Dn) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: D mismatch");
+  // flip the mode of this one problem, run it alone, restore
+  h.mode = 1;
+  HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
+  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  h.mode = 0;
+  HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
+  const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
+  std::vector<double> Hb(Dnp * h.ldh), Hbord(SFT_BORDER * Dnp), Hc(56);
+  HIPCHK(c, hipMemcpy(Hb.data(), h.Hb, 8 * Hb.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(Hbord.data(), h.Hbord, 8 * Hbord.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(Hc.data(), h.Hcorner, 8 * 49, hipMemcpyDeviceToHost));
+  if (chi2) HIPCHK(c, hipMemcpy(chi2, h.dbg, 8, hipMemcpyDeviceToHost));
+  // reference index order: camera 0..5, node a -> 6+3a
+  if (H) {
+    std::fill(H, H + (size_t)D * D, 0.0);
+    for (int r = 0; r < h.Dn; r++)
+      for (int k = 0; k <= h.kd; k++) {
+        const int cidx = r - h.kd + k;
+        if (cidx < 0) continue;
+        const double v = Hb[(size_t)r * h.ldh + k];
+        H[(size_t)(6 + r) + (size_t)(6 + cidx) * D] = v;
+        H[(size_t)(6 + cidx) + (size_t)(6 + r) * D] = v;
+      }
+    for (int k = 0; k < 6; k++)
+      for (int r = 0; r < h.Dn; r++) {
+        const double v = Hbord[(size_t)k * Dnp + r];
+        H[(size_t)k + (size_t)(6 + r) * D] = v;
+        H[(size_t)(6 + r) + (size_t)k * D] = v;
+      }
+    for (int r = 0; r < 6; r++)
+      for (int k = 0; k <= r; k++) {
+        H[(size_t)r + (size_t)k * D] = Hc[r * 7 + k];
+        H[(size_t)k + (size_t)r * D] = Hc[r * 7 + k];
+      }
+  }
+  if (bvec) {
+    for (int r = 0; r < 6; r++) bvec[r] = Hc[42 + r];
+    for (int r = 0; r < h.Dn; r++) bvec[6 + r] = Hbord[(size_t)6 * Dnp + r];
+  }
+  return DSH_OK;
+}
+
+}  // extern "C"

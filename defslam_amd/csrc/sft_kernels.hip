@@ -1,0 +1,784 @@
+// Shape-from-Template Levenberg-Marquardt solve on gfx950 (MI355X), FP64.
+//
+// One workgroup (SFT_NT = 1024 threads = 16 wavefronts = one CU) owns one problem and runs the
+// whole optimisation of defSLAM::Optimizer::DefPoseOptimization on the device:
+//
+//   residuals + Jacobians ... sft_types.h:102-133,137-206 (EdgeNodesCamera), :257-311
+//                             (EdgeMeanCurvature), :351-377 (EdgesStreching), :401-408 (EdgesReference)
+//   robust weights .......... robust_kernel_impl.cpp:78-91, base_edge.h:96-102
+//   normal equations ........ base_multi_edge.hpp:171-222, base_binary_edge.hpp:57-131,
+//                             base_unary_edge.hpp:43-72, block_solver.hpp:502-560
+//   damping / accept-reject . optimization_algorithm_levenberg.cpp:61-189
+//   linear solve ............ replaces block_solver.hpp:356-365 + linear_solver_dense.h:65-113
+//                             (dense Eigen::LDLT of the full (6+3n)^2 matrix) by a banded Cholesky
+//                             of the node block with the camera as a dense border (arrowhead)
+//   state update ............ sparse_optimizer.cpp:477-491, se3quat.h:223-257, types_sba.h:52-56
+//
+// Every sum is evaluated in a fixed order (no atomics), so a run is bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <float.h>
+#include "sft_problem.h"
+
+#define NB 32  // panel width of the blocked band Cholesky
+
+namespace {
+
+struct Ctl {       // LDS-resident control block, written by thread 0
+  double R[9], t[3];
+  double lambda, ni, chi_cur, chi_tmp, chi_ini, rho, scale;
+  int fact_ok, qmax, nbad, stop, accepted, it;
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+  const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ void quat_from_R(const double* R, double* q) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t;
+    q[1] = (R[2] - R[6]) * t;
+    q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+}
+
+__device__ __forceinline__ void quat_unit_pos(double* q) {
+  if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= nrm; q[1] /= nrm; q[2] /= nrm; q[3] /= nrm;
+}
+
+// pose <- exp(delta) * pose, delta = [omega, upsilon] (types_six_dof_expmap.h:73-76)
+__device__ void pose_oplus(double* pose, const double* d) {
+  const double om0 = d[0], om1 = d[1], om2 = d[2];
+  const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+  const double Om[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+  double Om2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += Om[i * 3 + k] * Om[k * 3 + j];
+      Om2[i * 3 + j] = s;
+    }
+  double Rd[9], V[9];
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) { Rd[i] = ((i % 4 == 0 ? 1.0 : 0.0) + Om[i]) + Om2[i]; V[i] = Rd[i]; }
+  } else {
+    const double a = sin(theta) / theta;
+    const double b = (1 - cos(theta)) / (theta * theta);
+    const double c = (theta - sin(theta)) / (theta * theta * theta);
+    for (int i = 0; i < 9; i++) {
+      const double id = (i % 4 == 0) ? 1.0 : 0.0;
+      Rd[i] = (id + a * Om[i]) + b * Om2[i];
+      V[i] = (id + b * Om[i]) + c * Om2[i];
+    }
+  }
+  double qd[4], td[3];
+  quat_from_R(Rd, qd);
+  quat_unit_pos(qd);
+  for (int i = 0; i < 3; i++) td[i] = V[i * 3] * d[3] + V[i * 3 + 1] * d[4] + V[i * 3 + 2] * d[5];
+  // t <- td + qd (x) t
+  const double* q = pose + 3;
+  const double v0 = pose[0], v1 = pose[1], v2 = pose[2];
+  double uv0 = qd[1] * v2 - qd[2] * v1, uv1 = qd[2] * v0 - qd[0] * v2, uv2 = qd[0] * v1 - qd[1] * v0;
+  uv0 += uv0; uv1 += uv1; uv2 += uv2;
+  const double c0 = qd[1] * uv2 - qd[2] * uv1, c1 = qd[2] * uv0 - qd[0] * uv2, c2 = qd[0] * uv1 - qd[1] * uv0;
+  const double nt0 = td[0] + (v0 + qd[3] * uv0 + c0);
+  const double nt1 = td[1] + (v1 + qd[3] * uv1 + c1);
+  const double nt2 = td[2] + (v2 + qd[3] * uv2 + c2);
+  double nq[4];
+  nq[3] = qd[3] * q[3] - qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2];
+  nq[0] = qd[3] * q[0] + qd[0] * q[3] + qd[1] * q[2] - qd[2] * q[1];
+  nq[1] = qd[3] * q[1] + qd[1] * q[3] + qd[2] * q[0] - qd[0] * q[2];
+  nq[2] = qd[3] * q[2] + qd[2] * q[3] + qd[0] * q[1] - qd[1] * q[0];
+  quat_unit_pos(nq);
+  pose[0] = nt0; pose[1] = nt1; pose[2] = nt2;
+  pose[3] = nq[0]; pose[4] = nq[1]; pose[5] = nq[2]; pose[6] = nq[3];
+}
+
+// Deterministic block-wide sum of NV values per thread. red: LDS scratch of 16*NV doubles.
+// Result valid in out[0..NV) (LDS) after the call for every thread.
+template <int NV>
+__device__ void block_sum(double* v, double* red, double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double s = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave * NV + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0;
+    for (int w = 0; w < SFT_NT / 64; w++) s += red[w * NV + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+__device__ double block_max(double v, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double m = red[0];
+  for (int w = 1; w < SFT_NT / 64; w++) m = fmax(m, red[w]);
+  __syncthreads();
+  return m;
+}
+
+__device__ __forceinline__ void huber(const SftDev& P, double e2, double& rho0, double& rho1) {
+  if (e2 <= P.hub_dsqr) { rho0 = e2; rho1 = 1.0; }
+  else { const double sq = sqrt(e2); rho0 = 2 * sq * P.hub_delta - P.hub_dsqr; rho1 = P.hub_delta / sq; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Residuals (+ Jacobian records when WANT_J): returns the robust chi2 in ctl-independent LDS out[0]
+// ------------------------------------------------------------------------------------------
+template <bool WANT_J>
+__device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out) {
+  if (threadIdx.x == 0) {
+    quat_to_R(P.pose + 3, ctl->R);
+    ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2];
+  }
+  __syncthreads();
+  double R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) R[i] = ctl->R[i];
+  t[0] = ctl->t[0]; t[1] = ctl->t[1]; t[2] = ctl->t[2];
+  const double* xyz = P.xyz;
+  double chi = 0.0;
+  const int total = P.M + P.V + P.S + P.Es;
+  for (int idx = threadIdx.x; idx < total; idx += SFT_NT) {
+    if (idx < P.M) {
+      const int m = idx;
+      const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
+      const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
+      double p[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { p[0][k] = xyz[3 * n0 + k]; p[1][k] = xyz[3 * n1 + k]; p[2][k] = xyz[3 * n2 + k]; }
+      double pw[3], pc[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pw[k] = (b0 * p[0][k] + b1 * p[1][k]) + b2 * p[2][k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pc[k] = (R[3 * k] * pw[0] + R[3 * k + 1] * pw[1] + R[3 * k + 2] * pw[2]) + t[k];
+      const double e0 = P.obs_uv[2 * m] - ((pc[0] / pc[2]) * P.fx + P.cx);
+      const double e1 = P.obs_uv[2 * m + 1] - ((pc[1] / pc[2]) * P.fy + P.cy);
+      const double w = P.obs_w[m];
+      const double c2 = e0 * (w * e0) + e1 * (w * e1);
+      double rho0, rho1;
+      huber(P, c2, rho0, rho1);
+      chi += rho0;
+      P.chi2_obs[m] = c2;
+      if (WANT_J) {
+        double* rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
+        double c[3][3];
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) c[s][k] = (R[3 * k] * p[s][0] + R[3 * k + 1] * p[s][1] + R[3 * k + 2] * p[s][2]) + t[k];
+        const double x = (c[0][0] * b0 + c[1][0] * b1) + c[2][0] * b2;
+        const double y = (c[0][1] * b0 + c[1][1] * b1) + c[2][1] * b2;
+        const double z = (c[0][2] * b0 + c[1][2] * b1) + c[2][2] * b2;
+        const double z2 = z * z, fx = P.fx, fy = P.fy;
+        rec[0] = e0; rec[1] = e1; rec[2] = rho1 * w; rec[3] = c2;
+        rec[4] = x * y / z2 * fx;
+        rec[5] = -(1 + (x * x / z2)) * fx;
+        rec[6] = y / z * fx;
+        rec[7] = -1. / z * fx;
+        rec[8] = 0;
+        rec[9] = x / z2 * fx;
+        rec[10] = (1 + y * y / z2) * fy;
+        rec[11] = -x * y / z2 * fy;
+        rec[12] = -x / z * fy;
+        rec[13] = 0;
+        rec[14] = -1. / z * fy;
+        rec[15] = y / z2 * fy;
+        const double bb[3] = {b0, b1, b2};
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+          // the reference linearises each node at ITS OWN camera-frame depth (sft_types.h:176-205)
+          const double xs = c[s][0], ys = c[s][1], zs = c[s][2];
+          const double sc = -1. / zs;
+          const double t00 = sc * fx, t02 = sc * (-xs / zs * fx), t11 = sc * fy, t12 = sc * (-ys / zs * fy);
+#pragma unroll
+          for (int cc = 0; cc < 3; cc++) {
+            rec[16 + 6 * s + cc] = ((t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc]) * bb[s];
+            rec[16 + 6 * s + 3 + cc] = ((0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc]) * bb[s];
+          }
+        }
+      }
+    } else if (idx < P.M + P.V) {
+      const int v = idx - P.M;
+      const int nd = P.ref_node[v];
+      const double e0 = xyz[3 * nd] - P.xyz0[3 * nd], e1 = xyz[3 * nd + 1] - P.xyz0[3 * nd + 1], e2 = xyz[3 * nd + 2] - P.xyz0[3 * nd + 2];
+      chi += (e0 * (P.w_ref * e0) + e1 * (P.w_ref * e1)) + e2 * (P.w_ref * e2);
+      if (WANT_J) { double* r = P.Jref + 4 * v; r[0] = e0; r[1] = e1; r[2] = e2; r[3] = 0; }
+    } else if (idx < P.M + P.V + P.S) {
+      const int s = idx - P.M - P.V;
+      const int nd = P.star_node[s];
+      double a0 = 0, a1 = 0, a2 = 0;
+      for (int q = P.nbr_ptr[nd]; q < P.nbr_ptr[nd + 1]; q++) {
+        const int j = P.nbr_idx[q];
+        const double wj = P.nbr_w[q];
+        a0 = a0 + wj * xyz[3 * j]; a1 = a1 + wj * xyz[3 * j + 1]; a2 = a2 + wj * xyz[3 * j + 2];
+      }
+      const double sw = P.nbr_sumw[nd];
+      const double m0 = xyz[3 * nd] - a0 / sw, m1 = xyz[3 * nd + 1] - a1 / sw, m2 = xyz[3 * nd + 2] - a2 / sw;
+      const double nrm = sqrt(m0 * m0 + m1 * m1 + m2 * m2);
+      const double r = nrm - P.k0[nd];
+      chi += (P.w_curv * P.star_sL[s]) * (r * r);
+      if (WANT_J) {
+        double* rr = P.Jstar + 4 * s;
+        if (nrm < 1E-15) { rr[0] = rr[1] = rr[2] = 0.0; }
+        else { rr[0] = m0 / nrm; rr[1] = m1 / nrm; rr[2] = m2 / nrm; }
+        rr[3] = r;
+      }
+    } else {
+      const int e = idx - P.M - P.V - P.S;
+      const int a = P.str_nodes[2 * e], b = P.str_nodes[2 * e + 1];
+      const double d0 = xyz[3 * a] - xyz[3 * b], d1 = xyz[3 * a + 1] - xyz[3 * b + 1], d2 = xyz[3 * a + 2] - xyz[3 * b + 2];
+      const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+      const double L0 = P.str_L0[e];
+      const double er = nrm * (1.0 / L0) - 1.0;
+      chi += er * (P.w_str * er);
+      if (WANT_J) {
+        const double ddo = 1.0 / (nrm * L0);
+        double* r = P.Jstr + 4 * e;
+        r[0] = d0 * ddo; r[1] = d1 * ddo; r[2] = d2 * ddo; r[3] = er;
+      }
+    }
+  }
+  block_sum<1>(&chi, red, out);
+  return out[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// Normal equations: gather per 3x3 block from the Jacobian records (fixed contribution order).
+// ------------------------------------------------------------------------------------------
+__device__ void assemble(const SftDev& P, double* red, double* out) {
+  const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
+  // camera corner: H_cc (lower 21) and b_c (6) as a block-wide reduction over the observations
+  {
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) acc[i] = 0.0;
+    for (int m = threadIdx.x; m < P.M; m += SFT_NT) {
+      const double* rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
+      const double wt = rec[2], e0 = rec[0], e1 = rec[1];
+      double j0[6], j1[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { j0[k] = rec[4 + k]; j1[k] = rec[10 + k]; }
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) acc[q++] += wt * (j0[r] * j0[c] + j1[r] * j1[c]);
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[21 + r] -= wt * (j0[r] * e0 + j1[r] * e1);
+    }
+    block_sum<27>(acc, red, out);
+    if (threadIdx.x == 0) {
+      int q = 0;
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c <= r; c++) P.Hcorner[r * 7 + c] = out[q++];
+      for (int r = 0; r < 6; r++) P.Hcorner[6 * 7 + r] = out[21 + r];
+      P.Hcorner[48] = 0.0;
+    }
+    __syncthreads();
+  }
+  const int kd = P.kd, ldh = P.ldh;
+  for (int q = threadIdx.x; q < P.nblk; q += SFT_NT) {
+    const int bi = P.blk_rc[2 * q], bj = P.blk_rc[2 * q + 1];
+    const bool diag = (bi == bj);
+    double H[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) H[i] = 0.0;
+    double Hc[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++) Hc[i] = 0.0;
+    double bn[3] = {0.0, 0.0, 0.0};
+    for (int p = P.blk_ptr[q]; p < P.blk_ptr[q + 1]; p++) {
+      const uint32_t rec = P.contrib[p];
+      const uint32_t kind = rec >> 30, s = (rec >> 26) & 15u, t = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
+      if (kind == SFT_KIND_OBS) {
+        const double* r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
+        const double wt = r[2];
+        const double* Js = r + 16 + 6 * s;
+        const double* Jt = r + 16 + 6 * t;
+        double js[6], jt[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { js[k] = Js[k]; jt[k] = Jt[k]; }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) H[3 * a + b] += wt * (js[a] * jt[b] + js[3 + a] * jt[3 + b]);
+        if (diag) {
+          const double e0 = r[0], e1 = r[1];
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) Hc[3 * k + a] += wt * (r[4 + k] * js[a] + r[10 + k] * js[3 + a]);
+#pragma unroll
+          for (int a = 0; a < 3; a++) bn[a] -= wt * (js[a] * e0 + js[3 + a] * e1);
+        }
+      } else if (kind == SFT_KIND_STAR) {
+        const double* r = P.Jstar + 4 * e;
+        const int nd = P.star_node[e];
+        const int base = P.nbr_ptr[nd];
+        const double cs = (s == 0) ? 1.0 : P.nbr_c[base + s - 1];
+        const double ct = (t == 0) ? 1.0 : P.nbr_c[base + t - 1];
+        const double wt = P.w_curv * P.star_sL[e];
+        const double u0 = r[0], u1 = r[1], u2 = r[2];
+        const double f = wt * (cs * ct);
+        H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
+        H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
+        H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
+        if (diag) {
+          const double g = wt * cs * r[3];
+          bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
+        }
+      } else if (kind == SFT_KIND_STR) {
+        const double* r = P.Jstr + 4 * e;
+        const double sg = ((s == 0) == (t == 0)) ? P.w_str : -P.w_str;
+        const double g0 = r[0], g1 = r[1], g2 = r[2];
+        H[0] += sg * (g0 * g0); H[1] += sg * (g0 * g1); H[2] += sg * (g0 * g2);
+        H[3] += sg * (g1 * g0); H[4] += sg * (g1 * g1); H[5] += sg * (g1 * g2);
+        H[6] += sg * (g2 * g0); H[7] += sg * (g2 * g1); H[8] += sg * (g2 * g2);
+        if (diag) {
+          const double g = (s == 0 ? P.w_str : -P.w_str) * r[3];
+          bn[0] -= g * g0; bn[1] -= g * g1; bn[2] -= g * g2;
+        }
+      } else {  // SFT_KIND_REF (diagonal only, J = I)
+        const double* r = P.Jref + 4 * e;
+        H[0] += P.w_ref; H[4] += P.w_ref; H[8] += P.w_ref;
+        bn[0] -= P.w_ref * r[0]; bn[1] -= P.w_ref * r[1]; bn[2] -= P.w_ref * r[2];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int r = 3 * bi + a;
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const int c = 3 * bj + b;
+        if (c <= r) P.Hb[(size_t)r * ldh + (c - r + kd)] = H[3 * a + b];
+      }
+    }
+    if (diag) {
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) P.Hbord[(size_t)k * Dnp + 3 * bi + a] = Hc[3 * k + a];
+#pragma unroll
+      for (int a = 0; a < 3; a++) P.Hbord[(size_t)6 * Dnp + 3 * bi + a] = bn[a];
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Banded Cholesky of (H + lambda I) with the 7-row border, right-looking, NB-wide panels.
+//   Lb    : lower band factor (row-major band), Lbord rows 0-5: L_cam,node ; row 6: forward-solved b
+//   panel : LDS, k-major: panel[k*LDP + row], row = 0..nb+m+7
+// Returns (in ctl->fact_ok) 0 when a pivot is not positive (== Eigen LDLT !isPositive()).
+// ------------------------------------------------------------------------------------------
+__device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, double* red) {
+  const int Dn = P.Dn, kd = P.kd, ldh = P.ldh;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  const double lambda = ctl->lambda;
+  const int tid = threadIdx.x;
+  // working copy L <- H + lambda I
+  for (size_t i = tid; i < (size_t)Dnp * ldh; i += SFT_NT) {
+    double v = P.Hb[i];
+    const int k = (int)(i % ldh);
+    const int r = (int)(i / ldh);
+    if (k == kd && r < Dn) v += lambda;
+    P.Lb[i] = v;
+  }
+  for (size_t i = tid; i < (size_t)SFT_BORDER * Dnp; i += SFT_NT) P.Lbord[i] = P.Hbord[i];
+  if (tid < 49) {
+    double v = P.Hcorner[tid];
+    if (tid % 8 == 0 && tid < 48) v += lambda;  // diagonal of the 6x6 camera block
+    P.Lcorner[tid] = v;
+  }
+  if (tid == 0) ctl->fact_ok = 1;
+  __syncthreads();
+
+  for (int j0 = 0; j0 < Dnp; j0 += NB) {
+    const int m = min(kd, Dnp - j0 - NB);   // band rows below the diagonal block
+    const int rows = NB + m + SFT_BORDER;   // panel rows
+    const int LDP = rows | 1;               // odd leading dimension
+    // ---- load + factor the panel, one thread per row, row kept in registers ----------------
+    // raw diagonal block (lower) goes to LDS first so every thread can rebuild pivots
+    double* diagraw = panel + (size_t)NB * LDP;          // NB*NB, [r*NB + c]
+    double* lrow = diagraw + NB * NB;                    // finalised rows of the diagonal block [r*NB + c]
+    if (tid < NB * NB) {
+      const int r = tid / NB, c = tid % NB;
+      double v = 0.0;
+      if (c <= r) v = P.Lb[(size_t)(j0 + r) * ldh + (c - r + kd)];
+      diagraw[tid] = v;
+    }
+    __syncthreads();
+    {
+      const bool active = tid < rows;
+      const bool wave_active = (tid & ~63) < rows;   // wave-uniform: idle waves only take part in the barriers
+      const int pr = tid;                            // panel row
+      double a[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) a[k] = 0.0;
+      if (active) {
+        if (pr < NB + m) {
+          const int r = j0 + pr;
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            const int c = j0 + k;
+            if (c <= r && r - c <= kd) a[k] = P.Lb[(size_t)r * ldh + (c - r + kd)];
+          }
+        } else {
+          const int br = pr - NB - m;
+#pragma unroll
+          for (int k = 0; k < NB; k++) a[k] = P.Lbord[(size_t)br * Dnp + j0 + k];
+        }
+      }
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        if (wave_active) {
+          // d = A[k][k] - sum_j L[k][j]^2 ; v = a[k] - sum_j a[j] L[k][j]   (j < k), two chains each
+          double d0 = diagraw[k * NB + k], d1 = 0.0, v0 = a[k], v1 = 0.0;
+#pragma unroll
+          for (int j = 0; j + 1 < k; j += 2) {
+            const double l0 = lrow[k * NB + j], l1 = lrow[k * NB + j + 1];
+            d0 -= l0 * l0; d1 -= l1 * l1;
+            v0 -= a[j] * l0; v1 -= a[j + 1] * l1;
+          }
+          if (k & 1) { const double l0 = lrow[k * NB + k - 1]; d0 -= l0 * l0; v0 -= a[k - 1] * l0; }
+          const double d = d0 + d1;
+          if (!(d > 0.0)) bad = true;
+          const double piv = sqrt(d);
+          const double v = v0 + v1;
+          a[k] = (pr == k) ? piv : ((pr < k) ? 0.0 : v / piv);
+          if (pr < NB && pr >= k) lrow[pr * NB + k] = a[k];
+        }
+        if (k + 1 < NB) __syncthreads();   // row k+1 of the diagonal block must be complete before step k+1
+      }
+      if (bad && tid == 0) ctl->fact_ok = 0;
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) panel[(size_t)k * LDP + pr] = a[k];
+        if (pr < NB + m) {
+          const int r = j0 + pr;
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            const int c = j0 + k;
+            if (c <= r && r - c <= kd) P.Lb[(size_t)r * ldh + (c - r + kd)] = a[k];
+          }
+        } else {
+          const int br = pr - NB - m;
+#pragma unroll
+          for (int k = 0; k < NB; k++) P.Lbord[(size_t)br * Dnp + j0 + k] = a[k];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- trailing update: window rows/cols [0, m+7) relative to j0+NB ----------------------
+    const int W = m + SFT_BORDER;
+    const int T = (W + 3) >> 2;
+    const int ntiles = T * (T + 1) / 2;
+    for (int q = tid; q < ntiles; q += SFT_NT) {
+      int ti = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
+      while (ti * (ti + 1) / 2 > q) ti--;
+      const int tj = q - ti * (ti + 1) / 2;
+      const int r0 = 4 * ti, c0 = 4 * tj;
+      double acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < NB; k++) {
+        const double* col = panel + (size_t)k * LDP + NB;
+        double ar[4], ac[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ar[i] = (r0 + i < W) ? col[r0 + i] : 0.0; ac[i] = (c0 + i < W) ? col[c0 + i] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] += ar[i] * ac[j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int rr = r0 + i;
+        if (rr >= W) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int cc = c0 + j;
+          if (cc > rr || cc >= W) continue;
+          double* dst;
+          if (rr < m) {
+            const int Rg = j0 + NB + rr, Cg = j0 + NB + cc;
+            dst = &P.Lb[(size_t)Rg * ldh + (Cg - Rg + kd)];
+          } else if (cc < m) {
+            dst = &P.Lbord[(size_t)(rr - m) * Dnp + j0 + NB + cc];
+          } else {
+            dst = &P.Lcorner[(rr - m) * 7 + (cc - m)];
+          }
+          *dst -= acc[i][j];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- corner: Cholesky of the 6x6 Schur complement, forward-solve its right-hand side, x_cam ---
+  double* x = P.x;
+  if (tid == 0) {
+    double* C = P.Lcorner;
+    bool bad = false;
+    for (int k = 0; k < 6; k++) {
+      double d = C[k * 7 + k];
+      for (int j = 0; j < k; j++) d -= C[k * 7 + j] * C[k * 7 + j];
+      if (!(d > 0.0)) bad = true;
+      const double piv = sqrt(d);
+      C[k * 7 + k] = piv;
+      for (int r = k + 1; r < 7; r++) {
+        double v = C[r * 7 + k];
+        for (int j = 0; j < k; j++) v -= C[r * 7 + j] * C[k * 7 + j];
+        C[r * 7 + k] = v / piv;
+      }
+    }
+    if (bad) ctl->fact_ok = 0;
+    if (ctl->fact_ok)
+    for (int k = 5; k >= 0; k--) {
+      double v = C[6 * 7 + k];
+      for (int r = k + 1; r < 6; r++) v -= C[r * 7 + k] * x[Dnp + r];
+      x[Dnp + k] = v / C[k * 7 + k];
+    }
+  }
+  __syncthreads();
+  // ---- back substitution over the node blocks (L^T x = y - Lcn^T x_cam) ----------------------
+  // (skipped when the factorisation failed: like g2o, x then keeps its previous content)
+  if (ctl->fact_ok) {
+    double* tvec = panel;            // NB
+    double* part = panel + NB;       // 32 parts x NB
+    double* dblk = part + 32 * NB;   // NB x NB diagonal block of L
+    const int c = tid & (NB - 1), pidx = tid / NB;  // 32 columns x 32 parts
+    double xc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xc[i] = x[Dnp + i];
+    for (int j0 = Dnp - NB; j0 >= 0; j0 -= NB) {
+      const int C = j0 + c;
+      double s = 0.0;
+      const int rend = min(Dnp - 1, C + kd);
+      for (int Rr = j0 + NB + pidx; Rr <= rend; Rr += 32) s += P.Lb[(size_t)Rr * ldh + (C - Rr + kd)] * x[Rr];
+      if (pidx < 6) s += P.Lbord[(size_t)pidx * Dnp + C] * xc[pidx];
+      part[pidx * NB + c] = s;
+      {
+        const int r = tid / NB, cc2 = tid % NB;
+        dblk[tid] = (cc2 <= r) ? P.Lb[(size_t)(j0 + r) * ldh + (cc2 - r + kd)] : 0.0;
+      }
+      __syncthreads();
+      if (tid < NB) {
+        double s2 = 0.0;
+        for (int p2 = 0; p2 < 32; p2++) s2 += part[p2 * NB + tid];
+        tvec[tid] = P.Lbord[(size_t)6 * Dnp + j0 + tid] - s2;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        double tv = (tid < NB) ? tvec[tid] : 0.0;
+        for (int k = NB - 1; k >= 0; k--) {
+          const double xk = __shfl(tv, k, 64) / dblk[k * NB + k];
+          if (tid == k) tv = xk;
+          else if (tid < k) tv -= dblk[k * NB + tid] * xk;
+        }
+        if (tid < NB) x[j0 + tid] = tv;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The persistent per-problem kernel
+// ------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev* __restrict__ probs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);   // 16*27 doubles
+  double* out = red + 16 * 27 + 5;                        // 27 doubles
+  double* panel = out + 32;
+  const int tid = threadIdx.x;
+  const int Dn = P.Dn, ldh = P.ldh, kd = P.kd;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+
+  // ---- initial state, zeroed system with identity padding --------------------------------
+  for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz[i] = P.xyz_init[i];
+  if (tid < 7) P.pose[tid] = P.pose_init[tid];
+  for (size_t i = tid; i < (size_t)Dnp * ldh; i += SFT_NT) {
+    const int k = (int)(i % ldh), r = (int)(i / ldh);
+    P.Hb[i] = (k == kd && r >= Dn) ? 1.0 : 0.0;
+  }
+  for (size_t i = tid; i < (size_t)SFT_BORDER * Dnp; i += SFT_NT) P.Hbord[i] = 0.0;
+  for (int i = tid; i < Dnp + 6; i += SFT_NT) P.x[i] = 0.0;
+  if (tid == 0) {
+    ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
+    P.info[0] = 0; P.info[1] = 0; P.info[2] = 0;
+  }
+  __syncthreads();
+
+  if (P.mode == 1) {  // test hook: one assembly at the initial state
+    const double chi = eval_edges<true>(P, ctl, red, out);
+    assemble(P, red, out);
+    if (tid == 0) P.dbg[0] = chi;
+    return;
+  }
+
+  int total_trials = 0, iters = 0;
+  for (int it = 0; it < P.max_iters; it++) {
+    const double chi0 = eval_edges<true>(P, ctl, red, out);
+    assemble(P, red, out);
+    if (it == 0) {
+      double mx = 0.0;
+      for (int r = tid; r < Dn; r += SFT_NT) mx = fmax(mx, fabs(P.Hb[(size_t)r * ldh + kd]));
+      if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+      mx = block_max(mx, red);
+      if (tid == 0) { ctl->lambda = 1e-5 * mx; ctl->ni = 2.0; ctl->nbad = 0; }
+    }
+    if (tid == 0) { ctl->chi_cur = chi0; ctl->chi_ini = chi0; ctl->qmax = 0; ctl->rho = 0.0; ctl->accepted = 0; }
+    __syncthreads();
+    const double lambda_start = ctl->lambda;
+    int all_ok = 1;
+    bool again;
+    do {
+      // push
+      for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz_bak[i] = P.xyz[i];
+      double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
+      factor_and_solve(P, ctl, panel, red);
+      const int ok = ctl->fact_ok;
+      all_ok &= ok;
+      // update
+      for (int i = tid; i < 3 * P.n; i += SFT_NT) {
+        const int a = P.act[i / 3];
+        if (a >= 0) P.xyz[i] += P.x[3 * a + (i % 3)];
+      }
+      if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
+      // scale = sum_j x_j (lambda x_j + b_j)
+      double sc = 0.0;
+      const double lam = ctl->lambda;
+      for (int r = tid; r < Dn; r += SFT_NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
+      if (tid < 6) { const double xv = P.x[Dnp + tid]; sc += xv * (lam * xv + P.Hcorner[42 + tid]); }
+      __syncthreads();
+      block_sum<1>(&sc, red, out);
+      const double scale = out[0];
+      __syncthreads();
+      const double chi_new = eval_edges<false>(P, ctl, red, out);
+      if (tid == 0) {
+        double tempChi = ok ? chi_new : DBL_MAX;
+        double rho = (ctl->chi_cur - tempChi);
+        rho /= (scale + 1e-3);
+        ctl->rho = rho;
+        if (rho > 0 && isfinite(tempChi)) {
+          double alpha = 1. - pow((2 * rho - 1), 3);
+          alpha = fmin(alpha, 2. / 3.);
+          const double sf = fmax(1. / 3., alpha);
+          ctl->lambda *= sf; ctl->ni = 2.0; ctl->chi_cur = tempChi; ctl->accepted = 1;
+          ctl->stop = 0;
+        } else {
+          ctl->lambda *= ctl->ni; ctl->ni *= 2.0;
+          ctl->stop = 1;  // reused as "restore" flag below
+        }
+        ctl->qmax++;
+      }
+      __syncthreads();
+      if (ctl->stop) {  // pop
+        for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz[i] = P.xyz_bak[i];
+        if (tid < 7) P.pose[tid] = pose_bak;
+      }
+      again = (ctl->rho < 0) && (ctl->qmax < 10);
+      __syncthreads();
+    } while (again);
+    total_trials += ctl->qmax;
+    iters++;
+    if (tid == 0 && P.trace) {
+      double* t = P.trace + it * 8;
+      t[0] = ctl->chi_ini; t[1] = lambda_start; t[2] = ctl->qmax; t[3] = ctl->chi_cur; t[4] = ctl->lambda; t[5] = ctl->rho;
+      t[6] = ctl->accepted; t[7] = all_ok;
+    }
+    if (tid == 0 && !all_ok) P.info[2] |= 1;
+    bool term = (ctl->qmax == 10) || (ctl->rho == 0);
+    if (!term) {
+      if (tid == 0) {
+        if ((ctl->chi_ini - ctl->chi_cur) * 1e3 < ctl->chi_ini) ctl->nbad++; else ctl->nbad = 0;
+      }
+      __syncthreads();
+      term = ctl->nbad >= 3;
+    }
+    __syncthreads();
+    if (term) break;
+  }
+  // final reprojection error norms at the final estimate (DefOptimizer.cc:538-559)
+  if (tid == 0) { quat_to_R(P.pose + 3, ctl->R); ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2]; }
+  __syncthreads();
+  for (int m = tid; m < P.M; m += SFT_NT) {
+    const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
+    const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
+    double pw[3], pc[3];
+    for (int k = 0; k < 3; k++) pw[k] = (b0 * P.xyz[3 * n0 + k] + b1 * P.xyz[3 * n1 + k]) + b2 * P.xyz[3 * n2 + k];
+    for (int k = 0; k < 3; k++) pc[k] = (ctl->R[3 * k] * pw[0] + ctl->R[3 * k + 1] * pw[1] + ctl->R[3 * k + 2] * pw[2]) + ctl->t[k];
+    const double e0 = P.obs_uv[2 * m] - ((pc[0] / pc[2]) * P.fx + P.cx);
+    const double e1 = P.obs_uv[2 * m + 1] - ((pc[1] / pc[2]) * P.fy + P.cy);
+    P.final_err[m] = sqrt(e0 * e0 + e1 * e1);
+  }
+  if (tid == 0) { P.info[0] = iters; P.info[1] = total_trials; }
+}
+
+}  // namespace
+
+// LDS bytes the kernel needs for a problem with half-bandwidth kd
+extern "C" size_t sft_lm_kernel_lds_bytes(int kd) {
+  const size_t rows = NB + kd + SFT_BORDER;
+  const size_t LDP = rows | 1;
+  size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
+  const size_t backsub = NB + 32 * NB + NB * NB;
+  if (backsub > panel) panel = backsub;
+  return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
+}
+
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(sft_lm_kernel, dim3(B), dim3(SFT_NT), lds, stream, d_probs);
+  return hipGetLastError();
+}

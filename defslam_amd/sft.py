@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's SfT operator interface, on top of the C ABI.
+
+Reference interface being mirrored (Modules/Tracking/DefOptimizer.h:51-53):
+
+    int defSLAM::Optimizer::DefPoseOptimization(Frame* pFrame, Map* mMap, double RegLap = 5000,
+                                                double RegInex = 5000, double RegTemp = 0,
+                                                uint NeighboursLayers = 1);
+
+`DefPoseOptimization(ctx, frame, ...)` below has the same argument meaning, the same
+return value (inliers) and the same in-place side effects (frame pose, outlier flags,
+repError, node positions, map-point positions).  The ORB_SLAM2 Frame/Map objects are
+replaced by the flat `Frame` / `Context.template` views that a C++ shim would fill
+(INTEGRATION.md).  All compute happens in libdefslam_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+class DshError(RuntimeError):
+    pass
+
+
+def _ptr(a: Optional[np.ndarray], ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+@dataclass
+class Frame:
+    """The fields of ORB_SLAM2::Frame / DefMap the optimiser reads and writes."""
+    Tcw: np.ndarray                 # (4,4) float32, pFrame->mTcw (in/out)
+    K: np.ndarray                   # fx, fy, cx, cy
+    N: int                          # pFrame->N
+    obs_nodes: np.ndarray           # (M,3) int32  facet nodes (ascending) of each matched map point
+    obs_bary: np.ndarray            # (M,3) float64 DefMapPoint::b1,b2,b3
+    obs_uv: np.ndarray              # (M,2) float64 pFrame->mvKeysUn[i].pt
+    obs_invsig2: np.ndarray         # (M,)  float64 pFrame->mvInvLevelSigma2[octave]
+    nodes_xyz: np.ndarray           # (n,3) float64 Node::x,y,z (in/out)
+    mvbOutlier: np.ndarray = field(default=None)   # (M,) bool, written
+    repError: float = 0.0           # written
+    mappoints: np.ndarray = field(default=None)    # (M,3) float32, written (RecalculatePosition)
+    # diagnostics (not part of the reference interface)
+    pose7: np.ndarray = field(default=None)
+    chi2_obs: np.ndarray = field(default=None)
+    iters: int = 0
+    trials: int = 0
+    dim: int = 0
+    half_bandwidth: int = 0
+    status: int = 0
+    trace: np.ndarray = field(default=None)
+
+
+class Context:
+    """One GPU context (dsh_ctx): owns the template and the device buffers."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.dsh_create(C.byref(h), device)
+        if rc != _lib.DSH_OK:
+            raise DshError(f"dsh_create failed with status {rc} (no gfx950 device visible?)")
+        self._h = h
+        self.n = 0
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dsh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != _lib.DSH_OK:
+            raise DshError(f"{what}: status {rc}: {self._L.dsh_last_error(self._h).decode()}")
+
+    # ---- template ---------------------------------------------------------------------------
+    def template_build(self, xyz0: np.ndarray, facets: np.ndarray):
+        xyz0 = np.ascontiguousarray(xyz0, np.float64)
+        facets = np.ascontiguousarray(facets, np.int32)
+        self._check(self._L.dsh_template_build(self._h, xyz0.shape[0], _ptr(xyz0, C.c_double), facets.shape[0], _ptr(facets, C.c_int32)),
+                    "dsh_template_build")
+        self.n = xyz0.shape[0]
+
+    def template_set(self, xyz0, boundary, nbr_ptr, nbr_idx, nbr_w, k0, edge_nodes, edge_L0, median_L):
+        xyz0 = np.ascontiguousarray(xyz0, np.float64)
+        boundary = np.ascontiguousarray(boundary, np.uint8)
+        nbr_ptr = np.ascontiguousarray(nbr_ptr, np.int32)
+        nbr_idx = np.ascontiguousarray(nbr_idx, np.int32)
+        nbr_w = np.ascontiguousarray(nbr_w, np.float64)
+        k0 = np.ascontiguousarray(k0, np.float64)
+        edge_nodes = np.ascontiguousarray(edge_nodes, np.int32)
+        edge_L0 = np.ascontiguousarray(edge_L0, np.float64)
+        self._check(self._L.dsh_template_set(self._h, xyz0.shape[0], _ptr(xyz0, C.c_double), _ptr(boundary, C.c_uint8), _ptr(nbr_ptr, C.c_int32),
+                                             _ptr(nbr_idx, C.c_int32), _ptr(nbr_w, C.c_double), _ptr(k0, C.c_double), edge_L0.shape[0],
+                                             _ptr(edge_nodes, C.c_int32), _ptr(edge_L0, C.c_double), float(median_L)), "dsh_template_set")
+        self.n = xyz0.shape[0]
+
+    def template_get(self) -> dict:
+        n, E, nnz = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.dsh_template_dims(self._h, C.byref(n), C.byref(E), C.byref(nnz)), "dsh_template_dims")
+        out = dict(boundary=np.zeros(n.value, np.uint8), nbr_ptr=np.zeros(n.value + 1, np.int32), nbr_idx=np.zeros(nnz.value, np.int32),
+                   nbr_w=np.zeros(nnz.value), k0=np.zeros(n.value), edge_nodes=np.zeros((E.value, 2), np.int32), edge_L0=np.zeros(E.value))
+        med = C.c_double()
+        self._check(self._L.dsh_template_get(self._h, _ptr(out["boundary"], C.c_uint8), _ptr(out["nbr_ptr"], C.c_int32), _ptr(out["nbr_idx"], C.c_int32),
+                                             _ptr(out["nbr_w"], C.c_double), _ptr(out["k0"], C.c_double), _ptr(out["edge_nodes"], C.c_int32),
+                                             _ptr(out["edge_L0"], C.c_double), C.byref(med)), "dsh_template_get")
+        out["median_L"] = med.value
+        return out
+
+    def template_embed(self, pts: np.ndarray):
+        pts = np.ascontiguousarray(pts, np.float32)
+        P = pts.shape[0]
+        fid = np.zeros(P, np.int32)
+        nodes = np.zeros((P, 3), np.int32)
+        bary = np.zeros((P, 3), np.float32)
+        self._check(self._L.dsh_template_embed(self._h, P, _ptr(pts, C.c_float), _ptr(fid, C.c_int32), _ptr(nodes, C.c_int32), _ptr(bary, C.c_float)),
+                    "dsh_template_embed")
+        return fid, nodes, bary
+
+    # ---- batched SfT ------------------------------------------------------------------------
+    def _frame_c(self, f: Frame, reg_lap, reg_inex, reg_temp, layers, max_iters, keep: list) -> _lib.SftFrameC:
+        Tcw = np.ascontiguousarray(f.Tcw, np.float32)
+        nodes = np.ascontiguousarray(f.obs_nodes, np.int32)
+        bary = np.ascontiguousarray(f.obs_bary, np.float64)
+        uv = np.ascontiguousarray(f.obs_uv, np.float64)
+        isg = np.ascontiguousarray(f.obs_invsig2, np.float64)
+        xyz = np.ascontiguousarray(f.nodes_xyz, np.float64)
+        keep += [Tcw, nodes, bary, uv, isg, xyz]
+        fc = _lib.SftFrameC()
+        fc.Tcw = _ptr(Tcw, C.c_float)
+        for i in range(4):
+            fc.K[i] = float(f.K[i])
+        fc.n_frame = int(f.N)
+        fc.M = int(nodes.shape[0])
+        fc.obs_nodes = _ptr(nodes, C.c_int32)
+        fc.obs_bary = _ptr(bary, C.c_double)
+        fc.obs_uv = _ptr(uv, C.c_double)
+        fc.obs_invsig2 = _ptr(isg, C.c_double)
+        fc.xyz = _ptr(xyz, C.c_double)
+        fc.reg_lap, fc.reg_inex, fc.reg_temp = float(reg_lap), float(reg_inex), float(reg_temp)
+        fc.neighbour_layers = int(layers)
+        fc.max_iters = int(max_iters)
+        return fc
+
+    def batch_upload(self, frames: Sequence[Frame], RegLap=5000.0, RegInex=5000.0, RegTemp=0.0, NeighboursLayers=1, max_iters=50):
+        keep: list = []
+        arr = (_lib.SftFrameC * len(frames))()
+        for i, f in enumerate(frames):
+            arr[i] = self._frame_c(f, RegLap, RegInex, RegTemp, NeighboursLayers, max_iters, keep)
+        self._check(self._L.dsh_sft_batch_upload(self._h, len(frames), arr), "dsh_sft_batch_upload")
+        self._frames = list(frames)
+        self._max_iters = max_iters
+
+    def batch_run(self):
+        self._check(self._L.dsh_sft_batch_run(self._h), "dsh_sft_batch_run")
+
+    def synchronize(self):
+        self._check(self._L.dsh_synchronize(self._h), "dsh_synchronize")
+
+    def stream(self) -> int:
+        return int(self._L.dsh_stream(self._h) or 0)
+
+    def batch_counts(self):
+        it, tr = C.c_int64(), C.c_int64()
+        self._check(self._L.dsh_sft_batch_counts(self._h, C.byref(it), C.byref(tr)), "dsh_sft_batch_counts")
+        return it.value, tr.value
+
+    def problem_info(self, b: int):
+        nbytes = C.c_int64()
+        counts = np.zeros(6, np.int32)
+        self._check(self._L.dsh_sft_batch_problem_info(self._h, b, C.byref(nbytes), _ptr(counts, C.c_int32)), "dsh_sft_batch_problem_info")
+        return nbytes.value, counts
+
+    def batch_download(self) -> List[int]:
+        """Write results back into the uploaded Frame objects (the reference's in-place mutations,
+        DefOptimizer.cc:515-576) and return the per-frame inlier counts."""
+        frames = self._frames
+        res = (_lib.SftResultC * len(frames))()
+        keep = []
+        for i, f in enumerate(frames):
+            M, n = f.obs_nodes.shape[0], f.nodes_xyz.shape[0]
+            bufs = dict(Tcw=np.zeros((4, 4), np.float32), pose7=np.zeros(7), xyz=np.zeros((n, 3)), chi2=np.zeros(M), outl=np.zeros(M, np.uint8),
+                        mp=np.zeros((M, 3), np.float32), trace=np.zeros((max(self._max_iters, 1), _lib.DSH_TRACE_STRIDE)))
+            keep.append(bufs)
+            r = res[i]
+            r.Tcw = _ptr(bufs["Tcw"], C.c_float)
+            r.pose7 = _ptr(bufs["pose7"], C.c_double)
+            r.xyz = _ptr(bufs["xyz"], C.c_double)
+            r.chi2_obs = _ptr(bufs["chi2"], C.c_double)
+            r.outlier = _ptr(bufs["outl"], C.c_uint8)
+            r.mappoint_xyz = _ptr(bufs["mp"], C.c_float)
+            r.trace = _ptr(bufs["trace"], C.c_double)
+        self._check(self._L.dsh_sft_batch_download(self._h, len(frames), res), "dsh_sft_batch_download")
+        out = []
+        for i, f in enumerate(frames):
+            b, r = keep[i], res[i]
+            f.Tcw = b["Tcw"]
+            f.pose7 = b["pose7"]
+            f.nodes_xyz = b["xyz"]
+            f.chi2_obs = b["chi2"]
+            f.mvbOutlier = b["outl"].astype(bool)
+            f.mappoints = b["mp"]
+            f.repError = float(np.float32(r.rep_error))   # pFrame->repError is a float (Frame.h:213)
+            f.rep_error_f64 = r.rep_error
+            f.iters, f.trials, f.dim, f.half_bandwidth, f.status = r.iters, r.trials, r.dim, r.half_bandwidth, r.status
+            f.trace = b["trace"][:r.iters].copy()
+            out.append(int(r.inliers))
+        return out
+
+    def debug_system(self, b: int, D: int):
+        H = np.zeros((D, D), order="F")
+        bv = np.zeros(D)
+        chi = C.c_double()
+        self._check(self._L.dsh_sft_debug_system(self._h, b, D, _ptr(H, C.c_double), _ptr(bv, C.c_double), C.byref(chi)), "dsh_sft_debug_system")
+        return H, bv, chi.value
+
+
+def DefPoseOptimization(ctx: Context, pFrame: Frame, RegLap: float = 5000, RegInex: float = 5000, RegTemp: float = 0,
+                        NeighboursLayers: int = 1, max_iters: int = 50) -> int:
+    """Shape-from-template with camera motion estimation for one frame (DefOptimizer.cc:251-578)."""
+    ctx.batch_upload([pFrame], RegLap, RegInex, RegTemp, NeighboursLayers, max_iters)
+    ctx.batch_run()
+    return ctx.batch_download()[0]
+
+
+def DefPoseOptimizationBatch(ctx: Context, frames: Sequence[Frame], RegLap: float = 5000, RegInex: float = 5000, RegTemp: float = 0,
+                             NeighboursLayers: int = 1, max_iters: int = 50) -> List[int]:
+    """Independent problems (different frames / keyframes against the same template) in one launch."""
+    ctx.batch_upload(frames, RegLap, RegInex, RegTemp, NeighboursLayers, max_iters)
+    ctx.batch_run()
+    return ctx.batch_download()
+
+
+def frame_from_synth(fr) -> Frame:
+    return Frame(Tcw=fr.Tcw.copy(), K=fr.K.copy(), N=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary, obs_uv=fr.obs_uv,
+                 obs_invsig2=fr.obs_invsig2, nodes_xyz=fr.xyz.copy())

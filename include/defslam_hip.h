@@ -1,0 +1,125 @@
+/*
+ * defslam_hip.h -- C ABI of libdefslam_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the two DefSLAM hot paths:
+ *   A. defSLAM::Optimizer::DefPoseOptimization(Frame*, Map*, RegLap, RegInex, RegTemp, layers)
+ *        -- Modules/Tracking/DefOptimizer.h:51-53, DefOptimizer.cc:251-578 (g2o LM + dense LDLT)
+ *   B. defSLAM::NormalEstimator::ObtainK1K2()       -- Modules/Mapping/NormalEstimator.h:46-53
+ *      BBS::eval / Warps::Warp estimates            -- Thirdparty/BBS/bbs.h:52-66
+ *
+ * Conventions: plain pointers + sizes, caller-owned host buffers, every entry point
+ * returns an int status (DSH_OK == 0); nothing throws or aborts across the ABI.  A context
+ * is bound to one GPU and is not thread-safe (one context per host thread / per GPU),
+ * mirroring the reference where each optimiser call runs on exactly one thread
+ * (DefOptimizer.cc:287 holds MapPoint::mGlobalMutex for its whole body).
+ * All floating point is FP64 unless a parameter says float (the reference's float32
+ * boundaries: cv::Mat pose, keypoints, DefMapPoint world positions).
+ */
+#ifndef DEFSLAM_HIP_H
+#define DEFSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSH_OK 0
+#define DSH_ERR_ARG 1        /* bad argument / size */
+#define DSH_ERR_HIP 2        /* HIP runtime failure (see dsh_last_error) */
+#define DSH_ERR_STATE 3      /* call sequence violated (no template, no batch ...) */
+#define DSH_ERR_NO_DEVICE 4  /* no usable gfx950 device */
+
+#define DSH_TRACE_STRIDE 8   /* doubles per outer LM iteration in the trace buffer:
+                                chi2_start, lambda_start, trials, chi2_end, lambda_end, rho, accepted, factor_ok */
+#define DSH_MAX_ITERS 64
+
+typedef struct dsh_ctx dsh_ctx;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int dsh_create(dsh_ctx** out, int device);
+int dsh_destroy(dsh_ctx* ctx);
+const char* dsh_last_error(const dsh_ctx* ctx);
+/* HIP stream handle (hipStream_t) the context launches on; lets a caller time with its own events. */
+void* dsh_stream(dsh_ctx* ctx);
+int dsh_synchronize(dsh_ctx* ctx);
+
+/* ---- template (replaces the numbers produced by Modules/Template) ------- */
+/* Derive every constant from vertices + facets the way the reference does:
+ * edges/rest lengths (Facet.cc:32-56, Edge.cc:29-59), 1-ring (Node.cc:114-129), Laplacian
+ * weights / boundary flags / initial mean curvature (LaplacianMesh.cc:53-162), median edge
+ * (Template.cc:158-175).  Ordering: nodes by index, edges by creation order. */
+int dsh_template_build(dsh_ctx* ctx, int n, const double* xyz0 /* n*3 */, int F, const int32_t* facets /* F*3 */);
+/* Or hand the constants over directly (what a host shim holding the reference's Template would do). */
+int dsh_template_set(dsh_ctx* ctx, int n, const double* xyz0, const uint8_t* boundary,
+                     const int32_t* nbr_rowptr /* n+1 */, const int32_t* nbr_col, const double* nbr_w,
+                     const double* k0 /* n */, int E, const int32_t* edge_nodes /* E*2 */, const double* edge_L0 /* E */,
+                     double median_L);
+/* Read back the constants of the current template (any pointer may be NULL; sizes via dsh_template_dims). */
+int dsh_template_dims(const dsh_ctx* ctx, int32_t* n, int32_t* E, int32_t* nnz_nbr);
+int dsh_template_get(const dsh_ctx* ctx, uint8_t* boundary, int32_t* nbr_rowptr, int32_t* nbr_col, double* nbr_w,
+                     double* k0, int32_t* edge_nodes, double* edge_L0, double* median_L);
+/* Barycentric embedding of P float32 points (TriangularMesh.cc:133-236): facet id (-1: none),
+ * facet node ids ascending, barycentrics (float32 arithmetic as in the reference). */
+int dsh_template_embed(const dsh_ctx* ctx, int P, const float* pts /* P*3 */, int32_t* facet_id, int32_t* nodes /* P*3 */,
+                       float* bary /* P*3 */);
+
+/* ---- Shape-from-Template solve ------------------------------------------------------------ */
+typedef struct dsh_sft_frame {
+  const float* Tcw;            /* 4x4 row-major float32 (cv::Mat pFrame->mTcw), initial camera pose */
+  double K[4];                 /* fx, fy, cx, cy */
+  int32_t n_frame;             /* pFrame->N: keypoints in the frame (DefOptimizer.cc:340 divides by it) */
+  int32_t M;                   /* observations that enter the graph (DefOptimizer.cc:293-361) */
+  const int32_t* obs_nodes;    /* M*3 node ids of the facet, ascending */
+  const double* obs_bary;      /* M*3 */
+  const double* obs_uv;        /* M*2 undistorted keypoints */
+  const double* obs_invsig2;   /* M   mvInvLevelSigma2[octave] */
+  const double* xyz;           /* n*3 current node positions */
+  double reg_lap, reg_inex, reg_temp;
+  int32_t neighbour_layers;    /* >=1: viewed nodes + 1-ring (the reference quirk, DefOptimizer.cc:388-406); 0: viewed only */
+  int32_t max_iters;           /* 50 in the reference (DefOptimizer.cc:513) */
+} dsh_sft_frame;
+
+typedef struct dsh_sft_result {
+  float* Tcw;                  /* 4x4 float32 out (Converter::toCvMat) */
+  double* pose7;               /* tx,ty,tz,qx,qy,qz,qw */
+  double* xyz;                 /* n*3 */
+  double* chi2_obs;            /* M: e^T Omega e of each observation at its last evaluation (DefOptimizer.cc:527) */
+  uint8_t* outlier;            /* M: (float)chi2 > 5.991 */
+  float* mappoint_xyz;         /* M*3 float32: DefMapPoint::RecalculatePosition of each observation's point */
+  double rep_error;            /* mean reprojection error over inliers (pFrame->repError) */
+  int32_t inliers;             /* return value of DefPoseOptimization */
+  int32_t iters;               /* outer LM iterations executed */
+  int32_t trials;              /* total damping trials (linear solves) */
+  int32_t dim;                 /* 6 + 3*active nodes */
+  int32_t half_bandwidth;      /* scalar half-bandwidth of the node block */
+  int32_t status;              /* 0, or bit 0: a factorisation failed at least once */
+  double* trace;               /* max_iters*DSH_TRACE_STRIDE doubles, may be NULL */
+} dsh_sft_result;
+
+/* One-shot: pack + upload + solve + download. */
+int dsh_sft_solve(dsh_ctx* ctx, const dsh_sft_frame* frame, dsh_sft_result* result);
+
+/* Batched / device-resident form (independent problems against the current template):
+ *   dsh_sft_batch_upload  packs B frames on the host and copies them to HBM,
+ *   dsh_sft_batch_run     launches the solve (asynchronous on dsh_stream); may be called
+ *                         repeatedly -- every run restarts from the uploaded initial state,
+ *   dsh_sft_batch_download copies results back. */
+int dsh_sft_batch_upload(dsh_ctx* ctx, int B, const dsh_sft_frame* frames);
+int dsh_sft_batch_run(dsh_ctx* ctx);
+int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
+/* Totals of the last completed run (valid after a synchronise): outer iterations and trials over the batch. */
+int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
+/* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts
+ * counts[6] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim. */
+int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int32_t* counts);
+
+/* Test hook: run only "residuals + Jacobians + normal equations" once at the uploaded state of
+ * problem b and return the dense system in the reference's index order (camera first, then active
+ * nodes ascending; column-major D x D) plus b and the robust chi2.  H/bvec may be NULL. */
+int dsh_sft_debug_system(dsh_ctx* ctx, int b, int32_t D, double* H, double* bvec, double* chi2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFSLAM_HIP_H */

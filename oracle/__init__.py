@@ -134,3 +134,33 @@ def sft_solve(tc: TemplateConsts, Tcw, K, n_frame, obs_nodes, obs_bary, obs_uv, 
         _p(Tout, C.c_float), _p(pose7, D), _p(xyz_out, D), _p(chi2, D), _p(outl, C.c_uint8), C.byref(rep), C.byref(it), C.byref(tr),
         _p(trace, D), _p(dims, C.c_int32))
     return SftResult(ret, Tout, pose7, xyz_out, chi2, outl, rep.value, it.value, tr.value, trace[:it.value].copy(), dims)
+
+
+def sft_system(tc: TemplateConsts, Tcw, K, n_frame, obs_nodes, obs_bary, obs_uv, obs_invsig2, xyz, reg_lap, reg_inex, reg_temp, layers=1):
+    """One 'residuals + Jacobians + normal equations' pass at the given state: (H dense, b, robust chi2)."""
+    L = lib()
+    L.sft_oracle_system.restype = C.c_int
+    M = int(obs_nodes.shape[0])
+    Tcw = np.ascontiguousarray(Tcw, dtype=np.float32)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    obs_nodes = np.ascontiguousarray(obs_nodes, dtype=np.int32)
+    obs_bary = np.ascontiguousarray(obs_bary, dtype=np.float64)
+    obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64)
+    obs_invsig2 = np.ascontiguousarray(obs_invsig2, dtype=np.float64)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    D = C.c_double
+
+    def call(Dexp, H, b, chi):
+        return L.sft_oracle_system(
+            tc.n, _p(tc.xyz0, D), _p(tc.boundary, C.c_uint8), _p(tc.nbr_ptr, C.c_int32), _p(tc.nbr_idx, C.c_int32), _p(tc.nbr_w, D),
+            _p(tc.k0, D), tc.E, _p(tc.edge_nodes, C.c_int32), _p(tc.edge_L0, D), _p(tc.inc_ptr, C.c_int32), _p(tc.inc_edge, C.c_int32),
+            D(tc.median_L), _p(Tcw, C.c_float), _p(K, D), int(n_frame), M, _p(obs_nodes, C.c_int32), _p(obs_bary, D), _p(obs_uv, D),
+            _p(obs_invsig2, D), _p(xyz, D), D(reg_lap), D(reg_inex), D(reg_temp), int(layers), int(Dexp),
+            _p(H, D) if H is not None else None, _p(b, D) if b is not None else None, C.byref(chi) if chi is not None else None)
+
+    dim = call(0, None, None, None)
+    H = np.zeros((dim, dim), order="F")
+    b = np.zeros(dim)
+    chi = C.c_double(0)
+    call(dim, H, b, chi)
+    return H, b, chi.value

@@ -605,19 +605,18 @@ static void build_system(graph_t* g, double* H, double* b) {
  * ldlt_mode: 0 = Eigen-style pivoted LDLT, 1 = blocked unpivoted.
  * Returns nInitialCorrespondences - nBad (DefOptimizer.cc:577), or -1 on bad input.
  */
-int sft_oracle_solve(
+/* Graph construction shared by the solve and the "one assembly" test hook. */
+typedef struct { uint8_t *viewed, *optlap, *eact; int nOptLap, nViewed, nCurv, nStretch; } graph_aux_t;
+
+static int graph_build(graph_t* gp, graph_aux_t* aux,
     int n, const double* xyz0, const uint8_t* boundary,
     const int32_t* nbr_ptr, const int32_t* nbr_idx, const double* nbr_w, const double* k0,
     int E, const int32_t* edge_nodes, const double* edge_L0,
     const int32_t* inc_ptr, const int32_t* inc_edge, double median_L,
     const float* Tcw_in, const double* K, int N_frame, int M,
     const int32_t* obs_nodes, const double* obs_bary, const double* obs_uv, const double* obs_invsig2,
-    const double* xyz_in,
-    double regLap, double regInex, double regTemp, int neighbours_layers, int max_iters, int ldlt_mode,
-    float* Tcw_out, double* pose7_out, double* xyz_out, double* chi2_obs, uint8_t* outlier,
-    double* rep_error, int32_t* iters_done, int32_t* trials_done, double* trace, int32_t* dims_out) {
-  (void)E;
-  graph_t g;
+    const double* xyz_in, double regLap, double regInex, double regTemp, int neighbours_layers, int32_t* dims_out) {
+#define g (*gp)
   memset(&g, 0, sizeof(g));
   g.n = n; g.xyz0 = xyz0;
   g.cam = se3_from_f32(Tcw_in);
@@ -712,6 +711,53 @@ int sft_oracle_solve(
   g.D = D;
   if (dims_out) { dims_out[0] = D; dims_out[1] = nOptLap; dims_out[2] = nViewed; dims_out[3] = nCurv; dims_out[4] = nStretch; dims_out[5] = g.ne; }
 
+  aux->viewed = viewed; aux->optlap = optlap; aux->eact = eact;
+  aux->nOptLap = nOptLap; aux->nViewed = nViewed; aux->nCurv = nCurv; aux->nStretch = nStretch;
+  return D;
+#undef g
+}
+
+static void graph_free(graph_t* gp, graph_aux_t* aux) {
+  for (int i = 0; i < gp->ne; i++) if (gp->e[i].vext) free(gp->e[i].vext);
+  free(gp->e); free(gp->hidx); free(gp->xyz); free(aux->viewed); free(aux->optlap); free(aux->eact);
+}
+
+/* Test hook: residuals + Jacobians + normal equations once, at the given state.
+ * H is column-major D x D in the reference's index order (camera, then active nodes ascending). */
+int sft_oracle_system(
+    int n, const double* xyz0, const uint8_t* boundary,
+    const int32_t* nbr_ptr, const int32_t* nbr_idx, const double* nbr_w, const double* k0,
+    int E, const int32_t* edge_nodes, const double* edge_L0,
+    const int32_t* inc_ptr, const int32_t* inc_edge, double median_L,
+    const float* Tcw_in, const double* K, int N_frame, int M,
+    const int32_t* obs_nodes, const double* obs_bary, const double* obs_uv, const double* obs_invsig2,
+    const double* xyz_in, double regLap, double regInex, double regTemp, int neighbours_layers,
+    int32_t D_expected, double* H, double* b, double* chi2) {
+  graph_t g; graph_aux_t aux;
+  int D = graph_build(&g, &aux, n, xyz0, boundary, nbr_ptr, nbr_idx, nbr_w, k0, E, edge_nodes, edge_L0, inc_ptr, inc_edge, median_L,
+                      Tcw_in, K, N_frame, M, obs_nodes, obs_bary, obs_uv, obs_invsig2, xyz_in, regLap, regInex, regTemp, neighbours_layers, NULL);
+  if (H == NULL || D != D_expected) { graph_free(&g, &aux); return D; }
+  compute_active_errors(&g);
+  if (chi2) *chi2 = active_robust_chi2(&g);
+  build_system(&g, H, b);
+  graph_free(&g, &aux);
+  return D;
+}
+
+int sft_oracle_solve(
+    int n, const double* xyz0, const uint8_t* boundary,
+    const int32_t* nbr_ptr, const int32_t* nbr_idx, const double* nbr_w, const double* k0,
+    int E, const int32_t* edge_nodes, const double* edge_L0,
+    const int32_t* inc_ptr, const int32_t* inc_edge, double median_L,
+    const float* Tcw_in, const double* K, int N_frame, int M,
+    const int32_t* obs_nodes, const double* obs_bary, const double* obs_uv, const double* obs_invsig2,
+    const double* xyz_in,
+    double regLap, double regInex, double regTemp, int neighbours_layers, int max_iters, int ldlt_mode,
+    float* Tcw_out, double* pose7_out, double* xyz_out, double* chi2_obs, uint8_t* outlier,
+    double* rep_error, int32_t* iters_done, int32_t* trials_done, double* trace, int32_t* dims_out) {
+  graph_t g; graph_aux_t aux;
+  int D = graph_build(&g, &aux, n, xyz0, boundary, nbr_ptr, nbr_idx, nbr_w, k0, E, edge_nodes, edge_L0, inc_ptr, inc_edge, median_L,
+                      Tcw_in, K, N_frame, M, obs_nodes, obs_bary, obs_uv, obs_invsig2, xyz_in, regLap, regInex, regTemp, neighbours_layers, dims_out);
   double* H = (double*)malloc(sizeof(double) * (size_t)D * D);
   double* Hs = (double*)malloc(sizeof(double) * (size_t)D * D);
   double* b = (double*)malloc(sizeof(double) * D);
@@ -821,8 +867,7 @@ int sft_oracle_solve(
   }
   if (xyz_out) memcpy(xyz_out, g.xyz, sizeof(double) * 3 * n);
 
-  for (int i = 0; i < g.ne; i++) if (g.e[i].vext) free(g.e[i].vext);
-  free(g.e); free(g.hidx); free(g.xyz); free(viewed); free(optlap); free(eact);
+  graph_free(&g, &aux);
   free(H); free(Hs); free(b); free(x); free(perm); free(tmp); free(xyz_bak);
   return M - nBadObs;
 }
