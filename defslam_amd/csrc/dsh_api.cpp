@@ -97,6 +97,7 @@ struct Arena {  // byte layout of a device allocation, 256-byte aligned slices
 
 struct dsh_ctx {
   int device = 0;
+  bool host_only = false;          // device == -1: template + packer only (CPU tests of the host logic)
   hipStream_t stream = nullptr;
   std::string err;
   dsh::TemplateHost tmpl;
@@ -133,6 +134,9 @@ int fail(dsh_ctx* c, int code, const std::string& m) {
   } while (0)
 
 int upload_template(dsh_ctx* c) {
+  c->B = 0;
+  c->ran = false;
+  if (c->host_only) return DSH_OK;
   const dsh::TemplateHost& t = c->tmpl;
   Arena a;
   const size_t o_xyz0 = a.take(sizeof(double) * 3 * t.n);
@@ -311,6 +315,13 @@ extern "C" {
 int dsh_create(dsh_ctx** out, int device) {
   if (!out) return DSH_ERR_ARG;
   *out = nullptr;
+  if (device == -1) {  // host-only context: template constants + packing, every GPU entry point fails loudly
+    dsh_ctx* hc = new dsh_ctx();
+    hc->device = -1;
+    hc->host_only = true;
+    *out = hc;
+    return DSH_OK;
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DSH_ERR_NO_DEVICE;
   if (device < 0 || device >= count) return DSH_ERR_ARG;
@@ -326,6 +337,7 @@ int dsh_create(dsh_ctx** out, int device) {
 
 int dsh_destroy(dsh_ctx* c) {
   if (!c) return DSH_ERR_ARG;
+  if (c->host_only) { delete c; return DSH_OK; }
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (c->d_tmpl) (void)hipFree(c->d_tmpl);
@@ -338,6 +350,7 @@ const char* dsh_last_error(const dsh_ctx* c) { return c ? c->err.c_str() : "null
 void* dsh_stream(dsh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int dsh_synchronize(dsh_ctx* c) {
   if (!c) return DSH_ERR_ARG;
+  if (c->host_only) return DSH_ERR_NO_DEVICE;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DSH_OK;
 }
@@ -346,7 +359,7 @@ int dsh_template_build(dsh_ctx* c, int n, const double* xyz0, int F, const int32
   if (!c || n <= 0 || F <= 0 || !xyz0 || !facets) return fail(c, DSH_ERR_ARG, "dsh_template_build: bad argument");
   for (int i = 0; i < 3 * F; i++)
     if (facets[i] < 0 || facets[i] >= n) return fail(c, DSH_ERR_ARG, "dsh_template_build: facet index out of range");
-  (void)hipSetDevice(c->device);
+  if (!c->host_only) (void)hipSetDevice(c->device);
   c->tmpl.build(n, xyz0, F, facets);
   return upload_template(c);
 }
@@ -354,7 +367,7 @@ int dsh_template_build(dsh_ctx* c, int n, const double* xyz0, int F, const int32
 int dsh_template_set(dsh_ctx* c, int n, const double* xyz0, const uint8_t* boundary, const int32_t* rp, const int32_t* col, const double* w,
                      const double* k0, int E, const int32_t* en, const double* eL, double median_L) {
   if (!c || n <= 0 || E < 0 || !xyz0 || !boundary || !rp || !col || !w || !k0 || !en || !eL) return fail(c, DSH_ERR_ARG, "dsh_template_set: bad argument");
-  (void)hipSetDevice(c->device);
+  if (!c->host_only) (void)hipSetDevice(c->device);
   c->tmpl.set(n, xyz0, boundary, rp, col, w, k0, E, en, eL, median_L);
   return upload_template(c);
 }
@@ -391,12 +404,19 @@ int dsh_template_embed(const dsh_ctx* c, int P, const float* pts, int32_t* facet
 int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   if (!c || B <= 0 || !frames) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_upload: bad argument");
   if (!c->tmpl.valid) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_upload: no template");
-  (void)hipSetDevice(c->device);
+  if (!c->host_only) (void)hipSetDevice(c->device);
+  c->B = 0;
   c->packed.assign(B, Packed());
   for (int b = 0; b < B; b++) {
     std::string e;
     const int rc = pack_problem(c->tmpl, frames[b], c->packed[b], e);
     if (rc != DSH_OK) return fail(c, rc, "problem " + std::to_string(b) + ": " + e);
+  }
+  if (c->host_only) {  // packed on the host only; dsh_sft_batch_problem_info works, running does not
+    c->h_probs.resize(B);
+    for (int b = 0; b < B; b++) c->h_probs[b] = c->packed[b].h;
+    c->B = B;
+    return DSH_OK;
   }
   // ---- layout: [SftDev table][read-only arrays of every problem] | [workspace of every problem]
   Arena a;
@@ -471,6 +491,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
 
 int dsh_sft_batch_run(dsh_ctx* c) {
   if (!c) return DSH_ERR_ARG;
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
   (void)hipSetDevice(c->device);
   HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->stream));
@@ -478,8 +499,30 @@ int dsh_sft_batch_run(dsh_ctx* c) {
   return DSH_OK;
 }
 
+int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
+  if (!c || launches <= 0 || !total_ms) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_run_timed: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run_timed: host-only context, no GPU (there is no CPU fallback)");
+  if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run_timed: nothing uploaded");
+  (void)hipSetDevice(c->device);
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->stream));
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *total_ms = (double)ms;
+  c->ran = true;
+  return DSH_OK;
+}
+
 int dsh_sft_batch_counts(dsh_ctx* c, int64_t* iters, int64_t* trials) {
   if (!c || c->B <= 0 || !c->ran) return DSH_ERR_STATE;
+  if (c->host_only) return DSH_ERR_NO_DEVICE;
   (void)hipSetDevice(c->device);
   int64_t it = 0, tr = 0;
   for (int b = 0; b < c->B; b++) {
@@ -508,6 +551,7 @@ int dsh_sft_batch_problem_info(dsh_ctx* c, int b, int64_t* bytes, int32_t* count
 
 int dsh_sft_batch_download(dsh_ctx* c, int B, dsh_sft_result* res) {
   if (!c || !res || B != c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_download: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_download: host-only context");
   if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_download: no run");
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -568,6 +612,7 @@ int dsh_sft_solve(dsh_ctx* c, const dsh_sft_frame* frame, dsh_sft_result* result
 
 int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, double* chi2) {
   if (!c || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_debug_system: host-only context");
   (void)hipSetDevice(c->device);
   SftDev h = c->h_probs[b];
   if (D != 6 + h.Dn) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: D mismatch");

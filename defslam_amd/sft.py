@@ -167,6 +167,12 @@ class Context:
     def batch_run(self):
         self._check(self._L.dsh_sft_batch_run(self._h), "dsh_sft_batch_run")
 
+    def batch_run_timed(self, launches: int = 1) -> float:
+        """`launches` back-to-back runs timed with HIP events on the context's stream; returns milliseconds."""
+        ms = C.c_double()
+        self._check(self._L.dsh_sft_batch_run_timed(self._h, int(launches), C.byref(ms)), "dsh_sft_batch_run_timed")
+        return ms.value
+
     def synchronize(self):
         self._check(self._L.dsh_synchronize(self._h), "dsh_synchronize")
 

@@ -37,6 +37,8 @@ extern "C" {
 typedef struct dsh_ctx dsh_ctx;
 
 /* ---- context ----------------------------------------------------------------------------- */
+/* device >= 0: bind to that GPU.  device == -1: host-only context (template constants, embedding and
+ * problem packing work; every entry point that needs the GPU returns DSH_ERR_NO_DEVICE -- no CPU fallback). */
 int dsh_create(dsh_ctx** out, int device);
 int dsh_destroy(dsh_ctx* ctx);
 const char* dsh_last_error(const dsh_ctx* ctx);
@@ -108,6 +110,9 @@ int dsh_sft_solve(dsh_ctx* ctx, const dsh_sft_frame* frame, dsh_sft_result* resu
 int dsh_sft_batch_upload(dsh_ctx* ctx, int B, const dsh_sft_frame* frames);
 int dsh_sft_batch_run(dsh_ctx* ctx);
 int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
+/* `launches` back-to-back runs bracketed by HIP events recorded on dsh_stream; returns the elapsed
+ * milliseconds between the two events (device time of the launches, no host round trips inside). */
+int dsh_sft_batch_run_timed(dsh_ctx* ctx, int launches, double* total_ms);
 /* Totals of the last completed run (valid after a synchronise): outer iterations and trials over the batch. */
 int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
 /* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts

@@ -1,0 +1,130 @@
+"""CPU tests: the C-ABI library loads, exports every symbol the header declares, and the host-side
+logic (template constants, embedding, problem packing) matches the oracle.  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from defslam_amd import _lib
+    L = _lib.load()
+    header = open(os.path.join(ROOT, "include", "defslam_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(dsh_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no prototypes found in the header"
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/defslam_hip.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(host_ctx):
+    from defslam_amd import sft, synth
+    tmpl, fr = synth.make_problem("smoke")
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    f = sft.frame_from_synth(fr)
+    host_ctx.batch_upload([f], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    with pytest.raises(sft.DshError, match="no GPU|host-only"):
+        host_ctx.batch_run()
+
+
+def test_bad_arguments_return_status_not_abort(host_ctx):
+    from defslam_amd import sft, synth
+    tmpl, fr = synth.make_problem("smoke")
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    f = sft.frame_from_synth(fr)
+    f.obs_nodes = f.obs_nodes.copy()
+    f.obs_nodes[0, 0] = 10_000
+    with pytest.raises(sft.DshError, match="out of range"):
+        host_ctx.batch_upload([f])
+    bad_facets = tmpl.facets.copy()
+    bad_facets[0, 0] = -1
+    with pytest.raises(sft.DshError):
+        host_ctx.template_build(tmpl.xyz0, bad_facets)
+
+
+@pytest.mark.parametrize("shape", [(10, 10), (25, 20), (7, 13)])
+def test_template_constants_match_oracle(host_ctx, oracle_mod, shape):
+    from defslam_amd import synth
+    tmpl = synth.make_grid_template(*shape)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    tg = host_ctx.template_get()
+    # integer / index work: bit exact
+    for k in ["boundary", "nbr_ptr", "nbr_idx", "edge_nodes"]:
+        np.testing.assert_array_equal(tg[k], getattr(tc, k))
+    # floating point: same formulas in the same order -> identical doubles
+    np.testing.assert_array_equal(tg["edge_L0"], tc.edge_L0)
+    np.testing.assert_array_equal(tg["nbr_w"], tc.nbr_w)
+    np.testing.assert_array_equal(tg["k0"], tc.k0)
+    assert tg["median_L"] == tc.median_L
+    rows, cols = shape
+    assert tc.E == (rows - 1) * cols + (cols - 1) * rows + (rows - 1) * (cols - 1)
+    assert int(tc.boundary.sum()) == 2 * (rows + cols) - 4
+
+
+def test_irregular_mesh_constants(host_ctx, oracle_mod):
+    """A fan + strip mesh: varying degrees, shuffled facet orientation."""
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-1, 1, size=(40, 2))
+    from scipy.spatial import Delaunay
+    tri = Delaunay(xy)
+    xyz = np.c_[xy, 1 + 0.1 * rng.normal(size=40)]
+    fac = tri.simplices.astype(np.int32)
+    tc = oracle_mod.template_build(xyz, fac)
+    host_ctx.template_build(xyz, fac)
+    tg = host_ctx.template_get()
+    for k in ["boundary", "nbr_ptr", "nbr_idx", "edge_nodes"]:
+        np.testing.assert_array_equal(tg[k], getattr(tc, k))
+    np.testing.assert_array_equal(tg["nbr_w"], tc.nbr_w)
+    np.testing.assert_array_equal(tg["k0"], tc.k0)
+
+
+def test_embedding_matches_oracle_bit_exact(host_ctx, oracle_mod):
+    from defslam_amd import synth
+    tmpl = synth.make_grid_template(10, 10)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    rng = np.random.default_rng(7)
+    F = tmpl.facets.shape[0]
+    fac = rng.integers(0, F, size=500)
+    bary = rng.dirichlet((1, 1, 1), size=500)
+    pts = (bary[:, :, None] * tmpl.xyz0[tmpl.facets[fac]]).sum(1)
+    pts[::7] += rng.normal(scale=0.01, size=pts[::7].shape)       # off-surface points
+    pts[::50] += 5.0                                               # far away: not embedded
+    pts = pts.astype(np.float32)
+    fid, nodes, b = host_ctx.template_embed(pts)
+    L = oracle_mod.lib()
+    ofid = np.zeros(500, np.int32)
+    ob = np.zeros((500, 3), np.float32)
+    xyz0 = np.ascontiguousarray(tmpl.xyz0)
+    L.tmpl_oracle_embed(tc.n, xyz0.ctypes.data_as(C.POINTER(C.c_double)), F, tc.facets.ctypes.data_as(C.POINTER(C.c_int32)), 500,
+                        pts.ctypes.data_as(C.POINTER(C.c_float)), ofid.ctypes.data_as(C.POINTER(C.c_int32)), ob.ctypes.data_as(C.POINTER(C.c_float)))
+    np.testing.assert_array_equal(fid, ofid)            # bit-exact triangle indexing
+    np.testing.assert_array_equal(b, ob)                # float32 barycentrics, same operation order
+    ok = fid >= 0
+    np.testing.assert_array_equal(nodes[ok], tc.facets[fid[ok]])
+    assert (fid[::50] == -1).all() and ok.sum() > 400
+    # reconstruct: sum b_k v_k is within the reference's 0.1 squared-distance gate
+    rec = (b[ok][:, :, None] * tmpl.xyz0[nodes[ok]]).sum(1)
+    assert ((rec - pts[ok]) ** 2).sum(1).max() <= 0.1
+
+
+def test_packer_counts_and_algorithmic_bytes(host_ctx, oracle_mod):
+    from defslam_amd import sft, synth
+    tmpl, fr = synth.make_problem("C2")
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    host_ctx.batch_upload([sft.frame_from_synth(fr)], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    nbytes, counts = host_ctx.problem_info(0)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz,
+                             synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, max_iters=0)
+    D, nopt, nview, ncurv, nstr, _ = r.dims
+    assert list(counts) == [1000, nopt, ncurv, nstr, nview, D]
+    M, n, Cc, E, V = 1000, 500, int(ncurv), int(nstr), int(nview)
+    expect = (60 * M + 24 * n + 88 + 92 * Cc + 16 * E + 28 * V) + 8 * (30 * M + 21 * Cc + 6 * E + 9 * V) + 8 * (2 * M + Cc + E + 3 * V) + 8 * M
+    assert nbytes == expect
+    assert 1.1e6 < nbytes < 1.25e6    # ~1.17 MB per assembly pass at C2
