@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,6 +20,7 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd);
 namespace {
 
 constexpr int kNB = 32;  // must match NB in sft_kernels.hip
+constexpr int kTS = 16, kBT = 8;  // must match TS / BT in sft_kernels.hip
 
 // ---- pose conversions at the float32 boundary (Converter.cc:35-66, se3quat.h:58-64,269-285) -------
 void pose7_from_Tcw(const float* T, double* p) {
@@ -288,7 +290,9 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   pose7_from_Tcw(f.Tcw, P.pose_init);
   SftDev& h = P.h;
   h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
+  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : 0;
   h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
+  if (const char* dm = std::getenv("DSH_EXPERIMENT")) h.mode = std::atoi(dm) & ~1;  // timing experiments only (results invalid)
   h.fx = f.K[0]; h.fy = f.K[1]; h.cx = f.K[2]; h.cy = f.K[3];
   h.w_ref = f.reg_temp / std::pow(t.median_L, 2);              // DefOptimizer.cc:378
   h.w_curv = f.reg_lap / (double)nA;                           // :458  (|OptLap|)
@@ -437,7 +441,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     o.pose_init = put(st, a, pi);
   }
   c->ro_bytes = a.size;
-  struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, x, chi2, ferr, trace, info, dbg; };
+  struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, x, chi2, ferr, trace, info, dbg; };
   std::vector<WOffs> wo(B);
   int max_kd = 0;
   for (int b = 0; b < B; b++) {
@@ -446,13 +450,16 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     WOffs& w = wo[b];
     w.xyz = a.take(8 * 3 * (size_t)h.n); w.bak = a.take(8 * 3 * (size_t)h.n); w.pose = a.take(8 * 8);
     w.Jobs = a.take(8 * (size_t)h.M * SFT_JOBS_STRIDE); w.Jstar = a.take(8 * 4 * (size_t)h.S); w.Jstr = a.take(8 * 4 * (size_t)h.Es); w.Jref = a.take(8 * 4 * (size_t)h.V);
-    w.Hb = a.take(8 * Dnp * h.ldh); w.Hbord = a.take(8 * SFT_BORDER * Dnp); w.Hc = a.take(8 * 56);
-    w.Lb = a.take(8 * Dnp * h.ldh); w.Lbord = a.take(8 * SFT_BORDER * Dnp); w.Lc = a.take(8 * 56);
+    const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
+    w.Hb = a.take(8 * band_elems); w.Hbord = a.take(8 * SFT_BORDER * Dnp); w.Hc = a.take(8 * 56);
+    w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * SFT_BORDER * Dnp); w.Lc = a.take(8 * 56);
+    w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.x = a.take(8 * (Dnp + 8)); w.chi2 = a.take(8 * (size_t)h.M); w.ferr = a.take(8 * (size_t)h.M);
     w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(64);
     max_kd = std::max(max_kd, h.kd);
   }
-  if (sft_lm_kernel_lds_bytes(max_kd) > 160 * 1024) return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel");
+  if (sft_lm_kernel_lds_bytes(max_kd) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
+    return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel / workgroup");
   if (a.size > c->d_batch_cap) {
     if (c->d_batch) { (void)hipFree(c->d_batch); c->d_batch = nullptr; c->d_batch_cap = 0; }
     HIPCHK(c, hipMalloc((void**)&c->d_batch, a.size));
@@ -473,7 +480,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.xyz = (double*)(base + w.xyz); h.xyz_bak = (double*)(base + w.bak); h.pose = (double*)(base + w.pose);
     h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
     h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
-    h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc);
+    h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc); h.Linv = (double*)(base + w.Linv);
     h.x = (double*)(base + w.x); h.chi2_obs = (double*)(base + w.chi2); h.final_err = (double*)(base + w.ferr);
     h.trace = (double*)(base + w.trace); h.info = (int32_t*)(base + w.info); h.dbg = (double*)(base + w.dbg);
     c->h_probs[b] = h;
@@ -517,6 +524,17 @@ int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
   (void)hipEventDestroy(e1);
   *total_ms = (double)ms;
   c->ran = true;
+  return DSH_OK;
+}
+
+int dsh_sft_batch_phase_ms(dsh_ctx* c, int b, double* out8) {
+  if (!c || !out8 || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_phase_ms: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_phase_ms: host-only context");
+  if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_phase_ms: no run");
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out8, c->h_probs[b].dbg, 8 * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; i++) out8[i] *= 1e-5;  // 100 MHz ticks -> ms
   return DSH_OK;
 }
 
@@ -624,7 +642,12 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   h.mode = 0;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
-  std::vector<double> Hb(Dnp * h.ldh), Hbord(SFT_BORDER * Dnp), Hc(56);
+  const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
+  std::vector<double> Hb(band_elems), Hbord(SFT_BORDER * Dnp), Hc(56);
+  auto hidx = [&](int r, int cc) -> size_t {
+    if (h.tile_mode) return ((size_t)(r >> 4) * (kBT + 1) + ((r >> 4) - (cc >> 4))) * (kTS * kTS) + (size_t)(r & 15) * kTS + (cc & 15);
+    return (size_t)r * h.ldh + (cc - r + h.kd);
+  };
   HIPCHK(c, hipMemcpy(Hb.data(), h.Hb, 8 * Hb.size(), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(Hbord.data(), h.Hbord, 8 * Hbord.size(), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(Hc.data(), h.Hcorner, 8 * 49, hipMemcpyDeviceToHost));
@@ -636,7 +659,7 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
       for (int k = 0; k <= h.kd; k++) {
         const int cidx = r - h.kd + k;
         if (cidx < 0) continue;
-        const double v = Hb[(size_t)r * h.ldh + k];
+        const double v = Hb[hidx(r, cidx)];
         H[(size_t)(6 + r) + (size_t)(6 + cidx) * D] = v;
         H[(size_t)(6 + cidx) + (size_t)(6 + r) * D] = v;
       }

@@ -1,6 +1,6 @@
 // Shape-from-Template Levenberg-Marquardt solve on gfx950 (MI355X), FP64.
 //
-// One workgroup (SFT_NT = 1024 threads = 16 wavefronts = one CU) owns one problem and runs the
+// One workgroup (SFT_NT = 512 threads = 8 wavefronts, 2 per SIMD, up to 256 VGPRs each) owns one problem and runs the
 // whole optimisation of defSLAM::Optimizer::DefPoseOptimization on the device:
 //
 //   residuals + Jacobians ... sft_types.h:102-133,137-206 (EdgeNodesCamera), :257-311
@@ -22,7 +22,40 @@
 
 #define NB 32  // panel width of the blocked band Cholesky
 
+// Phase timers (thread 0, constant 100 MHz counter): dbg[1] residuals, [2] assembly, [3] H->L copy,
+// [4] panel factorisation, [5] trailing update, [6] back substitution, [7] update + control
+#ifdef SFT_PHASE_TIMERS
+#define PH_T0() long long ph_t0__ = wall_clock64()
+#define PH_ADD(slot)                                                          \
+  do {                                                                        \
+    const long long t1__ = wall_clock64();                                    \
+    if (threadIdx.x == 0) P.dbg[slot] += (double)(t1__ - ph_t0__);            \
+    ph_t0__ = t1__;                                                           \
+  } while (0)
+#define PH_RESET() ph_t0__ = wall_clock64()
+#else
+#define PH_T0() do {} while (0)
+#define PH_ADD(slot) do {} while (0)
+#define PH_RESET() do {} while (0)
+#endif
+
+#define TS 16   // MFMA tile edge (v_mfma_f64_16x16x4_f64)
+#define TP 17   // padded leading dimension of a k-major tile in LDS
+#define BT 8    // sub-diagonal tiles per block column in tile mode (half-bandwidth <= 16*BT)
+#define TILE_LDS (TS * TP)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
 namespace {
+
+// Offset of tile (I, I-d) in the tile-band storage: (BT+1) row-major 16x16 tiles per tile row.
+__device__ __forceinline__ size_t tile_off(int I, int d) { return ((size_t)I * (BT + 1) + d) * (TS * TS); }
+
+// Address of H(r, c), c <= r, in either storage mode.
+__device__ __forceinline__ size_t h_index(const SftDev& P, int r, int c) {
+  if (P.tile_mode) return tile_off(r >> 4, (r >> 4) - (c >> 4)) + (size_t)(r & 15) * TS + (c & 15);
+  return (size_t)r * P.ldh + (c - r + P.kd);
+}
 
 struct Ctl {       // LDS-resident control block, written by thread 0
   double R[9], t[3];
@@ -313,7 +346,6 @@ __device__ void assemble(const SftDev& P, double* red, double* out) {
     }
     __syncthreads();
   }
-  const int kd = P.kd, ldh = P.ldh;
   for (int q = threadIdx.x; q < P.nblk; q += SFT_NT) {
     const int bi = P.blk_rc[2 * q], bj = P.blk_rc[2 * q + 1];
     const bool diag = (bi == bj);
@@ -387,7 +419,10 @@ __device__ void assemble(const SftDev& P, double* red, double* out) {
 #pragma unroll
       for (int b = 0; b < 3; b++) {
         const int c = 3 * bj + b;
-        if (c <= r) P.Hb[(size_t)r * ldh + (c - r + kd)] = H[3 * a + b];
+        if (c <= r) {
+          P.Hb[h_index(P, r, c)] = H[3 * a + b];
+          if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) P.Hb[tile_off(r >> 4, 0) + (size_t)(c & 15) * TS + (r & 15)] = H[3 * a + b];
+        }
       }
     }
     if (diag) {
@@ -413,6 +448,7 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
   const double lambda = ctl->lambda;
   const int tid = threadIdx.x;
+  PH_T0();
   // working copy L <- H + lambda I
   for (size_t i = tid; i < (size_t)Dnp * ldh; i += SFT_NT) {
     double v = P.Hb[i];
@@ -429,6 +465,7 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
   }
   if (tid == 0) ctl->fact_ok = 1;
   __syncthreads();
+  PH_ADD(3);
 
   for (int j0 = 0; j0 < Dnp; j0 += NB) {
     const int m = min(kd, Dnp - j0 - NB);   // band rows below the diagonal block
@@ -438,11 +475,11 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
     // raw diagonal block (lower) goes to LDS first so every thread can rebuild pivots
     double* diagraw = panel + (size_t)NB * LDP;          // NB*NB, [r*NB + c]
     double* lrow = diagraw + NB * NB;                    // finalised rows of the diagonal block [r*NB + c]
-    if (tid < NB * NB) {
-      const int r = tid / NB, c = tid % NB;
+    for (int e = tid; e < NB * NB; e += SFT_NT) {
+      const int r = e / NB, c = e % NB;
       double v = 0.0;
       if (c <= r) v = P.Lb[(size_t)(j0 + r) * ldh + (c - r + kd)];
-      diagraw[tid] = v;
+      diagraw[e] = v;
     }
     __syncthreads();
     {
@@ -507,6 +544,7 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
       }
     }
     __syncthreads();
+    PH_ADD(4);
     // ---- trailing update: window rows/cols [0, m+7) relative to j0+NB ----------------------
     const int W = m + SFT_BORDER;
     const int T = (W + 3) >> 2;
@@ -555,6 +593,7 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
       }
     }
     __syncthreads();
+    PH_ADD(5);
   }
   // ---- corner: Cholesky of the 6x6 Schur complement, forward-solve its right-hand side, x_cam ---
   double* x = P.x;
@@ -587,8 +626,9 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
   if (ctl->fact_ok) {
     double* tvec = panel;            // NB
     double* part = panel + NB;       // 32 parts x NB
-    double* dblk = part + 32 * NB;   // NB x NB diagonal block of L
-    const int c = tid & (NB - 1), pidx = tid / NB;  // 32 columns x 32 parts
+    constexpr int NPART = SFT_NT / NB;
+    double* dblk = part + NPART * NB;   // NB x NB diagonal block of L
+    const int c = tid & (NB - 1), pidx = tid / NB;  // NB columns x NPART parts
     double xc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) xc[i] = x[Dnp + i];
@@ -596,17 +636,17 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
       const int C = j0 + c;
       double s = 0.0;
       const int rend = min(Dnp - 1, C + kd);
-      for (int Rr = j0 + NB + pidx; Rr <= rend; Rr += 32) s += P.Lb[(size_t)Rr * ldh + (C - Rr + kd)] * x[Rr];
+      for (int Rr = j0 + NB + pidx; Rr <= rend; Rr += NPART) s += P.Lb[(size_t)Rr * ldh + (C - Rr + kd)] * x[Rr];
       if (pidx < 6) s += P.Lbord[(size_t)pidx * Dnp + C] * xc[pidx];
       part[pidx * NB + c] = s;
-      {
-        const int r = tid / NB, cc2 = tid % NB;
-        dblk[tid] = (cc2 <= r) ? P.Lb[(size_t)(j0 + r) * ldh + (cc2 - r + kd)] : 0.0;
+      for (int e = tid; e < NB * NB; e += SFT_NT) {
+        const int r = e / NB, cc2 = e % NB;
+        dblk[e] = (cc2 <= r) ? P.Lb[(size_t)(j0 + r) * ldh + (cc2 - r + kd)] : 0.0;
       }
       __syncthreads();
       if (tid < NB) {
         double s2 = 0.0;
-        for (int p2 = 0; p2 < 32; p2++) s2 += part[p2 * NB + tid];
+        for (int p2 = 0; p2 < NPART; p2++) s2 += part[p2 * NB + tid];
         tvec[tid] = P.Lbord[(size_t)6 * Dnp + j0 + tid] - s2;
       }
       __syncthreads();
@@ -621,6 +661,353 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
       }
       __syncthreads();
     }
+  }
+  PH_ADD(6);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Tile mode (half-bandwidth <= 16*BT): right-looking Cholesky on 16x16 tiles.
+//   * the trailing window (BT x BT tiles, lower triangle live) lives in MFMA accumulator registers:
+//     wave w owns ring slots (a = w>>1, b = 4*(w&1)+t), t = 0..3; slot (a,b) holds tile (I,J) with
+//     I = a, J = b (mod BT) inside the current window [k+1, k+BT]
+//   * every step publishes block column k to LDS, wave 0 factors the diagonal tile and inverts it,
+//     the sub-diagonal tiles become X = A * Linv^T (MFMA), the window gets C -= X_I X_J^T (MFMA)
+//   * the 6 camera rows + the right-hand side ride along as a 7 x 128 ring in LDS (VALU)
+// H is read once (fresh tiles enter the window as it slides), L is written once.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26 relative) + one coupled Goldschmidt/Newton step
+// (quadratic: ~2^-52) + one residual correction of the square root.
+__device__ __forceinline__ void rsqrt_sqrt(double d, double& inv, double& s) {
+  const double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double res = fma(-g, g, d);
+  s = fma(res, h, g);
+  inv = fma(fma(-h, g, 0.5), h + h, h + h);   // one more correction of 1/sqrt without lengthening the sqrt chain
+}
+
+// Barrier that orders LDS traffic only: outstanding global loads/stores stay in flight across it
+// (prefetched H tiles must not be drained at every step; L tiles are first re-read after the loop).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Cholesky A = L L^T of the symmetric 16x16 tile `a` (accumulator layout: lane (g = l>>4, c = l&15),
+// register q holds A[g+4q][c]) and W = L^-1, both by rank-1 MFMA updates executed by ONE wavefront:
+//   step j: l = A[:,j] / sqrt(A[j][j])  (row j of the symmetric tile = lanes 16*(j&3).., register j>>2)
+//           A -= l l^T                   (one v_mfma_f64_16x16x4 with only k = j&3 populated)
+//           W[j,:] /= L[j][j];  W -= (l - e_j) W[j,:]     (second MFMA, same operand lanes)
+// The next pivot is formed ahead of the MFMA result (A[j+1][j+1] - l[j+1]^2) so the rsqrt chain overlaps it.
+// Returns false when a pivot is not positive.
+__device__ __forceinline__ bool chol_inv_mfma(v4d& a, v4d& w) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
+  bool bad = false;
+  double pd = bcast_lane(a[0], 0);     // A[0][0]: lane 0, register 0
+#pragma unroll
+  for (int j = 0; j < TS; j++) {
+    const int gj = j & 3, qj = j >> 2;
+    if (!(pd > 0.0)) bad = true;
+    double inv, sq;
+    rsqrt_sqrt(pd, inv, sq);
+    const double m = (g == gj) ? inv : 0.0;          // operand lanes of this step
+    const double la = a[qj] * m;                       // l[c] in lanes (gj, c), 0 elsewhere
+    if (j + 1 < TS) {                                  // next pivot ahead of the MFMA: A[j+1][j+1] - l[j+1]^2
+      const double an = bcast_lane(a[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1);
+      const double ln = bcast_lane(la, 16 * gj + j + 1);
+      pd = fma(-ln, ln, an);
+    }
+    const double nla = -la;
+    a = __builtin_amdgcn_mfma_f64_16x16x4f64(nla, la, a, 0, 0, 0);
+    const double wr = w[qj] * m;                       // W[j][c] / L[j][j] (previous W update has landed by now)
+    const double u = (g == gj && c == j) ? (nla + 1.0) : nla;   // -(l - e_j)
+    w = __builtin_amdgcn_mfma_f64_16x16x4f64(u, wr, w, 0, 0, 0);
+  }
+  return !bad;
+}
+
+// Tile-mode factorisation, 8 wavefronts.  Wave w owns ring row a = w of the BT x BT accumulator window
+// (slots b = 0..BT-1; tile (I,J) of the window [k+1, k+BT] sits in slot (I mod BT, J mod BT)), the border tile
+// of ring column w (7 camera/rhs rows x 16 columns) and, for wave 0, the 7x7 corner.  One step:
+//   C(k): X_i = A_i Linv_k^T for the published block column k (MFMA GEMM), border panel on 112 lanes
+//   D(k): window, border and corner get  -= X X^T (MFMA);  the owner of tile row k+1 factors the next
+//         diagonal tile while the other waves still update (look-ahead), everybody publishes block column k+1
+__device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws) {
+  static_assert(SFT_NT == 64 * BT, "one wavefront per ring row");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Dn = P.Dn;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  const int nT = Dnp / TS;
+  double* Araw = ws;                         // (BT+1) tiles, k-major padded (slot 0 unused)
+  double* Xp = Araw + (BT + 1) * TILE_LDS;   // (BT+1) tiles; slot 0: border panel as a tile (rows 7..15 zero)
+  double* LinvK = Xp + (BT + 1) * TILE_LDS;  // Linv^T, k-major padded: LinvK[k*TP + j] = Linv[j][k]
+  double* Abord = LinvK + TILE_LDS;          // 7 x 16 border block of the published column, row-major
+  double* Cn = Abord + SFT_BORDER * TS;      // 7 x 7 corner (written once at the end)
+  const double lambda = ctl->lambda;
+  const int crow = lane >> 4, ccol = lane & 15;   // accumulator layout: rows crow + 4q, column ccol
+  const double* Hg = P.Hb;
+  const double* Hbord = P.Hbord;
+  double* Lg = P.Lb;
+  double* Lbord = P.Lbord;
+  v4d acc[BT];
+#pragma unroll
+  for (int t = 0; t < BT; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  // raw tile (I, J) of H in accumulator layout (zero outside the matrix / band); no dependent ALU on the loads
+  auto fresh_tile = [&](int I, int J) -> v4d {
+    v4d v = {0.0, 0.0, 0.0, 0.0};
+    if (I < nT && J >= 0 && J <= I && I - J <= BT) {
+      const double* src = Hg + tile_off(I, I - J) + crow * TS + ccol;
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = src[4 * q * TS];
+    }
+    return v;
+  };
+  // border block of tile column J: rows 0..6 of Hbord, accumulator layout
+  auto fresh_border = [&](int J) -> v4d {
+    v4d v = {0.0, 0.0, 0.0, 0.0};
+    if (J < nT) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (crow + 4 * q < SFT_BORDER) v[q] = Hbord[(size_t)(crow + 4 * q) * Dnp + TS * J + ccol];
+    }
+    return v;
+  };
+  // tile row I enters the window: the owner of ring row (I mod BT) reloads its slots
+  auto load_row = [&](int I) {
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[b] = fresh_tile(I, I - ((I - b) & (BT - 1)));
+  };
+  load_row(wave);                       // rows 0..BT-1
+  v4d bacc = fresh_border(wave);        // border tile of column `wave`
+  v4d cacc = {0.0, 0.0, 0.0, 0.0};      // wave 0: corner
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
+    }
+  }
+  for (int i = tid; i < TILE_LDS; i += SFT_NT) Xp[i] = 0.0;   // rows 7..15 of the border panel tile stay zero
+  if (tid == 0) ctl->fact_ok = 1;
+  v4d fr8 = {0.0, 0.0, 0.0, 0.0};       // wave 7: tile (kc+BT, kc) prefetched one step ahead
+  if (wave == BT - 1) fr8 = fresh_tile(BT, 0);
+  __syncthreads();
+  PH_T0();
+
+#pragma unroll 1
+  for (int k = -1; k < nT; k++) {
+    const int kc = k + 1;                  // block column published / factored in this D phase
+    if (k >= 0 && !(P.mode & 16)) {
+      // ---- C(k): X_i = A_i Linv^T (one wave per sub-diagonal tile), border panel on 112 lanes ------
+      const int i = wave + 1;
+      v4d x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const double av = Araw[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
+        const double bv = LinvK[(4 * kk + crow) * TP + ccol];
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+      }
+      if (tid < SFT_BORDER * TS) {
+        const int r = tid / TS, j = tid % TS;
+        double sacc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < TS; kk++) sacc = fma(Abord[r * TS + kk], LinvK[kk * TP + j], sacc);
+        Xp[j * TP + r] = sacc;      // slot 0 of Xp, k-major like the other panel tiles
+        Lbord[(size_t)r * Dnp + TS * k + j] = sacc;
+      }
+      double* dst = Xp + i * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+      for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
+      if (k + i < nT) {
+        double* g = Lg + tile_off(k + i, i) + crow * TS + ccol;
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[4 * q * TS] = x[q];
+      }
+      lds_barrier();
+      PH_ADD(0);
+    }
+    // ---- D(k): trailing update of window / border / corner, look-ahead factorisation of column kc --
+    const int I = kc + ((wave - kc) & (BT - 1));   // tile row held by this wave inside the window [kc, kc+BT-1]
+    if (k >= 0) {
+      double an[4], bn[4];
+      const int i = I - k;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        an[kk] = -Xp[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
+        bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];                 // border panel
+      }
+      if (I < nT && !(P.mode & 4)) {
+#pragma unroll
+        for (int b = 0; b < BT; b++) {
+          const int J = kc + ((b - kc) & (BT - 1));
+          if (J <= I) {
+            const int j = J - k;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const double bv = Xp[j * TILE_LDS + (4 * kk + crow) * TP + ccol];
+              acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bv, acc[b], 0, 0, 0);
+            }
+          }
+        }
+      }
+      {  // border tile of ring column `wave`: global tile column Jb in [kc, kc+BT-1]
+        const int Jb = kc + ((wave - kc) & (BT - 1));
+        const int j = Jb - k;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const double bv = Xp[j * TILE_LDS + (4 * kk + crow) * TP + ccol];
+          bacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bv, bacc, 0, 0, 0);
+        }
+      }
+      if (wave == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
+      }
+    }
+    if (kc < nT) {
+      if (I == kc) {
+        // owner of tile row kc: publish its border block, factor the diagonal tile, then recycle the ring row
+        if (crow + 0 < SFT_BORDER) Abord[(crow + 0) * TS + ccol] = bacc[0];
+        if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[1];
+        v4d dtile = acc[0];
+        switch (wave) {
+          case 1: dtile = acc[1]; break; case 2: dtile = acc[2]; break; case 3: dtile = acc[3]; break; case 4: dtile = acc[4]; break;
+          case 5: dtile = acc[5]; break; case 6: dtile = acc[6]; break; case 7: dtile = acc[7]; break; default: break;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (crow + 4 * q == ccol && TS * kc + ccol < Dn) dtile[q] += lambda;
+        v4d w = dtile;
+        const bool ok = (P.mode & 8) ? true : chol_inv_mfma(dtile, w);
+        if (!ok && lane == 0) ctl->fact_ok = 0;
+        double* dst = LinvK + ccol * TP + crow;
+        double* g = P.Linv + (size_t)kc * TS * TS + crow * TS + ccol;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { dst[4 * q] = w[q]; g[4 * q * TS] = w[q]; }
+        load_row(kc + BT);
+        bacc = fresh_border(kc + BT);
+      } else {
+        // publish tile (I, kc) of block column kc
+        v4d t = acc[0];
+        switch (kc & (BT - 1)) {
+          case 1: t = acc[1]; break; case 2: t = acc[2]; break; case 3: t = acc[3]; break; case 4: t = acc[4]; break;
+          case 5: t = acc[5]; break; case 6: t = acc[6]; break; case 7: t = acc[7]; break; default: break;
+        }
+        double* dst = Araw + (I - kc) * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[4 * q] = t[q];
+      }
+      if (wave == BT - 1) {
+        double* dst = Araw + BT * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[4 * q] = fr8[q];
+        fr8 = fresh_tile(kc + 1 + BT, kc + 1);
+      }
+    }
+    lds_barrier();
+    PH_ADD(5);
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = cacc[q];
+    }
+  }
+  __syncthreads();
+  // ---- corner: 6x6 Schur complement of the camera, its right-hand side, x_cam -------------------
+  if (tid == 0) {
+    bool bad = false;
+    for (int k = 0; k < 6; k++) {
+      double d = Cn[k * 7 + k];
+      for (int j = 0; j < k; j++) d -= Cn[k * 7 + j] * Cn[k * 7 + j];
+      if (!(d > 0.0)) bad = true;
+      const double piv = sqrt(d);
+      Cn[k * 7 + k] = piv;
+      for (int r = k + 1; r < 7; r++) {
+        double v = Cn[r * 7 + k];
+        for (int j = 0; j < k; j++) v -= Cn[r * 7 + j] * Cn[k * 7 + j];
+        Cn[r * 7 + k] = v / piv;
+      }
+    }
+    if (bad) ctl->fact_ok = 0;
+    if (ctl->fact_ok)
+      for (int k = 5; k >= 0; k--) {
+        double v = Cn[6 * 7 + k];
+        for (int r = k + 1; r < 6; r++) v -= Cn[r * 7 + k] * P.x[Dnp + r];
+        P.x[Dnp + k] = v / Cn[k * 7 + k];
+      }
+  }
+  __syncthreads();
+}
+
+// Back substitution in tile mode: x_J = Linv_J^T (y_J - sum_{I>J} X_{I,J}^T x_I - Lcn_J^T x_cam).
+// Wave w forms the partial product of tile (J+w+1, J); wave 0 finishes the block.
+__device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws) {
+  if (!ctl->fact_ok) return;   // like g2o, x keeps its previous content when the factorisation failed
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
+  const int nT = Dnp / TS;
+  double* xw = ws;                 // ring of BT x-tiles
+  double* part = xw + TS * BT;     // (BT+1) partial vectors
+  const int crow = lane >> 4, ccol = lane & 15;
+  const double xc = (lane < 6) ? P.x[Dnp + lane] : 0.0;
+  const double* Lg = P.Lb;
+  const double* Lbord = P.Lbord;
+#pragma unroll 1
+  for (int J = nT - 1; J >= 0; J--) {
+    {
+      const int d = wave + 1;
+      const int I = J + d;
+      double p = 0.0;
+      if (I < nT) {
+        const double* g = Lg + tile_off(I, d) + crow * TS + ccol;
+        const double* xi = xw + (I & (BT - 1)) * TS + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) p = fma(g[4 * q * TS], xi[4 * q], p);
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+      }
+      if (lane < TS) part[d * TS + lane] = p;
+    }
+    v4d li = {0.0, 0.0, 0.0, 0.0};
+    double y = 0.0;
+    if (wave == 1) {
+      double p = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const double xr = bcast_lane(xc, r);
+        if (lane < TS) p = fma(Lbord[(size_t)r * Dnp + TS * J + lane], xr, p);
+      }
+      if (lane < TS) part[lane] = p;
+    } else if (wave == 0) {
+      const double* g = P.Linv + (size_t)J * TS * TS + crow * TS + ccol;
+#pragma unroll
+      for (int q = 0; q < 4; q++) li[q] = g[4 * q * TS];
+      y = Lbord[(size_t)6 * Dnp + TS * J + ccol];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double v = y;
+#pragma unroll
+      for (int i = 0; i <= BT; i++) v -= part[i * TS + ccol];
+      // x[c] = sum_r Linv[r][c] v[r]   (v is replicated in every 16-lane group)
+      double p = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) p = fma(li[q], __shfl(v, crow + 4 * q, 64), p);
+      p += __shfl_xor(p, 16, 64);
+      p += __shfl_xor(p, 32, 64);
+      if (lane < TS) { xw[(J & (BT - 1)) * TS + lane] = p; P.x[TS * J + lane] = p; }
+    }
+    __syncthreads();
   }
 }
 
@@ -641,17 +1028,28 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   // ---- initial state, zeroed system with identity padding --------------------------------
   for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
-  for (size_t i = tid; i < (size_t)Dnp * ldh; i += SFT_NT) {
-    const int k = (int)(i % ldh), r = (int)(i / ldh);
-    P.Hb[i] = (k == kd && r >= Dn) ? 1.0 : 0.0;
+  if (P.tile_mode) {
+    const size_t nel = (size_t)(Dnp / TS) * (BT + 1) * TS * TS;
+    for (size_t i = tid; i < nel; i += SFT_NT) {
+      const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % (BT + 1)), I = (int)(i / ((size_t)(BT + 1) * TS * TS));
+      const bool pad_diag = td == 0 && (e / TS) == (e % TS) && TS * I + (e % TS) >= Dn;
+      P.Hb[i] = pad_diag ? 1.0 : 0.0;
+    }
+  } else {
+    for (size_t i = tid; i < (size_t)Dnp * ldh; i += SFT_NT) {
+      const int k = (int)(i % ldh), r = (int)(i / ldh);
+      P.Hb[i] = (k == kd && r >= Dn) ? 1.0 : 0.0;
+    }
   }
   for (size_t i = tid; i < (size_t)SFT_BORDER * Dnp; i += SFT_NT) P.Hbord[i] = 0.0;
   for (int i = tid; i < Dnp + 6; i += SFT_NT) P.x[i] = 0.0;
   if (tid == 0) {
     ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
     P.info[0] = 0; P.info[1] = 0; P.info[2] = 0;
+    for (int i = 0; i < 8; i++) P.dbg[i] = 0.0;
   }
   __syncthreads();
+  PH_T0();
 
   if (P.mode == 1) {  // test hook: one assembly at the initial state
     const double chi = eval_edges<true>(P, ctl, red, out);
@@ -663,10 +1061,12 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   int total_trials = 0, iters = 0;
   for (int it = 0; it < P.max_iters; it++) {
     const double chi0 = eval_edges<true>(P, ctl, red, out);
+    PH_ADD(1);
     assemble(P, red, out);
+    PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
-      for (int r = tid; r < Dn; r += SFT_NT) mx = fmax(mx, fabs(P.Hb[(size_t)r * ldh + kd]));
+      for (int r = tid; r < Dn; r += SFT_NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
       if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
       mx = block_max(mx, red);
       if (tid == 0) { ctl->lambda = 1e-5 * mx; ctl->ni = 2.0; ctl->nbad = 0; }
@@ -680,7 +1080,16 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
       // push
       for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz_bak[i] = P.xyz[i];
       double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
-      factor_and_solve(P, ctl, panel, red);
+      PH_ADD(7);
+      if (P.tile_mode) {
+        factor_tiles(P, ctl, panel);
+        PH_RESET();
+        backsub_tiles(P, ctl, panel);
+        PH_ADD(6);
+      } else {
+        factor_and_solve(P, ctl, panel, red);
+      }
+      PH_RESET();
       const int ok = ctl->fact_ok;
       all_ok &= ok;
       // update
@@ -698,7 +1107,9 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
       block_sum<1>(&sc, red, out);
       const double scale = out[0];
       __syncthreads();
+      PH_ADD(7);
       const double chi_new = eval_edges<false>(P, ctl, red, out);
+      PH_ADD(1);
       if (tid == 0) {
         double tempChi = ok ? chi_new : DBL_MAX;
         double rho = (ctl->chi_cur - tempChi);
@@ -723,6 +1134,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
       }
       again = (ctl->rho < 0) && (ctl->qmax < 10);
       __syncthreads();
+      PH_ADD(7);
     } while (again);
     total_trials += ctl->qmax;
     iters++;
@@ -766,8 +1178,10 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd) {
   const size_t rows = NB + kd + SFT_BORDER;
   const size_t LDP = rows | 1;
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
-  const size_t backsub = NB + 32 * NB + NB * NB;
+  const size_t backsub = NB + (SFT_NT / NB) * NB + NB * NB;
   if (backsub > panel) panel = backsub;
+  const size_t tiles = (size_t)(2 * (BT + 1) + 1) * TILE_LDS + SFT_BORDER * TS + 64;
+  if (kd <= TS * BT) panel = tiles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
 

@@ -12,7 +12,7 @@
 #pragma once
 #include <stdint.h>
 
-#define SFT_NT 1024            // threads of the per-problem workgroup (16 wavefronts, one CU)
+#define SFT_NT 512             // threads of the per-problem workgroup (8 wavefronts: 2 per SIMD, 256-VGPR budget)
 #define SFT_JOBS_STRIDE 36     // doubles per observation Jacobian record
 #define SFT_BORDER 7           // 6 camera rows + the right-hand side carried through the factorisation
 
@@ -26,6 +26,7 @@
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
+  int32_t tile_mode, pad0;  // 1: 16x16-tile band storage + MFMA factorisation (kd <= 128); 0: row-major band (general)
   double fx, fy, cx, cy;
   double w_ref, w_curv, w_str, hub_delta, hub_dsqr;
   // template (shared by every problem of a batch)
@@ -61,12 +62,14 @@ struct SftDev {
   double* Jstar;            // S*4  (u, r)
   double* Jstr;             // Es*4 (g, e)
   double* Jref;             // V*4  (e)
-  double* Hb;               // Dn*ldh   lower band, row-major: (r,c) at r*ldh + c-r+kd
+  double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
+                            // tile mode: nT*(BT+1) row-major 16x16 tiles, tile (I,J) at (I*(BT+1) + I-J)*256
   double* Hbord;            // 7*Dn     rows 0-5: camera x node, row 6: b_node
   double* Hcorner;          // 7*7      camera x camera (lower) + b_cam in row 6
   double* Lb;               // Dn*ldh
   double* Lbord;            // 7*Dn
   double* Lcorner;          // 7*7
+  double* Linv;             // tile mode: nT inverse diagonal tiles (16x16 row-major)
   double* x;                // Dn+6
   // outputs
   double* chi2_obs;         // M

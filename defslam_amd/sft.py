@@ -173,6 +173,11 @@ class Context:
         self._check(self._L.dsh_sft_batch_run_timed(self._h, int(launches), C.byref(ms)), "dsh_sft_batch_run_timed")
         return ms.value
 
+    def phase_ms(self, b: int = 0):
+        out = np.zeros(8)
+        self._check(self._L.dsh_sft_batch_phase_ms(self._h, b, _ptr(out, C.c_double)), "dsh_sft_batch_phase_ms")
+        return dict(trsm=out[0], residuals=out[1], assembly=out[2], copy=out[3], panel=out[4], update=out[5], backsub=out[6], control=out[7])
+
     def synchronize(self):
         self._check(self._L.dsh_synchronize(self._h), "dsh_synchronize")
 

@@ -113,6 +113,10 @@ int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
 /* `launches` back-to-back runs bracketed by HIP events recorded on dsh_stream; returns the elapsed
  * milliseconds between the two events (device time of the launches, no host round trips inside). */
 int dsh_sft_batch_run_timed(dsh_ctx* ctx, int launches, double* total_ms);
+/* Per-phase device time of problem b in the last run, milliseconds (constant 100 MHz counter read by one lane):
+ * out8[1] residuals, [2] normal-equation assembly, [3] H->L copy, [4] panel factorisation, [5] trailing update,
+ * [6] back substitution, [7] state update + LM control.  out8[0] is reserved. */
+int dsh_sft_batch_phase_ms(dsh_ctx* ctx, int b, double* out8);
 /* Totals of the last completed run (valid after a synchronise): outer iterations and trials over the batch. */
 int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
 /* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts

@@ -1,0 +1,17 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+from defslam_amd import synth, sft
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = sft.Context(0)
+rows, cols, m = synth.CONFIGS[cfg]
+tmpl = synth.make_grid_template(rows, cols)
+ctx.template_build(tmpl.xyz0, tmpl.facets)
+frames = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(B)]
+ctx.batch_upload(frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
+ctx.batch_run(); ctx.synchronize()
+ms = ctx.batch_run_timed(3) / 3
+it, tr = ctx.batch_counts()
+ph = ctx.phase_ms(0)
+print(f"{cfg} B={B}: {ms:.2f} ms/launch, iters {it} trials {tr}, per-trial {ms/ (tr/B):.3f} ms; single-problem it/s {it/B/(ms*1e-3):.0f}")
+print(" phases of problem 0 (ms):", {k: round(v, 2) for k, v in ph.items()}, "sum", round(sum(ph.values()), 2))
