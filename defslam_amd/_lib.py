@@ -59,12 +59,22 @@ class SftResultC(C.Structure):
     ]
 
 
+class BbsC(C.Structure):
+    _fields_ = [("umin", C.c_double), ("umax", C.c_double), ("nptsu", C.c_int32), ("vmin", C.c_double), ("vmax", C.c_double),
+                ("nptsv", C.c_int32), ("valdim", C.c_int32)]
+
+
+DIFFPROP_FIELDS = ["I1u", "I1v", "I2u", "I2v", "J12a", "J12b", "J12c", "J12d", "J21a", "J21b", "J21c", "J21d",
+                   "H12uux", "H12uuy", "H12uvx", "H12uvy", "H12vvx", "H12vvy"]
+
+
 # Every symbol include/defslam_hip.h declares (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
     "dsh_create", "dsh_destroy", "dsh_last_error", "dsh_stream", "dsh_synchronize",
     "dsh_template_build", "dsh_template_set", "dsh_template_dims", "dsh_template_get", "dsh_template_embed",
     "dsh_sft_solve", "dsh_sft_batch_upload", "dsh_sft_batch_run", "dsh_sft_batch_download",
     "dsh_sft_batch_run_timed", "dsh_sft_batch_phase_ms", "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
+    "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate",
 ]
 
 _lib = None
@@ -102,6 +112,10 @@ def load() -> C.CDLL:
     L.dsh_sft_batch_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dsh_sft_batch_problem_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), c_i32_p]
     L.dsh_sft_debug_system.argtypes = [vp, C.c_int, C.c_int32, c_double_p, c_double_p, c_double_p]
+    L.dsh_bbs_eval.argtypes = [vp, C.POINTER(BbsC), c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, c_double_p, c_u8_p]
+    L.dsh_bbs_coloc.argtypes = [vp, C.POINTER(BbsC), c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, c_i32_p, c_double_p, c_i32_p]
+    L.dsh_normals_estimate.argtypes = [vp, C.c_int, c_i32_p, c_float_p, c_u8_p, c_float_p, c_u8_p, c_float_p, c_u8_p, c_float_p,
+                                       c_double_p, c_double_p, c_i32_p, c_float_p, c_float_p, c_u8_p, c_i32_p]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("dsh_last_error", "dsh_stream"):

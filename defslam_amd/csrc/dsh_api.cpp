@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/defslam_hip.h"
+#include "dsh_ctx.h"
 #include "dsh_template.h"
 #include "sft_problem.h"
 
@@ -97,11 +98,7 @@ struct Arena {  // byte layout of a device allocation, 256-byte aligned slices
 
 }  // namespace
 
-struct dsh_ctx {
-  int device = 0;
-  bool host_only = false;          // device == -1: template + packer only (CPU tests of the host logic)
-  hipStream_t stream = nullptr;
-  std::string err;
+struct dsh_ctx : dsh_ctx_base {
   dsh::TemplateHost tmpl;
   // device copy of the template
   char* d_tmpl = nullptr;

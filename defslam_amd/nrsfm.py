@@ -1,0 +1,93 @@
+"""Host-side mirror of the mapping-side (NRSfM) entry points, on top of the C ABI.
+
+Reference interfaces being mirrored:
+  * BBS::eval / BBS::coloc / BBS::coloc_deriv   (Thirdparty/BBS/bbs.h:52-66)
+  * defSLAM::NormalEstimator::ObtainK1K2()      (Modules/Mapping/NormalEstimator.h:46-53)
+The WarpDatabase / MapPoint / KeyFrame objects are replaced by flat record arrays (INTEGRATION.md shows the
+shim that fills them from `WarpDatabase::getDiffDatabase()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .sft import Context, _ptr
+
+
+@dataclass
+class Bbs:
+    """BBS::bbs_t."""
+    umin: float
+    umax: float
+    nptsu: int
+    vmin: float
+    vmax: float
+    nptsv: int
+    valdim: int
+
+    def c(self) -> _lib.BbsC:
+        return _lib.BbsC(self.umin, self.umax, self.nptsu, self.vmin, self.vmax, self.nptsv, self.valdim)
+
+
+def bbs_eval(ctx: Context, bbs: Bbs, ctrlpts: np.ndarray, u: np.ndarray, v: np.ndarray, du: int = 0, dv: int = 0):
+    """BBS::eval: returns (val[n, valdim], outside[n])."""
+    ctrl = np.ascontiguousarray(ctrlpts, np.float64)
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    n = u.shape[0]
+    val = np.zeros((n, bbs.valdim))
+    outside = np.zeros(n, np.uint8)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_bbs_eval(ctx._h, C.byref(b), _ptr(ctrl, C.c_double), _ptr(u, C.c_double), _ptr(v, C.c_double), n, du, dv,
+                                   _ptr(val, C.c_double), _ptr(outside, C.c_uint8)), "dsh_bbs_eval")
+    return val, outside.astype(bool)
+
+
+def bbs_coloc(ctx: Context, bbs: Bbs, u: np.ndarray, v: np.ndarray, du: int = 0, dv: int = 0):
+    """Row view of BBS::coloc / coloc_deriv: (cols[n,16], w[n,16], n_outside)."""
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    n = u.shape[0]
+    cols = np.zeros((n, 16), np.int32)
+    w = np.zeros((n, 16))
+    cnt = C.c_int32(0)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_bbs_coloc(ctx._h, C.byref(b), _ptr(u, C.c_double), _ptr(v, C.c_double), n, du, dv, _ptr(cols, C.c_int32),
+                                    _ptr(w, C.c_double), C.byref(cnt)), "dsh_bbs_coloc")
+    return cols, w, cnt.value
+
+
+@dataclass
+class NormalsResult:
+    k1k2: np.ndarray
+    cov: np.ndarray
+    status: np.ndarray
+    normal_ref: np.ndarray
+    normal_rec: np.ndarray
+    rec_written: np.ndarray
+    iters: np.ndarray
+
+
+def ObtainK1K2(ctx: Context, rec_ptr, recs, rec_is_ref, rec_first_normal, rec_has_first_normal, x0, has_x0, ref_uv) -> NormalsResult:
+    """NormalEstimator::ObtainK1K2 over the points with new observations. `recs` is (R, 18) float32 in DIFFPROP_FIELDS order."""
+    rec_ptr = np.ascontiguousarray(rec_ptr, np.int32)
+    P = rec_ptr.shape[0] - 1
+    recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 18)
+    R = recs.shape[0]
+    is_ref = np.ascontiguousarray(rec_is_ref, np.uint8)
+    fn = np.ascontiguousarray(rec_first_normal, np.float32).reshape(-1, 2)
+    hfn = np.ascontiguousarray(rec_has_first_normal, np.uint8)
+    x0 = np.ascontiguousarray(x0, np.float32).reshape(-1, 2)
+    hx0 = np.ascontiguousarray(has_x0, np.uint8)
+    uv = np.ascontiguousarray(ref_uv, np.float32).reshape(-1, 2)
+    out = NormalsResult(np.zeros((P, 2)), np.zeros((P, 2, 2)), np.zeros(P, np.int32), np.zeros((P, 3), np.float32),
+                        np.zeros((R, 3), np.float32), np.zeros(R, np.uint8), np.zeros(P, np.int32))
+    ctx._check(ctx._L.dsh_normals_estimate(ctx._h, P, _ptr(rec_ptr, C.c_int32), _ptr(recs, C.c_float), _ptr(is_ref, C.c_uint8), _ptr(fn, C.c_float),
+                                           _ptr(hfn, C.c_uint8), _ptr(x0, C.c_float), _ptr(hx0, C.c_uint8), _ptr(uv, C.c_float),
+                                           _ptr(out.k1k2, C.c_double), _ptr(out.cov, C.c_double), _ptr(out.status, C.c_int32),
+                                           _ptr(out.normal_ref, C.c_float), _ptr(out.normal_rec, C.c_float), _ptr(out.rec_written, C.c_uint8),
+                                           _ptr(out.iters, C.c_int32)), "dsh_normals_estimate")
+    return out

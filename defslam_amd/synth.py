@@ -142,3 +142,66 @@ def make_problem(config: str = "C2", problem_id: int = 0):
     rows, cols, m = CONFIGS[config]
     tmpl = make_grid_template(rows, cols)
     return tmpl, make_frame(tmpl, m, problem_id)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# NRSfM normals: a rigid planar scene seen from several keyframes.  For a plane N.X = 1 (camera-1 frame) the
+# inter-image warp in normalised coordinates is the homography (R + t N^T); its first and second derivatives
+# are the DiffProp fields (Modules/Mapping/diffProp.h, SchwarpDatabase.cc:299-345) and the solution of the
+# two bicubic polynomials is k = (N1, N2) / (N.[u,v,1])  (normal ~ [k1, k2, 1 - k1 u - k2 v]).
+# ---------------------------------------------------------------------------------------------------------
+def _homography_derivs(Hm, u, v):
+    p = np.array([u, v, 1.0])
+    h = Hm @ p
+    ha, hb = Hm[:, 0], Hm[:, 1]
+    eta = h[:2] / h[2]
+    d1 = {}
+    for name, hd in (("u", ha), ("v", hb)):
+        d1[name] = (hd[:2] * h[2] - h[:2] * hd[2]) / h[2] ** 2
+    d2 = {}
+    for (na, hd_a), (nb, hd_b) in ((("u", ha), ("u", ha)), (("u", ha), ("v", hb)), (("v", hb), ("v", hb))):
+        d2[na + nb] = -(hd_a[:2] * hd_b[2] + hd_b[:2] * hd_a[2]) / h[2] ** 2 + 2 * h[:2] * hd_a[2] * hd_b[2] / h[2] ** 3
+    return eta, d1, d2
+
+
+def make_normals_scene(n_points: int = 200, n_views: int = 4, seed: int = 7, nonref_frac: float = 0.3):
+    """Returns a dict with the flat arrays of dsh_normals_estimate plus the ground-truth (k1,k2) per point."""
+    rng = np.random.default_rng(seed)
+    recs, is_ref, first_n, has_first_n, rec_ptr = [], [], [], [], [0]
+    x0, has_x0, ref_uv, truth = [], [], [], []
+    for p in range(n_points):
+        # plane in the reference camera frame: N.X = 1, roughly fronto-parallel at depth ~1
+        n = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), 1.0])
+        N = n / rng.uniform(0.8, 1.5)
+        u, v = rng.uniform(-0.4, 0.4, size=2)
+        k_true = N[:2] / (N @ np.array([u, v, 1.0]))
+        nv = int(rng.integers(1, n_views + 1))
+        for _ in range(nv):
+            w = rng.normal(size=3)
+            w *= rng.uniform(0.03, 0.15) / np.linalg.norm(w)
+            R = _rodrigues(w)
+            t = rng.uniform(-0.15, 0.15, size=3)
+            Hm = R + np.outer(t, N)
+            eta, d1, d2 = _homography_derivs(Hm, u, v)
+            a, b = d1["u"]      # d eta_u/du, d eta_v/du
+            c, d = d1["v"]
+            det = a * d - c * b
+            rec = [u, v, eta[0], eta[1], a, b, c, d, d / det, -c / det, -b / det, a / det,
+                   d2["uu"][0], d2["uu"][1], d2["uv"][0], d2["uv"][1], d2["vv"][0], d2["vv"][1]]
+            # J21 fields follow SchwarpDatabase.cc:322-329: J21a = J12d/det, J21b = -J12c/det, J21c = -J12b/det, J21d = J12a/det
+            recs.append(rec)
+            ref = rng.uniform() >= nonref_frac
+            is_ref.append(1 if ref else 0)
+            hf = (not ref) and rng.uniform() < 0.7
+            has_first_n.append(1 if hf else 0)
+            first_n.append(list(k_true + rng.normal(scale=1e-3, size=2)) if hf else [0.0, 0.0])
+        rec_ptr.append(len(recs))
+        hx = rng.uniform() < 0.5
+        has_x0.append(1 if hx else 0)
+        x0.append(list(k_true + rng.normal(scale=0.05, size=2)) if hx else [0.0, 0.0])
+        ref_uv.append([u, v])
+        truth.append(k_true)
+    return dict(rec_ptr=np.asarray(rec_ptr, np.int32), recs=np.asarray(recs, np.float32).reshape(-1, 18), rec_is_ref=np.asarray(is_ref, np.uint8),
+                rec_first_normal=np.asarray(first_n, np.float32).reshape(-1, 2), rec_has_first_normal=np.asarray(has_first_n, np.uint8),
+                x0=np.asarray(x0, np.float32), has_x0=np.asarray(has_x0, np.uint8), ref_uv=np.asarray(ref_uv, np.float32),
+                k_true=np.asarray(truth))

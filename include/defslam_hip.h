@@ -128,6 +128,51 @@ int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int
  * nodes ascending; column-major D x D) plus b and the robust chi2.  H/bvec may be NULL. */
 int dsh_sft_debug_system(dsh_ctx* ctx, int b, int32_t D, double* H, double* bvec, double* chi2);
 
+/* ---- NRSfM mapping side ----------------------------------------------------------------------- */
+/* Uniform bicubic B-spline (BBS::bbs_t, Thirdparty/BBS/bbs.h:41-50). */
+typedef struct dsh_bbs {
+  double umin, umax;
+  int32_t nptsu;
+  double vmin, vmax;
+  int32_t nptsv;
+  int32_t valdim;
+} dsh_bbs;
+
+/* BBS::eval (Thirdparty/BBS/bbs.h:59, bbs.cc:155-195): val[valdim*k + d] = d^du d^dv spline(u_k, v_k).
+ * ctrl: valdim x (nptsu*nptsv), index valdim*(iu*nptsv + iv) + d.  outside[k] (may be NULL) = 1 for a site outside the
+ * definition domain (the reference reads out of bounds there; here the value is 0). */
+int dsh_bbs_eval(dsh_ctx* ctx, const dsh_bbs* bbs, const double* ctrl, const double* u, const double* v, int n, int du, int dv,
+                 double* val, uint8_t* outside);
+/* Row view of BBS::coloc / BBS::coloc_deriv (bbs.h:61-63, bbs.cc:214-355): for site k the 16 (column, weight) pairs in
+ * (iu, iv) order, cols[16k + 4iu + iv] = (iu+Iu)*nptsv + iv+Iv.  n_outside counts sites outside the domain (the reference
+ * returns error code 1 for them); their columns are -1. */
+int dsh_bbs_coloc(dsh_ctx* ctx, const dsh_bbs* bbs, const double* u, const double* v, int n, int du, int dv, int32_t* cols, double* w,
+                  int32_t* n_outside);
+
+/* The float32 fields of defSLAM::DiffProp the normal solve reads (Modules/Mapping/diffProp.h:52-83), in this order. */
+typedef struct dsh_diffprop {
+  float I1u, I1v, I2u, I2v;
+  float J12a, J12b, J12c, J12d;
+  float J21a, J21b, J21c, J21d;
+  float H12uux, H12uuy, H12uvx, H12uvy, H12vvx, H12vvy;
+} dsh_diffprop;
+
+/* NormalEstimator::ObtainK1K2 (Modules/Mapping/NormalEstimator.h:53, NormalEstimator.cc:38-229) over the P map points that
+ * have new observations.
+ *   rec_ptr[P+1]            CSR: DiffProp records of point p are rec_ptr[p] .. rec_ptr[p+1]-1
+ *   rec_is_ref[R]           record.KFToKF.first is the point's reference keyframe (it contributes a residual block)
+ *   rec_first_normal[R*2], rec_has_first_normal[R]   (k1,k2) stored for the record's first keyframe (used by non-ref records)
+ *   x0[P*2], has_x0[P]      previous normal of the reference keyframe; without it the start is (0,-0)
+ *   ref_uv[P*2]             mpKeypointNorm of the point in its reference keyframe
+ * Outputs: k1k2[P*2]; cov[P*4] (may be NULL); status[P]: 0 solved and written, 1 no residual block, 2 covariance failed
+ * (rank-deficient Jacobian -> the reference skips the point); normal_ref[P*3] float = (k1,k2,1-k1 u-k2 v) (may be NULL);
+ * normal_rec[R*3] float + rec_written[R]: normals propagated to the second keyframe of each record (may be NULL); iters[P]
+ * (may be NULL). */
+int dsh_normals_estimate(dsh_ctx* ctx, int P, const int32_t* rec_ptr, const dsh_diffprop* recs, const uint8_t* rec_is_ref,
+                         const float* rec_first_normal, const uint8_t* rec_has_first_normal, const float* x0, const uint8_t* has_x0,
+                         const float* ref_uv, double* k1k2, double* cov, int32_t* status, float* normal_ref, float* normal_rec,
+                         uint8_t* rec_written, int32_t* iters);
+
 #ifdef __cplusplus
 }
 #endif

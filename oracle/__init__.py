@@ -164,3 +164,147 @@ def sft_system(tc: TemplateConsts, Tcw, K, n_frame, obs_nodes, obs_bary, obs_uv,
     chi = C.c_double(0)
     call(dim, H, b, chi)
     return H, b, chi.value
+
+
+# ---- B-spline oracle + the reference's own bbs.cc (oracle/_ref/libbbs_ref.so) -------------------------------
+class _BbsT(C.Structure):  # BBS::bbs_t, Thirdparty/BBS/bbs.h:41-50
+    _fields_ = [("umin", C.c_double), ("umax", C.c_double), ("nptsu", C.c_int), ("vmin", C.c_double), ("vmax", C.c_double),
+                ("nptsv", C.c_int), ("valdim", C.c_int)]
+
+
+def bbs_eval(bbs, ctrl, u, v, du=0, dv=0):
+    """oracle/bbs_oracle.c; bbs = (umin, umax, nptsu, vmin, vmax, nptsv, valdim)."""
+    L = lib()
+    umin, umax, nptsu, vmin, vmax, nptsv, valdim = bbs
+    ctrl = np.ascontiguousarray(ctrl, np.float64)
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    n = u.shape[0]
+    val = np.zeros((n, valdim))
+    st = np.zeros(n, np.uint8)
+    D = C.c_double
+    L.bbs_oracle_eval(D(umin), D(umax), int(nptsu), D(vmin), D(vmax), int(nptsv), int(valdim), _p(ctrl, D), _p(u, D), _p(v, D), n, int(du), int(dv),
+                      _p(val, D), _p(st, C.c_uint8))
+    return val, st.astype(bool)
+
+
+def bbs_coloc(bbs, u, v, du=0, dv=0):
+    L = lib()
+    L.bbs_oracle_coloc.restype = C.c_int
+    umin, umax, nptsu, vmin, vmax, nptsv, _ = bbs
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    n = u.shape[0]
+    cols = np.zeros((n, 16), np.int32)
+    w = np.zeros((n, 16))
+    D = C.c_double
+    ret = L.bbs_oracle_coloc(D(umin), D(umax), int(nptsu), D(vmin), D(vmax), int(nptsv), _p(u, D), _p(v, D), n, int(du), int(dv),
+                             _p(cols, C.c_int32), _p(w, D))
+    return cols, w, ret
+
+
+def bbs_basis(order, t):
+    L = lib()
+    b = (C.c_double * 4)()
+    L.bbs_oracle_basis(int(order), C.c_double(t), b)
+    return np.array(b[:])
+
+
+_REF = None
+
+
+def ref_bbs_lib():
+    """The reference's bbs.cc compiled as-is (oracle/Makefile `ref`); None when it has not been built."""
+    global _REF
+    if _REF is None:
+        so = os.path.join(_HERE, "_ref", "libbbs_ref.so")
+        if not os.path.exists(so):
+            return None
+        _REF = C.CDLL(so)
+    return _REF
+
+
+def ref_bbs_eval(bbs, ctrl, u, v, du=0, dv=0):
+    R = ref_bbs_lib()
+    b = _BbsT(*bbs)
+    ctrl = np.ascontiguousarray(ctrl, np.float64)
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    n = u.shape[0]
+    val = np.zeros((n, bbs[6]))
+    D = C.c_double
+    R._ZN3BBS4evalEPNS_6_bbs_tEPdS2_S2_iS2_ii(C.byref(b), _p(ctrl, D), _p(u, D), _p(v, D), n, _p(val, D), int(du), int(dv))
+    return val
+
+
+def ref_bbs_basis(order, t):
+    R = ref_bbs_lib()
+    b = (C.c_double * 4)()
+    fn = [R._ZN3BBS10eval_basisEdPd, R._ZN3BBS12eval_basis_dEdPd, R._ZN3BBS13eval_basis_ddEdPd][order]
+    fn(C.c_double(t), b)
+    return np.array(b[:])
+
+
+def ref_bbs_coloc_dense(bbs, u, v, du=0, dv=0):
+    """Dense (nsites x ncols) colocation matrix from the reference's CSC output; returns (A, ret_code)."""
+    R = ref_bbs_lib()
+    b = _BbsT(*bbs)
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    n = u.shape[0]
+    ncol = bbs[2] * bbs[5]
+    pr = np.zeros(16 * n)
+    ir = np.zeros(16 * n, np.uint64)
+    jc = np.zeros(ncol + 1, np.uint64)
+    D = C.c_double
+    f = R._ZN3BBS11coloc_derivEPNS_6_bbs_tEPdS2_iiiS2_PmS3_
+    f.restype = C.c_int
+    ret = f(C.byref(b), _p(u, D), _p(v, D), n, int(du), int(dv), _p(pr, D), _p(ir, C.c_uint64), _p(jc, C.c_uint64))
+    A = np.zeros((n, ncol))
+    if ret == 0:
+        for j in range(ncol):
+            for q in range(int(jc[j]), int(jc[j + 1])):
+                A[int(ir[q]), j] = pr[q]
+    return A, ret
+
+
+# ---- normals oracle ----------------------------------------------------------------------------------
+def normals(rec_ptr, recs, rec_is_ref, rec_first_n, rec_has_first_n, x0, has_x0, ref_uv):
+    L = lib()
+    rec_ptr = np.ascontiguousarray(rec_ptr, np.int32)
+    P = rec_ptr.shape[0] - 1
+    recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 18)
+    R = recs.shape[0]
+    is_ref = np.ascontiguousarray(rec_is_ref, np.uint8)
+    fn = np.ascontiguousarray(rec_first_n, np.float32).reshape(-1, 2)
+    hfn = np.ascontiguousarray(rec_has_first_n, np.uint8)
+    x0 = np.ascontiguousarray(x0, np.float32).reshape(-1, 2)
+    hx0 = np.ascontiguousarray(has_x0, np.uint8)
+    uv = np.ascontiguousarray(ref_uv, np.float32).reshape(-1, 2)
+    out = dict(k1k2=np.zeros((P, 2)), cov=np.zeros((P, 2, 2)), status=np.zeros(P, np.int32), normal_ref=np.zeros((P, 3), np.float32),
+               normal_rec=np.zeros((R, 3), np.float32), rec_written=np.zeros(R, np.uint8), iters=np.zeros(P, np.int32), term=np.zeros(P, np.int32))
+    L.nrsfm_oracle_normals(P, _p(rec_ptr, C.c_int32), _p(recs, C.c_float), _p(is_ref, C.c_uint8), _p(fn, C.c_float), _p(hfn, C.c_uint8),
+                           _p(x0, C.c_float), _p(hx0, C.c_uint8), _p(uv, C.c_float), _p(out["k1k2"], C.c_double), _p(out["cov"], C.c_double),
+                           _p(out["status"], C.c_int32), _p(out["normal_ref"], C.c_float), _p(out["normal_rec"], C.c_float),
+                           _p(out["rec_written"], C.c_uint8), _p(out["iters"], C.c_int32), _p(out["term"], C.c_int32))
+    return out
+
+
+def record_coeffs(rec18):
+    L = lib()
+    rec = np.ascontiguousarray(rec18, np.float32)
+    q1 = np.zeros(10)
+    q2 = np.zeros(10)
+    L.nrsfm_oracle_record_coeffs(_p(rec, C.c_float), _p(q1, C.c_double), _p(q2, C.c_double))
+    return q1, q2
+
+
+def poly_eval(q1, q2, x):
+    L = lib()
+    q1 = np.ascontiguousarray(q1, np.float64)
+    q2 = np.ascontiguousarray(q2, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    e = np.zeros(2)
+    J = np.zeros(4)
+    L.nrsfm_oracle_poly_eval(_p(q1, C.c_double), _p(q2, C.c_double), _p(x, C.c_double), _p(e, C.c_double), _p(J, C.c_double))
+    return e, J.reshape(2, 2)

@@ -1,0 +1,100 @@
+"""GPU parity tests of the mapping-side kernels, through the C ABI, against the CPU oracles and the golden vectors
+produced by the reference's own bbs.cc."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BBS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "bbs_*.npz")))
+ORDERS = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2)]
+
+
+@pytest.mark.parametrize("path", BBS_GOLDEN, ids=[os.path.basename(p) for p in BBS_GOLDEN])
+def test_bbs_eval_and_coloc_match_reference_golden(gpu_ctx, path):
+    from defslam_amd import nrsfm
+    g = np.load(path)
+    b = g["bbs"]
+    bbs = nrsfm.Bbs(float(b[0]), float(b[1]), int(b[2]), float(b[3]), float(b[4]), int(b[5]), int(b[6]))
+    for du, dv in ORDERS:
+        val, out = nrsfm.bbs_eval(gpu_ctx, bbs, g["ctrl"], g["u"], g["v"], du, dv)
+        assert not out.any()
+        # same expression order, no FMA contraction: equal to the reference's bbs.cc up to the last bit of pow()
+        np.testing.assert_allclose(val, g[f"val_{du}{dv}"], rtol=1e-15, atol=0)
+        cols, w, n_out = nrsfm.bbs_coloc(gpu_ctx, bbs, g["u"], g["v"], du, dv)
+        assert n_out == 0
+        A = np.zeros_like(g[f"coloc_{du}{dv}"])
+        np.add.at(A, (np.repeat(np.arange(cols.shape[0]), 16), cols.ravel()), w.ravel())
+        ref = g[f"coloc_{du}{dv}"]
+        np.testing.assert_array_equal(A != 0, ref != 0)           # bit-exact tap indexing
+        np.testing.assert_allclose(A, ref, rtol=1e-15, atol=0)
+
+
+def test_bbs_large_and_edge_cases(gpu_ctx, oracle_mod):
+    from defslam_amd import nrsfm
+    rng = np.random.default_rng(3)
+    bbs_t = (-0.85, 0.9, 13, -0.7, 0.75, 15, 2)
+    bbs = nrsfm.Bbs(*bbs_t)
+    ctrl = rng.normal(size=(195, 2))
+    n = 200_003                                               # ragged size, > one grid sweep
+    u, v = rng.uniform(-0.85, 0.9, n), rng.uniform(-0.7, 0.75, n)
+    u[:4] = [-0.85, 0.9, 0.9, -0.85]
+    v[:4] = [-0.7, 0.75, -0.7, 0.75]
+    for du, dv in [(0, 0), (1, 1), (0, 2)]:
+        val, out = nrsfm.bbs_eval(gpu_ctx, bbs, ctrl, u, v, du, dv)
+        ref, _ = oracle_mod.bbs_eval(bbs_t, ctrl, u, v, du, dv)
+        assert not out.any()
+        np.testing.assert_allclose(val, ref, rtol=1e-15, atol=0)
+    # outside sites are flagged, empty input is fine
+    val, out = nrsfm.bbs_eval(gpu_ctx, bbs, ctrl, np.array([-1.0, 0.0, 2.0]), np.array([0.0, 0.0, 0.0]))
+    assert out.tolist() == [True, False, True] and (val[[0, 2]] == 0).all()
+    _, _, n_out = nrsfm.bbs_coloc(gpu_ctx, bbs, np.array([-1.0, 0.0, 2.0]), np.array([0.0, 0.0, 0.0]))
+    assert n_out == 2
+    val, out = nrsfm.bbs_eval(gpu_ctx, bbs, ctrl, np.zeros(0), np.zeros(0))
+    assert val.shape == (0, 2)
+    # a control grid too large for LDS takes the global-memory path
+    big = nrsfm.Bbs(0.0, 1.0, 120, 0.0, 1.0, 100, 1)
+    cb = rng.normal(size=(12000, 1))
+    ub, vb = rng.uniform(0, 1, 1000), rng.uniform(0, 1, 1000)
+    vg, _ = nrsfm.bbs_eval(gpu_ctx, big, cb, ub, vb, 1, 0)
+    vr, _ = oracle_mod.bbs_eval((0.0, 1.0, 120, 0.0, 1.0, 100, 1), cb, ub, vb, 1, 0)
+    np.testing.assert_allclose(vg, vr, rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("n_points,n_views,seed", [(300, 4, 7), (5000, 6, 1), (1, 1, 2)])
+def test_normals_match_oracle(gpu_ctx, oracle_mod, n_points, n_views, seed):
+    from defslam_amd import nrsfm, synth
+    sc = synth.make_normals_scene(n_points, n_views, seed)
+    keys = ["rec_ptr", "recs", "rec_is_ref", "rec_first_normal", "rec_has_first_normal", "x0", "has_x0", "ref_uv"]
+    o = oracle_mod.normals(*[sc[k] for k in keys])
+    g = nrsfm.ObtainK1K2(gpu_ctx, *[sc[k] for k in keys])
+    np.testing.assert_array_equal(g.status, o["status"])            # which points are solved / skipped / rejected
+    np.testing.assert_array_equal(g.rec_written, o["rec_written"])  # which keyframe normals are written
+    np.testing.assert_array_equal(g.iters, o["iters"])              # same accept/reject sequence
+    solved = o["status"] == 0
+    np.testing.assert_allclose(g.k1k2[solved], o["k1k2"][solved], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g.cov[solved], o["cov"][solved], rtol=1e-7)
+    np.testing.assert_allclose(g.normal_ref[solved], o["normal_ref"][solved], rtol=0, atol=1e-6)
+    wr = o["rec_written"].astype(bool)
+    np.testing.assert_allclose(g.normal_rec[wr], o["normal_rec"][wr], rtol=0, atol=1e-6)
+
+
+def test_normals_degenerate_inputs(gpu_ctx, oracle_mod):
+    from defslam_amd import nrsfm
+    # point 0: no records at all; point 1: rank-deficient (identity warp); point 2: only non-reference records
+    recs = np.zeros((3, 18), np.float32)
+    recs[:, 4] = 1.0
+    recs[:, 7] = 1.0
+    recs[:, 8] = 1.0
+    recs[:, 11] = 1.0
+    rec_ptr = np.array([0, 0, 1, 3], np.int32)
+    is_ref = np.array([1, 0, 0], np.uint8)
+    args = (rec_ptr, recs, is_ref, np.full((3, 2), 0.25, np.float32), np.array([0, 1, 0], np.uint8), np.zeros((3, 2), np.float32), np.zeros(3, np.uint8),
+            np.zeros((3, 2), np.float32))
+    o = oracle_mod.normals(*args)
+    g = nrsfm.ObtainK1K2(gpu_ctx, *args)
+    assert g.status.tolist() == o["status"].tolist() == [1, 2, 1]
+    assert g.rec_written.tolist() == o["rec_written"].tolist() == [0, 1, 0]
+    np.testing.assert_array_equal(g.normal_rec[1], o["normal_rec"][1])

@@ -1,0 +1,132 @@
+"""CPU tests of the mapping-side oracles: B-spline (pinned to the reference's own bbs.cc) and normals (unpinned: Ceres)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+BBS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "bbs_*.npz")))
+ORDERS = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2)]
+
+
+def _bbs(g):
+    b = g["bbs"]
+    return (float(b[0]), float(b[1]), int(b[2]), float(b[3]), float(b[4]), int(b[5]), int(b[6]))
+
+
+@pytest.mark.parametrize("path", BBS_GOLDEN, ids=[os.path.basename(p) for p in BBS_GOLDEN])
+def test_bbs_oracle_bit_exact_vs_reference_golden(oracle_mod, path):
+    g = np.load(path)
+    bbs = _bbs(g)
+    for du, dv in ORDERS:
+        val, out = oracle_mod.bbs_eval(bbs, g["ctrl"], g["u"], g["v"], du, dv)
+        assert not out.any()
+        np.testing.assert_array_equal(val, g[f"val_{du}{dv}"])          # bit exact vs the reference's bbs.cc
+        cols, w, ret = oracle_mod.bbs_coloc(bbs, g["u"], g["v"], du, dv)
+        assert ret == 0
+        A = np.zeros_like(g[f"coloc_{du}{dv}"])
+        np.add.at(A, (np.repeat(np.arange(cols.shape[0]), 16), cols.ravel()), w.ravel())
+        np.testing.assert_array_equal(A, g[f"coloc_{du}{dv}"])
+    for order in range(3):
+        b = np.stack([oracle_mod.bbs_basis(order, t) for t in np.linspace(0, 1, 11)])
+        np.testing.assert_array_equal(b, g[f"basis_{order}"])
+
+
+def test_bbs_oracle_vs_live_reference_library(oracle_mod):
+    if oracle_mod.ref_bbs_lib() is None:
+        pytest.skip("oracle/_ref/libbbs_ref.so not built (reference not present)")
+    rng = np.random.default_rng(11)
+    bbs = (-0.3, 0.9, 9, 0.1, 0.8, 11, 2)
+    ctrl = rng.normal(size=(99, 2))
+    u, v = rng.uniform(-0.3, 0.9, 500), rng.uniform(0.1, 0.8, 500)
+    for du, dv in ORDERS:
+        np.testing.assert_array_equal(oracle_mod.bbs_eval(bbs, ctrl, u, v, du, dv)[0], oracle_mod.ref_bbs_eval(bbs, ctrl, u, v, du, dv))
+
+
+def test_bbs_properties(oracle_mod):
+    bbs = (0.0, 2.0, 8, -1.0, 1.0, 6, 1)
+    rng = np.random.default_rng(2)
+    u, v = rng.uniform(0, 2, 200), rng.uniform(-1, 1, 200)
+    cols, w, _ = oracle_mod.bbs_coloc(bbs, u, v)
+    np.testing.assert_allclose(w.sum(1), 1.0, atol=1e-14)            # partition of unity
+    cu, cv = np.meshgrid(np.arange(8), np.arange(6), indexing="ij")
+    # cubic B-splines reproduce linear functions of the (Greville) control abscissae
+    su, sv = 2.0 / 5, 2.0 / 3
+    ctrl = ((0.0 + su * (cu - 1)) * 3 - 2 * (-1.0 + sv * (cv - 1))).reshape(-1, 1)
+    val, _ = oracle_mod.bbs_eval(bbs, ctrl, u, v)
+    np.testing.assert_allclose(val[:, 0], 3 * u - 2 * v, atol=1e-12)
+    d, _ = oracle_mod.bbs_eval(bbs, ctrl, u, v, 1, 0)
+    np.testing.assert_allclose(d[:, 0], 3.0, atol=1e-11)
+    # outside the domain is flagged
+    _, out = oracle_mod.bbs_eval(bbs, ctrl, np.array([-0.1, 2.1, 1.0]), np.array([0.0, 0.0, 1.5]))
+    assert out.tolist() == [True, True, True]
+
+
+def test_polynomial_jacobian_matches_finite_differences(oracle_mod):
+    from defslam_amd import synth
+    sc = synth.make_normals_scene(5, 1, 1, nonref_frac=0.0)
+    for r in range(sc["recs"].shape[0]):
+        q1, q2 = oracle_mod.record_coeffs(sc["recs"][r])
+        assert q1[2] == q1[3] == q1[6] == 0 and q2[0] == q2[1] == q2[4] == 0   # structural zeros (PolySolver.cc:76-78,115-117)
+        x = np.array([0.13, -0.21])
+        e, J = oracle_mod.poly_eval(q1, q2, x)
+        for k in range(2):
+            d = np.zeros(2)
+            d[k] = 1e-6
+            fd = (oracle_mod.poly_eval(q1, q2, x + d)[0] - oracle_mod.poly_eval(q1, q2, x - d)[0]) / 2e-6
+            np.testing.assert_allclose(J[:, k], fd, rtol=1e-6, atol=1e-9)
+
+
+def test_normals_oracle_reaches_the_same_minimum_as_scipy(oracle_mod):
+    """The restated Ceres-style LM and scipy's MINPACK LM must agree on the minimiser they converge to."""
+    from scipy.optimize import least_squares
+    from defslam_amd import synth
+    sc = synth.make_normals_scene(120, 4, 5)
+    o = oracle_mod.normals(sc["rec_ptr"], sc["recs"], sc["rec_is_ref"], sc["rec_first_normal"], sc["rec_has_first_normal"], sc["x0"], sc["has_x0"],
+                           sc["ref_uv"])
+    checked = 0
+    for p in range(120):
+        rr = [r for r in range(sc["rec_ptr"][p], sc["rec_ptr"][p + 1]) if sc["rec_is_ref"][r]]
+        if not rr:
+            assert o["status"][p] == 1
+            continue
+        Q = [oracle_mod.record_coeffs(sc["recs"][r]) for r in rr]
+
+        def fun(x):
+            return np.concatenate([oracle_mod.poly_eval(q1, q2, x)[0] for q1, q2 in Q])
+
+        xs = o["k1k2"][p]
+        # first-order optimality of the oracle's answer
+        J = np.vstack([oracle_mod.poly_eval(q1, q2, xs)[1] for q1, q2 in Q])
+        g = J.T @ fun(xs)
+        assert np.abs(g).max() < 1e-6 * max(1.0, np.abs(J).max() ** 2)
+        x_start = sc["x0"][p].astype(float) if sc["has_x0"][p] else np.zeros(2)
+        ls = least_squares(fun, x_start, method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14)
+        if np.abs(ls.x - xs).max() < 1e-5:
+            checked += 1
+    assert checked > 80      # different LM flavours may pick different basins for a few points
+
+
+def test_normals_status_codes_and_propagation(oracle_mod):
+    from defslam_amd import synth
+    sc = synth.make_normals_scene(60, 3, 9)
+    o = oracle_mod.normals(sc["rec_ptr"], sc["recs"], sc["rec_is_ref"], sc["rec_first_normal"], sc["rec_has_first_normal"], sc["x0"], sc["has_x0"],
+                           sc["ref_uv"])
+    for p in range(60):
+        r0, r1 = sc["rec_ptr"][p], sc["rec_ptr"][p + 1]
+        nref = int(sc["rec_is_ref"][r0:r1].sum())
+        assert (o["status"][p] == 1) == (nref == 0)
+        if o["status"][p] == 0:
+            k1, k2 = o["k1k2"][p]
+            u, v = sc["ref_uv"][p]
+            np.testing.assert_array_equal(o["normal_ref"][p], np.array([k1, k2, 1 - k1 * u - k2 * v]).astype(np.float32))
+        for r in range(r0, r1):
+            expect_written = bool(sc["rec_is_ref"][r]) or bool(sc["rec_has_first_normal"][r])
+            assert bool(o["rec_written"][r]) == expect_written
+    # a rank-deficient system (all-zero derivatives -> zero Jacobian) is reported as "covariance failed" and nothing is written
+    recs = np.zeros((1, 18), np.float32)
+    recs[0, 4] = 1.0
+    recs[0, 7] = 1.0       # J12 = identity, no curvature: both polynomials vanish identically in k
+    o2 = oracle_mod.normals(np.array([0, 1], np.int32), recs, np.array([1], np.uint8), np.zeros((1, 2), np.float32), np.array([0], np.uint8),
+                            np.zeros((1, 2), np.float32), np.array([0], np.uint8), np.zeros((1, 2), np.float32))
+    assert o2["status"][0] == 2 and not o2["rec_written"][0]
