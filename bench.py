@@ -25,20 +25,28 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector == matrix peak
 
 
-def cpu_baseline(tmpl, fr, budget_iters):
+def cpu_baseline(tmpl, m, budget_s):
     """The C oracle (a restatement of the reference's g2o path: dense (6+3n)^2 Eigen-style pivoted LDLT, 1 thread)
-    timed on a bounded sample of the same workload: the first `budget_iters` LM iterations of one C2 problem."""
+    timed on a bounded sample of the same workload: whole C2 problems (ids 0,1,...) until `budget_s` seconds are used."""
     import oracle
     from defslam_amd import synth
     tc = oracle.template_build(tmpl.xyz0, tmpl.facets)
+    iters = trials = probs = 0
+    D = 0
     t0 = time.perf_counter()
-    r = oracle.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz,
-                         synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, max_iters=budget_iters, ldlt_mode=0)
+    while time.perf_counter() - t0 < budget_s and probs < 8:
+        fr = synth.make_frame(tmpl, m, probs)
+        r = oracle.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz,
+                             synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, max_iters=50, ldlt_mode=0)
+        iters += r.iters
+        trials += r.trials
+        probs += 1
+        D = int(r.dims[0])
     dt = time.perf_counter() - t0
-    return {"value": r.iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"first {r.iters} LM iterations ({r.trials} dense LDLT trials, D={int(r.dims[0])}) of one C2 problem, {dt:.1f} s, "
-                      f"oracle/sft_oracle.c ldlt_mode=0 (reference binary not buildable: Eigen/OpenCV absent)",
-            "lm_trials_per_s": r.trials / dt}
+    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{probs} whole problems of the same workload (ids 0..{probs - 1}): {iters} LM iterations, {trials} dense LDLT trials, "
+                      f"D={D}, {dt:.1f} s; oracle/sft_oracle.c ldlt_mode=0, 1 thread (reference binary not buildable: Eigen/OpenCV absent)",
+            "lm_trials_per_s": trials / dt, "frames_per_s": probs / dt}
 
 
 def main():
@@ -49,7 +57,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="independent problems per GPU per step (256 = one per CU)")
     ap.add_argument("--config", default="C2", choices=["smoke", "C2", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
     import torch
@@ -104,6 +112,15 @@ def main():
     g_iters, g_trials, g_problems = (float(v) for v in tot.tolist())
 
     if rank == 0:
+        # HBM traffic per launch measured with rocprofv3 PMC passes for exactly this configuration (profiles/r01/traffic.json)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+            key = f"{args.config}_B{args.batch}"
+            if key in tj:
+                traffic = tj[key]["bytes_per_launch"]
+        except Exception:
+            traffic = None
         ms_per_step = 1e3 * wall / args.steps
         value = g_iters * args.steps / wall
         kern_ms = kernel_ms / args.steps            # avg duration of the persistent kernel (rank 0)
@@ -111,7 +128,10 @@ def main():
         # figure x iterations the launch executes) over its measured duration
         bytes_per_launch = (alg_bytes / args.batch) * iters
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-        Dn, kd = int(counts[5]) - 6, None
+        # solve-inclusive algorithmic stream of the tile-mode factorisation: H tiles read once, L written once and read once per trial
+        Dn = int(counts[5]) - 6
+        nT = ((Dn + 31) // 32) * 2
+        solver_bytes = trials * (3 * nT * 9 * 2048 + 2 * nT * 2048 + 3 * 7 * 16 * nT * 8)
         out = {
             "metric": "SfT GN iters/sec (500-node mesh, 1k matches)", "value": value, "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -123,8 +143,9 @@ def main():
             "lm_trials_per_s": g_trials * args.steps / wall,
             "iters_per_frame": g_iters / g_problems,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "sft_lm_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "sft_lm_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "solver_stream_GBps": (bytes_per_launch + solver_bytes) / (kern_ms * 1e-3) / 1e9,
                          "note": "persistent kernel = residuals + Jacobian assembly + banded Cholesky + LM control; bytes count assembly only (SURVEY 8d)"},
         }
         # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
@@ -135,7 +156,7 @@ def main():
         it1, tr1 = ctx.batch_counts()
         out["latency"] = {"single_problem_iters_per_s": it1 / (ms1 * 1e-3), "ms_per_frame": ms1, "iters": it1, "trials": tr1}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tmpl, synth.make_frame(tmpl, m, 0), args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(tmpl, m, args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
