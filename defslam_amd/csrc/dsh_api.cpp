@@ -15,8 +15,8 @@
 #include "dsh_template.h"
 #include "sft_problem.h"
 
-extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, hipStream_t stream);
-extern "C" size_t sft_lm_kernel_lds_bytes(int kd);
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, hipStream_t stream);
+extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 
 namespace {
 
@@ -78,7 +78,7 @@ void Tcw_from_pose7(const double* p, float* T) {
 // ---- one packed problem on the host ---------------------------------------------------------------
 struct Packed {
   SftDev h{};                   // sizes + scalars (pointers filled at upload)
-  std::vector<int32_t> act, obs_nodes, ref_node, star_node, str_nodes, blk_rc, blk_ptr;
+  std::vector<int32_t> act, obs_nodes, ref_node, star_node, str_nodes, blk_rc, blk_ptr, diag_blk, off_blk;
   std::vector<uint32_t> contrib;
   std::vector<double> obs_bary, obs_uv, obs_w, star_sL, str_L0, xyz_init;
   double pose_init[7];
@@ -117,6 +117,7 @@ struct dsh_ctx : dsh_ctx_base {
   std::vector<char> stage;         // host staging of the read-only part
   size_t ro_bytes = 0;             // leading read-only bytes of d_batch (uploaded)
   int max_kd = 0;
+  size_t jl_doubles = 0;
   bool ran = false;
 };
 
@@ -282,6 +283,11 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   for (int a = 0; a < nA; a++)
     for (auto& cc : rows[a]) { P.blk_rc.push_back(a); P.blk_rc.push_back(cc.c); P.blk_ptr.push_back(cc.off); }
   P.blk_ptr.push_back((int)total);
+  P.diag_blk.assign(nA, -1);
+  P.off_blk.clear();
+  for (int q = 0; q < nblk; q++) {
+    if (P.blk_rc[2 * q] == P.blk_rc[2 * q + 1]) P.diag_blk[P.blk_rc[2 * q]] = q; else P.off_blk.push_back(q);
+  }
 
   P.xyz_init.assign(f.xyz, f.xyz + 3 * (size_t)n);
   pose7_from_Tcw(f.Tcw, P.pose_init);
@@ -425,7 +431,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   st.clear();
   const size_t o_tab = a.take(sizeof(SftDev) * B);
   st.resize(a.size);
-  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, contrib, xyz_init, pose_init; };
+  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, xyz_init, pose_init; };
   std::vector<Offs> ro(B);
   for (int b = 0; b < B; b++) {
     Packed& P = c->packed[b];
@@ -433,6 +439,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     o.act = put(st, a, P.act); o.obs_nodes = put(st, a, P.obs_nodes); o.obs_bary = put(st, a, P.obs_bary); o.obs_uv = put(st, a, P.obs_uv);
     o.obs_w = put(st, a, P.obs_w); o.ref = put(st, a, P.ref_node); o.star = put(st, a, P.star_node); o.sL = put(st, a, P.star_sL);
     o.strn = put(st, a, P.str_nodes); o.strL = put(st, a, P.str_L0); o.rc = put(st, a, P.blk_rc); o.ptr = put(st, a, P.blk_ptr);
+    o.dblk = put(st, a, P.diag_blk); o.oblk = put(st, a, P.off_blk);
     o.contrib = put(st, a, P.contrib); o.xyz_init = put(st, a, P.xyz_init);
     std::vector<double> pi(P.pose_init, P.pose_init + 7);
     o.pose_init = put(st, a, pi);
@@ -441,6 +448,13 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, x, chi2, ferr, trace, info, dbg; };
   std::vector<WOffs> wo(B);
   int max_kd = 0;
+  size_t jl_doubles = 0;
+  for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to nothing else (<= 96 KiB)
+    SftDev& hh = c->packed[b].h;
+    const size_t need = 4 * ((size_t)hh.S + hh.Es + hh.V);
+    hh.jl_lds = (need * 8 <= 96 * 1024) ? 1 : 0;
+    if (hh.jl_lds) jl_doubles = std::max(jl_doubles, need);
+  }
   for (int b = 0; b < B; b++) {
     const SftDev& h = c->packed[b].h;
     const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
@@ -455,7 +469,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(64);
     max_kd = std::max(max_kd, h.kd);
   }
-  if (sft_lm_kernel_lds_bytes(max_kd) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
+  if (sft_lm_kernel_lds_bytes(max_kd, jl_doubles) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
     return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel / workgroup");
   if (a.size > c->d_batch_cap) {
     if (c->d_batch) { (void)hipFree(c->d_batch); c->d_batch = nullptr; c->d_batch_cap = 0; }
@@ -473,6 +487,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w); h.ref_node = (const int32_t*)(base + o.ref);
     h.star_node = (const int32_t*)(base + o.star); h.star_sL = (const double*)(base + o.sL); h.str_nodes = (const int32_t*)(base + o.strn);
     h.str_L0 = (const double*)(base + o.strL); h.blk_rc = (const int32_t*)(base + o.rc); h.blk_ptr = (const int32_t*)(base + o.ptr);
+    h.diag_blk = (const int32_t*)(base + o.dblk); h.off_blk = (const int32_t*)(base + o.oblk);
     h.contrib = (const uint32_t*)(base + o.contrib); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
     h.xyz = (double*)(base + w.xyz); h.xyz_bak = (double*)(base + w.bak); h.pose = (double*)(base + w.pose);
     h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
@@ -489,6 +504,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->d_probs = (SftDev*)(base + o_tab);
   c->B = B;
   c->max_kd = max_kd;
+  c->jl_doubles = jl_doubles;
   c->ran = false;
   return DSH_OK;
 }
@@ -498,7 +514,7 @@ int dsh_sft_batch_run(dsh_ctx* c) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
   (void)hipSetDevice(c->device);
-  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->stream));
+  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->stream));
   c->ran = true;
   return DSH_OK;
 }
@@ -512,7 +528,7 @@ int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->stream));
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0.f;
@@ -634,7 +650,7 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   // flip the mode of this one problem, run it alone, restore
   h.mode = 1;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
-  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->stream));
+  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h.mode = 0;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));

@@ -194,8 +194,15 @@ __device__ __forceinline__ void huber(const SftDev& P, double e2, double& rho0, 
 // ------------------------------------------------------------------------------------------
 // Residuals (+ Jacobian records when WANT_J): returns the robust chi2 in ctl-independent LDS out[0]
 // ------------------------------------------------------------------------------------------
+struct JPtr { double *star, *str, *ref; };   // small Jacobian records: LDS when they fit (P.jl_lds), else global
+
+__device__ __forceinline__ JPtr jrecords(const SftDev& P, double* lds) {
+  if (P.jl_lds) return JPtr{lds, lds + 4 * (size_t)P.S, lds + 4 * ((size_t)P.S + P.Es)};
+  return JPtr{P.Jstar, P.Jstr, P.Jref};
+}
+
 template <bool WANT_J>
-__device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out) {
+__device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, JPtr jp) {
   if (threadIdx.x == 0) {
     quat_to_R(P.pose + 3, ctl->R);
     ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2];
@@ -272,7 +279,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       const int nd = P.ref_node[v];
       const double e0 = xyz[3 * nd] - P.xyz0[3 * nd], e1 = xyz[3 * nd + 1] - P.xyz0[3 * nd + 1], e2 = xyz[3 * nd + 2] - P.xyz0[3 * nd + 2];
       chi += (e0 * (P.w_ref * e0) + e1 * (P.w_ref * e1)) + e2 * (P.w_ref * e2);
-      if (WANT_J) { double* r = P.Jref + 4 * v; r[0] = e0; r[1] = e1; r[2] = e2; r[3] = 0; }
+      if (WANT_J) { double* r = jp.ref + 4 * v; r[0] = e0; r[1] = e1; r[2] = e2; r[3] = 0; }
     } else if (idx < P.M + P.V + P.S) {
       const int s = idx - P.M - P.V;
       const int nd = P.star_node[s];
@@ -288,7 +295,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       const double r = nrm - P.k0[nd];
       chi += (P.w_curv * P.star_sL[s]) * (r * r);
       if (WANT_J) {
-        double* rr = P.Jstar + 4 * s;
+        double* rr = jp.star + 4 * s;
         if (nrm < 1E-15) { rr[0] = rr[1] = rr[2] = 0.0; }
         else { rr[0] = m0 / nrm; rr[1] = m1 / nrm; rr[2] = m2 / nrm; }
         rr[3] = r;
@@ -303,7 +310,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       chi += er * (P.w_str * er);
       if (WANT_J) {
         const double ddo = 1.0 / (nrm * L0);
-        double* r = P.Jstr + 4 * e;
+        double* r = jp.str + 4 * e;
         r[0] = d0 * ddo; r[1] = d1 * ddo; r[2] = d2 * ddo; r[3] = er;
       }
     }
@@ -315,7 +322,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
 // ------------------------------------------------------------------------------------------
 // Normal equations: gather per 3x3 block from the Jacobian records (fixed contribution order).
 // ------------------------------------------------------------------------------------------
-__device__ void assemble(const SftDev& P, double* red, double* out) {
+__device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
   // camera corner: H_cc (lower 21) and b_c (6) as a block-wide reduction over the observations
   {
@@ -346,73 +353,61 @@ __device__ void assemble(const SftDev& P, double* red, double* out) {
     }
     __syncthreads();
   }
-  for (int q = threadIdx.x; q < P.nblk; q += SFT_NT) {
-    const int bi = P.blk_rc[2 * q], bj = P.blk_rc[2 * q + 1];
-    const bool diag = (bi == bj);
-    double H[9];
+  // one contribution into the accumulators of a block (H 3x3; for diagonal blocks also the 6x3 camera block and b)
+  auto contribute = [&](uint32_t rec, bool diag, double* H, double* Hc, double* bn) {
+    const uint32_t kind = rec >> 30, s = (rec >> 26) & 15u, t = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
+    if (kind == SFT_KIND_OBS) {
+      const double* r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
+      const double wt = r[2];
+      double js[6], jt[6];
 #pragma unroll
-    for (int i = 0; i < 9; i++) H[i] = 0.0;
-    double Hc[18];
+      for (int k = 0; k < 6; k++) { js[k] = r[16 + 6 * s + k]; jt[k] = r[16 + 6 * t + k]; }
 #pragma unroll
-    for (int i = 0; i < 18; i++) Hc[i] = 0.0;
-    double bn[3] = {0.0, 0.0, 0.0};
-    for (int p = P.blk_ptr[q]; p < P.blk_ptr[q + 1]; p++) {
-      const uint32_t rec = P.contrib[p];
-      const uint32_t kind = rec >> 30, s = (rec >> 26) & 15u, t = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
-      if (kind == SFT_KIND_OBS) {
-        const double* r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
-        const double wt = r[2];
-        const double* Js = r + 16 + 6 * s;
-        const double* Jt = r + 16 + 6 * t;
-        double js[6], jt[6];
+      for (int a = 0; a < 3; a++)
 #pragma unroll
-        for (int k = 0; k < 6; k++) { js[k] = Js[k]; jt[k] = Jt[k]; }
+        for (int b = 0; b < 3; b++) H[3 * a + b] += wt * (js[a] * jt[b] + js[3 + a] * jt[3 + b]);
+      if (diag) {
+        const double e0 = r[0], e1 = r[1];
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int k = 0; k < 6; k++)
 #pragma unroll
-          for (int b = 0; b < 3; b++) H[3 * a + b] += wt * (js[a] * jt[b] + js[3 + a] * jt[3 + b]);
-        if (diag) {
-          const double e0 = r[0], e1 = r[1];
+          for (int a = 0; a < 3; a++) Hc[3 * k + a] += wt * (r[4 + k] * js[a] + r[10 + k] * js[3 + a]);
 #pragma unroll
-          for (int k = 0; k < 6; k++)
-#pragma unroll
-            for (int a = 0; a < 3; a++) Hc[3 * k + a] += wt * (r[4 + k] * js[a] + r[10 + k] * js[3 + a]);
-#pragma unroll
-          for (int a = 0; a < 3; a++) bn[a] -= wt * (js[a] * e0 + js[3 + a] * e1);
-        }
-      } else if (kind == SFT_KIND_STAR) {
-        const double* r = P.Jstar + 4 * e;
-        const int nd = P.star_node[e];
-        const int base = P.nbr_ptr[nd];
-        const double cs = (s == 0) ? 1.0 : P.nbr_c[base + s - 1];
-        const double ct = (t == 0) ? 1.0 : P.nbr_c[base + t - 1];
-        const double wt = P.w_curv * P.star_sL[e];
-        const double u0 = r[0], u1 = r[1], u2 = r[2];
-        const double f = wt * (cs * ct);
-        H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
-        H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
-        H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
-        if (diag) {
-          const double g = wt * cs * r[3];
-          bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
-        }
-      } else if (kind == SFT_KIND_STR) {
-        const double* r = P.Jstr + 4 * e;
-        const double sg = ((s == 0) == (t == 0)) ? P.w_str : -P.w_str;
-        const double g0 = r[0], g1 = r[1], g2 = r[2];
-        H[0] += sg * (g0 * g0); H[1] += sg * (g0 * g1); H[2] += sg * (g0 * g2);
-        H[3] += sg * (g1 * g0); H[4] += sg * (g1 * g1); H[5] += sg * (g1 * g2);
-        H[6] += sg * (g2 * g0); H[7] += sg * (g2 * g1); H[8] += sg * (g2 * g2);
-        if (diag) {
-          const double g = (s == 0 ? P.w_str : -P.w_str) * r[3];
-          bn[0] -= g * g0; bn[1] -= g * g1; bn[2] -= g * g2;
-        }
-      } else {  // SFT_KIND_REF (diagonal only, J = I)
-        const double* r = P.Jref + 4 * e;
-        H[0] += P.w_ref; H[4] += P.w_ref; H[8] += P.w_ref;
-        bn[0] -= P.w_ref * r[0]; bn[1] -= P.w_ref * r[1]; bn[2] -= P.w_ref * r[2];
+        for (int a = 0; a < 3; a++) bn[a] -= wt * (js[a] * e0 + js[3 + a] * e1);
       }
+    } else if (kind == SFT_KIND_STAR) {
+      const double* r = jp.star + 4 * e;
+      const int base = P.nbr_ptr[P.star_node[e]];
+      const double cs = (s == 0) ? 1.0 : P.nbr_c[base + s - 1];
+      const double ct = (t == 0) ? 1.0 : P.nbr_c[base + t - 1];
+      const double wt = P.w_curv * P.star_sL[e];
+      const double u0 = r[0], u1 = r[1], u2 = r[2];
+      const double f = wt * (cs * ct);
+      H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
+      H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
+      H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
+      if (diag) {
+        const double g = wt * cs * r[3];
+        bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
+      }
+    } else if (kind == SFT_KIND_STR) {
+      const double* r = jp.str + 4 * e;
+      const double sg = ((s == 0) == (t == 0)) ? P.w_str : -P.w_str;
+      const double g0 = r[0], g1 = r[1], g2 = r[2];
+      H[0] += sg * (g0 * g0); H[1] += sg * (g0 * g1); H[2] += sg * (g0 * g2);
+      H[3] += sg * (g1 * g0); H[4] += sg * (g1 * g1); H[5] += sg * (g1 * g2);
+      H[6] += sg * (g2 * g0); H[7] += sg * (g2 * g1); H[8] += sg * (g2 * g2);
+      if (diag) {
+        const double g = (s == 0 ? P.w_str : -P.w_str) * r[3];
+        bn[0] -= g * g0; bn[1] -= g * g1; bn[2] -= g * g2;
+      }
+    } else {  // SFT_KIND_REF (diagonal only, J = I)
+      const double* r = jp.ref + 4 * e;
+      H[0] += P.w_ref; H[4] += P.w_ref; H[8] += P.w_ref;
+      bn[0] -= P.w_ref * r[0]; bn[1] -= P.w_ref * r[1]; bn[2] -= P.w_ref * r[2];
     }
+  };
+  auto store_block = [&](int bi, int bj, const double* H) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const int r = 3 * bi + a;
@@ -425,14 +420,49 @@ __device__ void assemble(const SftDev& P, double* red, double* out) {
         }
       }
     }
-    if (diag) {
+  };
+  // ---- diagonal blocks (longest contribution lists): a group of DG lanes per block, contributions dealt round-robin,
+  //      partial sums combined with a fixed xor-butterfly (deterministic)
+  constexpr int DG = 8;
+  {
+    const int sub = threadIdx.x & (DG - 1), grp = threadIdx.x / DG;
+    for (int a0 = 0; a0 < P.nA; a0 += SFT_NT / DG) {
+      const int a = a0 + grp;
+      double acc[30];
 #pragma unroll
-      for (int k = 0; k < 6; k++)
+      for (int i = 0; i < 30; i++) acc[i] = 0.0;
+      if (a < P.nA) {
+        const int q = P.diag_blk[a];
+        for (int p = P.blk_ptr[q] + sub; p < P.blk_ptr[q + 1]; p += DG) contribute(P.contrib[p], true, acc, acc + 9, acc + 27);
+      }
 #pragma unroll
-        for (int a = 0; a < 3; a++) P.Hbord[(size_t)k * Dnp + 3 * bi + a] = Hc[3 * k + a];
+      for (int i = 0; i < 30; i++) {
+        double v = acc[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        acc[i] = v;
+      }
+      if (a < P.nA && sub == 0) {
+        store_block(a, a, acc);
 #pragma unroll
-      for (int a = 0; a < 3; a++) P.Hbord[(size_t)6 * Dnp + 3 * bi + a] = bn[a];
+        for (int k = 0; k < 6; k++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) P.Hbord[(size_t)k * Dnp + 3 * a + c] = acc[9 + 3 * k + c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) P.Hbord[(size_t)6 * Dnp + 3 * a + c] = acc[27 + c];
+      }
     }
+  }
+  // ---- off-diagonal blocks: one lane per block, contributions in the reference's edge order
+  const int noff = P.nblk - P.nA;
+  for (int o = threadIdx.x; o < noff; o += SFT_NT) {
+    const int q = P.off_blk[o];
+    double H[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) H[i] = 0.0;
+    for (int p = P.blk_ptr[q]; p < P.blk_ptr[q + 1]; p++) contribute(P.contrib[p], false, H, nullptr, nullptr);
+    store_block(P.blk_rc[2 * q], P.blk_rc[2 * q + 1], H);
   }
   __syncthreads();
 }
@@ -950,7 +980,8 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
 }
 
 // Back substitution in tile mode: x_J = Linv_J^T (y_J - sum_{I>J} X_{I,J}^T x_I - Lcn_J^T x_cam).
-// Wave w forms the partial product of tile (J+w+1, J); wave 0 finishes the block.
+// Wave w forms the partial product of tile (J+w+1, J); wave 0 finishes the block.  The tiles of block J-1 are
+// prefetched while block J is processed (LDS-only barriers keep the loads in flight).
 __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws) {
   if (!ctl->fact_ok) return;   // like g2o, x keeps its previous content when the factorisation failed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -960,55 +991,74 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   double* part = xw + TS * BT;     // (BT+1) partial vectors
   const int crow = lane >> 4, ccol = lane & 15;
   const double xc = (lane < 6) ? P.x[Dnp + lane] : 0.0;
+  double xcr[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) xcr[r] = bcast_lane(xc, r);
   const double* Lg = P.Lb;
   const double* Lbord = P.Lbord;
+  const int d = wave + 1;
+  struct Pre { v4d t, li; double y, b[6]; };
+  auto fetch = [&](int J) -> Pre {
+    Pre p;
+    p.t = (v4d){0.0, 0.0, 0.0, 0.0}; p.li = p.t; p.y = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) p.b[r] = 0.0;
+    if (J < 0) return p;
+    if (J + d < nT) {
+      const double* g = Lg + tile_off(J + d, d) + crow * TS + ccol;
+#pragma unroll
+      for (int q = 0; q < 4; q++) p.t[q] = g[4 * q * TS];
+    }
+    if (wave == 0) {
+      const double* g = P.Linv + (size_t)J * TS * TS + crow * TS + ccol;
+#pragma unroll
+      for (int q = 0; q < 4; q++) p.li[q] = g[4 * q * TS];
+      p.y = Lbord[(size_t)6 * Dnp + TS * J + ccol];
+    } else if (wave == 1) {
+#pragma unroll
+      for (int r = 0; r < 6; r++) p.b[r] = Lbord[(size_t)r * Dnp + TS * J + ccol];
+    }
+    return p;
+  };
+  Pre cur = fetch(nT - 1);
 #pragma unroll 1
   for (int J = nT - 1; J >= 0; J--) {
+    const Pre nxt = fetch(J - 1);
     {
-      const int d = wave + 1;
       const int I = J + d;
       double p = 0.0;
       if (I < nT) {
-        const double* g = Lg + tile_off(I, d) + crow * TS + ccol;
         const double* xi = xw + (I & (BT - 1)) * TS + crow;
 #pragma unroll
-        for (int q = 0; q < 4; q++) p = fma(g[4 * q * TS], xi[4 * q], p);
+        for (int q = 0; q < 4; q++) p = fma(cur.t[q], xi[4 * q], p);
         p += __shfl_xor(p, 16, 64);
         p += __shfl_xor(p, 32, 64);
       }
       if (lane < TS) part[d * TS + lane] = p;
     }
-    v4d li = {0.0, 0.0, 0.0, 0.0};
-    double y = 0.0;
-    if (wave == 1) {
+    if (wave == 1 && lane < TS) {
       double p = 0.0;
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const double xr = bcast_lane(xc, r);
-        if (lane < TS) p = fma(Lbord[(size_t)r * Dnp + TS * J + lane], xr, p);
-      }
-      if (lane < TS) part[lane] = p;
-    } else if (wave == 0) {
-      const double* g = P.Linv + (size_t)J * TS * TS + crow * TS + ccol;
-#pragma unroll
-      for (int q = 0; q < 4; q++) li[q] = g[4 * q * TS];
-      y = Lbord[(size_t)6 * Dnp + TS * J + ccol];
+      for (int r = 0; r < 6; r++) p = fma(cur.b[r], xcr[r], p);
+      part[lane] = p;
     }
-    __syncthreads();
+    lds_barrier();
     if (wave == 0) {
-      double v = y;
+      double v = cur.y;
 #pragma unroll
       for (int i = 0; i <= BT; i++) v -= part[i * TS + ccol];
       // x[c] = sum_r Linv[r][c] v[r]   (v is replicated in every 16-lane group)
       double p = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) p = fma(li[q], __shfl(v, crow + 4 * q, 64), p);
+      for (int q = 0; q < 4; q++) p = fma(cur.li[q], __shfl(v, crow + 4 * q, 64), p);
       p += __shfl_xor(p, 16, 64);
       p += __shfl_xor(p, 32, 64);
       if (lane < TS) { xw[(J & (BT - 1)) * TS + lane] = p; P.x[TS * J + lane] = p; }
     }
-    __syncthreads();
+    lds_barrier();
+    cur = nxt;
   }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1021,6 +1071,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   double* red = reinterpret_cast<double*>(smem + 512);   // 16*27 doubles
   double* out = red + 16 * 27 + 5;                        // 27 doubles
   double* panel = out + 32;
+  const JPtr jp = jrecords(P, panel);   // the small Jacobian records alias the solver workspace (dead once H is assembled)
   const int tid = threadIdx.x;
   const int Dn = P.Dn, ldh = P.ldh, kd = P.kd;
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
@@ -1052,17 +1103,17 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   PH_T0();
 
   if (P.mode == 1) {  // test hook: one assembly at the initial state
-    const double chi = eval_edges<true>(P, ctl, red, out);
-    assemble(P, red, out);
+    const double chi = eval_edges<true>(P, ctl, red, out, jp);
+    assemble(P, red, out, jp);
     if (tid == 0) P.dbg[0] = chi;
     return;
   }
 
   int total_trials = 0, iters = 0;
   for (int it = 0; it < P.max_iters; it++) {
-    const double chi0 = eval_edges<true>(P, ctl, red, out);
+    const double chi0 = eval_edges<true>(P, ctl, red, out, jp);
     PH_ADD(1);
-    assemble(P, red, out);
+    assemble(P, red, out, jp);
     PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
@@ -1108,7 +1159,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
       const double scale = out[0];
       __syncthreads();
       PH_ADD(7);
-      const double chi_new = eval_edges<false>(P, ctl, red, out);
+      const double chi_new = eval_edges<false>(P, ctl, red, out, jp);
       PH_ADD(1);
       if (tid == 0) {
         double tempChi = ok ? chi_new : DBL_MAX;
@@ -1174,7 +1225,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
 }  // namespace
 
 // LDS bytes the kernel needs for a problem with half-bandwidth kd
-extern "C" size_t sft_lm_kernel_lds_bytes(int kd) {
+extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   const size_t rows = NB + kd + SFT_BORDER;
   const size_t LDP = rows | 1;
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
@@ -1182,11 +1233,12 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd) {
   if (backsub > panel) panel = backsub;
   const size_t tiles = (size_t)(2 * (BT + 1) + 1) * TILE_LDS + SFT_BORDER * TS + 64;
   if (kd <= TS * BT) panel = tiles;
+  if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
 
-extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, hipStream_t stream) {
-  const size_t lds = sft_lm_kernel_lds_bytes(max_kd);
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
   static size_t configured = 0;
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -26,7 +26,7 @@
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
-  int32_t tile_mode, pad0;  // 1: 16x16-tile band storage + MFMA factorisation (kd <= 128); 0: row-major band (general)
+  int32_t tile_mode, jl_lds;  // 1: 16x16-tile band storage + MFMA factorisation (kd <= 128); 0: row-major band (general)
   double fx, fy, cx, cy;
   double w_ref, w_curv, w_str, hub_delta, hub_dsqr;
   // template (shared by every problem of a batch)
@@ -50,6 +50,8 @@ struct SftDev {
   const double* str_L0;     // Es
   const int32_t* blk_rc;    // nblk*2 (block row, block col), lower, sorted
   const int32_t* blk_ptr;   // nblk+1
+  const int32_t* diag_blk;  // nA: block index of every diagonal block
+  const int32_t* off_blk;   // nblk-nA: block indices of the off-diagonal blocks
   const uint32_t* contrib;
   // initial state (restored at the start of every run)
   const double* xyz_init;   // n*3
