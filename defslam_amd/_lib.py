@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "dsh_template_build", "dsh_template_set", "dsh_template_dims", "dsh_template_get", "dsh_template_embed",
     "dsh_sft_solve", "dsh_sft_batch_upload", "dsh_sft_batch_run", "dsh_sft_batch_download",
     "dsh_sft_batch_run_timed", "dsh_sft_batch_phase_ms", "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
-    "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate",
+    "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit",
 ]
 
 _lib = None
@@ -116,6 +116,10 @@ def load() -> C.CDLL:
     L.dsh_bbs_coloc.argtypes = [vp, C.POINTER(BbsC), c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, c_i32_p, c_double_p, c_i32_p]
     L.dsh_normals_estimate.argtypes = [vp, C.c_int, c_i32_p, c_float_p, c_u8_p, c_float_p, c_u8_p, c_float_p, c_u8_p, c_float_p,
                                        c_double_p, c_double_p, c_i32_p, c_float_p, c_float_p, c_u8_p, c_i32_p]
+    L.dsh_schwarp_eval.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_float_p, c_float_p, c_float_p, C.c_double, C.c_double, C.c_double, c_double_p,
+                                   c_double_p, c_double_p]
+    L.dsh_schwarp_fit.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_float_p, c_float_p, c_float_p, C.c_double, C.c_double, C.c_double, C.c_float,
+                                  C.c_float, C.c_int, c_double_p, c_float_p, c_u8_p, c_i32_p, c_double_p]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("dsh_last_error", "dsh_stream"):

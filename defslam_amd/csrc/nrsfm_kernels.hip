@@ -307,6 +307,263 @@ __global__ void normals_propagate_kernel(int R, const float* __restrict__ recs, 
   written[r] = 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Schwarzian-regularised warp fit: Schwarp.cc:38-97,235-543, SchwarpDatabase.cc:145-349
+// Parameter layout x[0..N) first coordinate, x[N..2N) second; dense row-major Jacobian (2P+4N) x 2N.
+// ------------------------------------------------------------------------------------------------
+struct SwpPar { double umin, umax, vmin, vmax, fxs, fys, lambda; int nu, nv, N, P; };
+
+__device__ __forceinline__ void swp_eval16(const SwpPar& p, const double* x, double u, double v, int du, int dv, double& ox, double& oy) {
+  BbsPar b = {p.umin, p.umax, p.vmin, p.vmax, p.nu, p.nv, 2, 0};
+  double nu, nv, bu[4], bv[4];
+  int Iu, Iv;
+  norm_inter(p.umin, p.umax, p.nu, u, nu, Iu);
+  norm_inter(p.vmin, p.vmax, p.nv, v, nv, Iv);
+  cubic_basis(du, nu, bu);
+  cubic_basis(dv, nv, bv);
+  double ax = 0.0, ay = 0.0;
+  if (!(Iu < 0 || Iu > p.nu - 4 || Iv < 0 || Iv > p.nv - 4)) {
+    for (int iu = 0; iu < 4; iu++)
+      for (int iv = 0; iv < 4; iv++) {
+        const double bas = bu[iu] * bv[iv];
+        const int l = (iu + Iu) * p.nv + iv + Iv;
+        ax += x[l] * bas;
+        ay += x[p.N + l] * bas;
+      }
+    const double fact = deriv_fact(b, du, dv);
+    ax *= fact; ay *= fact;
+  }
+  ox = ax; oy = ay;
+}
+
+// taps of the site: columns (16) and weights for derivative order (du,dv)
+__device__ __forceinline__ bool swp_taps(const SwpPar& p, double u, double v, int du, int dv, int* cols, double* w) {
+  BbsPar b = {p.umin, p.umax, p.vmin, p.vmax, p.nu, p.nv, 2, 0};
+  double nu, nv, bu[4], bv[4];
+  int Iu, Iv;
+  norm_inter(p.umin, p.umax, p.nu, u, nu, Iu);
+  norm_inter(p.vmin, p.vmax, p.nv, v, nv, Iv);
+  if (Iu < 0 || Iu > p.nu - 4 || Iv < 0 || Iv > p.nv - 4) return false;
+  cubic_basis(du, nu, bu);
+  cubic_basis(dv, nv, bv);
+  const double fact = deriv_fact(b, du, dv);
+  for (int iu = 0; iu < 4; iu++)
+    for (int iv = 0; iv < 4; iv++) {
+      cols[4 * iu + iv] = (iu + Iu) * p.nv + iv + Iv;
+      w[4 * iu + iv] = (du == 0 && dv == 0) ? bu[iu] * bv[iv] : fact * bu[iu] * bv[iv];
+    }
+  return true;
+}
+
+template <bool WITH_J>
+__global__ void swp_eval_kernel(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const float* __restrict__ invsig,
+                                const double* __restrict__ x, double* __restrict__ r, double* __restrict__ J) {
+  const int n2 = 2 * p.N;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < p.P) {
+    const int i = t;
+    const double u = kp1[2 * i], v = kp1[2 * i + 1];
+    double ex, ey;
+    swp_eval16(p, x, u, v, 0, 0, ex, ey);
+    r[i] = invsig[i] * ((double)kp2[2 * i] - ex) * p.fxs;
+    r[i + p.P] = invsig[i] * ((double)kp2[2 * i + 1] - ey) * p.fys;
+    if (WITH_J) {
+      int cols[16]; double w[16];
+      if (swp_taps(p, u, v, 0, 0, cols, w))
+        for (int k = 0; k < 16; k++) {
+          const double jv = -w[k] * p.fxs;
+          J[(size_t)i * n2 + cols[k]] = jv;            // x row
+          J[(size_t)(i + p.P) * n2 + cols[k]] = jv;    // y row: the reference overwrites it with the x row (Schwarp.cc:291-298)
+        }
+    }
+  } else if (t < p.P + p.N) {
+    const int k = t - p.P;
+    const int iu = k / p.nv, iv = k % p.nv;
+    const double X = (double)((p.umax - p.umin) * iu) / (p.nu - 1) + p.umin;
+    const double Y = (double)((p.vmax - p.vmin) * iv) / (p.nv - 1) + p.vmin;
+    double xu, yu, xv, yv, xuu, yuu, xvv, yvv, xuv, yuv;
+    swp_eval16(p, x, X, Y, 1, 0, xu, yu);
+    swp_eval16(p, x, X, Y, 0, 1, xv, yv);
+    swp_eval16(p, x, X, Y, 2, 0, xuu, yuu);
+    swp_eval16(p, x, X, Y, 0, 2, xvv, yvv);
+    swp_eval16(p, x, X, Y, 1, 1, xuv, yuv);
+    const double lam = p.lambda;
+    double* rs = r + 2 * p.P;
+    rs[k] = ((xuu * yu - yuu * xu)) * lam;
+    rs[p.N + k] = ((yvv * xv - xvv * yv)) * lam;
+    rs[2 * p.N + k] = ((xuu * yv - yuu * xv + 2 * (xuv * yu - yuv * xu))) * lam;
+    rs[3 * p.N + k] = ((yvv * xu - xvv * yu + 2 * (yuv * xv - xuv * yv))) * lam;
+    if (WITH_J) {
+      int c[16]; double wu[16], wv[16], wuu[16], wvv[16], wuv[16];
+      if (swp_taps(p, X, Y, 1, 0, c, wu)) {
+        swp_taps(p, X, Y, 0, 1, c, wv); swp_taps(p, X, Y, 2, 0, c, wuu); swp_taps(p, X, Y, 0, 2, c, wvv); swp_taps(p, X, Y, 1, 1, c, wuv);
+        double* Js = J + (size_t)2 * p.P * n2;
+        const int N = p.N;
+        for (int q = 0; q < 16; q++) {
+          const int col = c[q];
+          const double Cu = wu[q], Cv = wv[q], Cuu = wuu[q], Cvv = wvv[q], Cuv = wuv[q];
+          Js[(size_t)k * n2 + col] = lam * (yu * Cuu - yuu * Cu);
+          Js[(size_t)k * n2 + N + col] = lam * (xuu * Cu - xu * Cuu);
+          Js[(size_t)(N + k) * n2 + col] = lam * (yvv * Cv - yv * Cvv);
+          Js[(size_t)(N + k) * n2 + N + col] = lam * (xv * Cvv - xvv * Cv);
+          Js[(size_t)(2 * N + k) * n2 + col] = lam * (yv * Cuu - yuu * Cv + 2 * yu * Cuv - 2 * yuv * Cu);
+          Js[(size_t)(2 * N + k) * n2 + N + col] = lam * (xuu * Cv - xv * Cuu + 2 * xuv * Cu - 2 * xu * Cuv);
+          Js[(size_t)(3 * N + k) * n2 + col] = lam * (yvv * Cu - yu * Cvv - 2 * yv * Cuv + 2 * yuv * Cv);
+          Js[(size_t)(3 * N + k) * n2 + N + col] = lam * (xu * Cvv - xvv * Cu - 2 * xuv * Cv + 2 * xv * Cuv);
+        }
+      }
+    }
+  }
+}
+
+// scal[0] = cost = 1/2 (rho(|r_warp|^2) + |r_schw|^2), scal[1] = sqrt(rho'), sequential sums (oracle order), one lane.
+__global__ void swp_loss_kernel(int P2, int m, const double* __restrict__ r, double* __restrict__ scal) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double a = 5.77;   // HuberLoss(5.77), SchwarpDatabase.cc:208
+  double sq = 0.0;
+  for (int i = 0; i < P2; i++) sq += r[i] * r[i];
+  double rho0 = sq, rho1 = 1.0;
+  if (sq > a * a) { const double rt = sqrt(sq); rho0 = 2 * a * rt - a * a; rho1 = a / rt; }
+  double cost = rho0;
+  for (int i = P2; i < m; i++) cost += r[i] * r[i];
+  scal[0] = cost * 0.5;
+  scal[1] = sqrt(rho1);
+}
+
+__global__ void swp_scale_kernel(int P2, int n2, const double* __restrict__ scal, double* __restrict__ r, double* __restrict__ J) {
+  const double sc = scal[1];
+  const size_t tot = (size_t)P2 * n2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) J[i] *= sc;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)P2; i += (size_t)gridDim.x * blockDim.x) r[i] *= sc;
+}
+
+// A = (J S)^T (J S) (lower and mirrored), g = (J S)^T r; one lane per (a,b), rows summed in ascending order.
+__global__ void swp_normal_kernel(int m, int n2, const double* __restrict__ J, const double* __restrict__ r, const double* __restrict__ cs,
+                                  double* __restrict__ A, double* __restrict__ g) {
+  __shared__ double Ja[16][17], Jb[16][17], rr[16];
+  const int ta = blockIdx.y * 16, tb = blockIdx.x * 16;
+  if (tb > ta) return;
+  const int la = threadIdx.y, lb = threadIdx.x;
+  const int a = ta + la, b = tb + lb;
+  const double csa = a < n2 ? cs[a] : 0.0, csb = b < n2 ? cs[b] : 0.0;
+  double acc = 0.0, gacc = 0.0;
+  for (int i0 = 0; i0 < m; i0 += 16) {
+    // stage 16 rows x 16 columns of both column tiles (thread (la, lb) loads row i0+la)
+    const int i = i0 + la;
+    Ja[la][lb] = (i < m && ta + lb < n2) ? J[(size_t)i * n2 + ta + lb] : 0.0;
+    Jb[la][lb] = (i < m && tb + lb < n2) ? J[(size_t)i * n2 + tb + lb] : 0.0;
+    if (lb == 0) rr[la] = i < m ? r[i] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const double ja = Ja[k][la], jb = Jb[k][lb];
+      if (ja != 0.0) {
+        const double jas = ja * csa;
+        if (jb != 0.0) acc += jas * (jb * csb);
+        if (tb == 0 && lb == 0) gacc += jas * rr[k];
+      }
+    }
+    __syncthreads();
+  }
+  if (a < n2 && b < n2 && b <= a) { A[(size_t)a * n2 + b] = acc; A[(size_t)b * n2 + a] = acc; }
+  if (tb == 0 && lb == 0 && a < n2) g[a] = gacc;
+}
+
+// One workgroup: M = A + diag(clamp(diag A)/radius), Cholesky (row-wise left-looking, oracle summation order), solve M dx = -g,
+// model = -(dx.g + 1/2 dx^T A dx).  out[0] = ok, out[1] = model.
+__global__ void swp_solve_kernel(int n, const double* __restrict__ A, const double* __restrict__ g, double radius, double* __restrict__ M,
+                                 double* __restrict__ dx, double* __restrict__ out) {
+  __shared__ int bad;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (size_t i = tid; i < (size_t)n * n; i += nt) {
+    const int rr = (int)(i / n), cc = (int)(i % n);
+    double v = A[i];
+    if (rr == cc) v += fmin(fmax(v, 1e-6), 1e32) / radius;
+    M[i] = v;
+  }
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    // every lane forms the pivot itself (same sequential sum), rows r > k form their entry of column k
+    double d = M[(size_t)k * n + k];
+    for (int j = 0; j < k; j++) d -= M[(size_t)k * n + j] * M[(size_t)k * n + j];
+    if (!(d > 0)) { if (tid == 0) bad = 1; }
+    const double piv = sqrt(d);
+    for (int rI = k + 1 + tid; rI < n; rI += nt) {
+      double v = M[(size_t)rI * n + k];
+      for (int j = 0; j < k; j++) v -= M[(size_t)rI * n + j] * M[(size_t)k * n + j];
+      M[(size_t)rI * n + k] = v / piv;
+    }
+    __syncthreads();
+    if (tid == 0) M[(size_t)k * n + k] = piv;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out[0] = bad ? 0.0 : 1.0;
+    out[1] = 0.0;
+    if (!bad) {
+      for (int i = 0; i < n; i++) { double v = -g[i]; for (int j = 0; j < i; j++) v -= M[(size_t)i * n + j] * dx[j]; dx[i] = v / M[(size_t)i * n + i]; }
+      for (int i = n - 1; i >= 0; i--) { double v = dx[i]; for (int j = i + 1; j < n; j++) v -= M[(size_t)j * n + i] * dx[j]; dx[i] = v / M[(size_t)i * n + i]; }
+      double dg = 0, q = 0;
+      for (int a = 0; a < n; a++) {
+        dg += dx[a] * g[a];
+        double t = 0;
+        for (int b = 0; b < n; b++) t += A[(size_t)a * n + b] * dx[b];
+        q += dx[a] * t;
+      }
+      const double model = -(dg + 0.5 * q);
+      out[1] = model;
+      if (!(model > 0)) out[0] = 0.0;
+    }
+  }
+}
+
+// xn = x + dx*cs; out[2] = |step|, out[3] = |x|, out[4] = max |g|
+__global__ void swp_step_kernel(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
+                                const double* __restrict__ g, double* __restrict__ xn, double* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double sn = 0, xnrm = 0, gm = 0;
+  for (int j = 0; j < n; j++) {
+    const double st = dx[j] * cs[j];
+    xn[j] = x[j] + st;
+    sn += st * st;
+    xnrm += x[j] * x[j];
+    gm = fmax(gm, fabs(g[j]));
+  }
+  out[2] = sqrt(sn); out[3] = sqrt(xnrm); out[4] = gm;
+}
+
+__global__ void swp_colscale_kernel(int n, const double* __restrict__ A, double* __restrict__ cs) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) cs[j] = 1.0 / (1.0 + sqrt(A[(size_t)j * n + j]));
+}
+
+// DiffProp records of the fitted warp (SchwarpDatabase.cc:243-345): six evaluations -> float32 key points
+__global__ void swp_diffprop_kernel(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const double* __restrict__ x,
+                                    float fx_true, float fy_true, float* __restrict__ diff, uint8_t* __restrict__ drop) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.P) return;
+  const double u = kp1[2 * i], v = kp1[2 * i + 1];
+  double ax, ay;
+  float qe[2], dqu[2], dqv[2], dquv[2], dquu[2], dqvv[2];
+  swp_eval16(p, x, u, v, 0, 0, ax, ay); qe[0] = (float)ax; qe[1] = (float)ay;
+  swp_eval16(p, x, u, v, 1, 0, ax, ay); dqu[0] = (float)ax; dqu[1] = (float)ay;
+  swp_eval16(p, x, u, v, 0, 1, ax, ay); dqv[0] = (float)ax; dqv[1] = (float)ay;
+  swp_eval16(p, x, u, v, 1, 1, ax, ay); dquv[0] = (float)ax; dquv[1] = (float)ay;
+  swp_eval16(p, x, u, v, 2, 0, ax, ay); dquu[0] = (float)ax; dquu[1] = (float)ay;
+  swp_eval16(p, x, u, v, 0, 2, ax, ay); dqvv[0] = (float)ax; dqvv[1] = (float)ay;
+  float ex = qe[0] - kp2[2 * i], ey = qe[1] - kp2[2 * i + 1];
+  ex *= fx_true; ey *= fy_true;
+  drop[i] = sqrt((double)ex * ex + (double)ey * ey) > 10 ? 1 : 0;
+  float* d = diff + 18 * (size_t)i;
+  d[0] = kp1[2 * i]; d[1] = kp1[2 * i + 1]; d[2] = kp2[2 * i]; d[3] = kp2[2 * i + 1];
+  d[4] = dqu[0]; d[5] = dqu[1]; d[6] = dqv[0]; d[7] = dqv[1];
+  const float det = dqu[0] * dqv[1] - dqv[0] * dqu[1];
+  d[8] = d[7] / det; d[9] = -d[6] / det; d[10] = -d[5] / det; d[11] = d[4] / det;
+  d[12] = dquu[0]; d[13] = dquu[1]; d[14] = dquv[0]; d[15] = dquv[1]; d[16] = dqvv[0]; d[17] = dqvv[1];
+}
+
 }  // namespace
 
 // ---- launchers (called from dsh_nrsfm.cpp) ---------------------------------------------------------
@@ -342,5 +599,48 @@ extern "C" hipError_t nrsfm_launch_normals(int P, int R, const int32_t* rec_ptr,
   if (R > 0)
     hipLaunchKernelGGL(normals_propagate_kernel, dim3((R + block - 1) / block), dim3(block), 0, st, R, recs, rec_point, is_ref, first_n, has_first_n, k1k2,
                        status, normal_rec, written);
+  return hipGetLastError();
+}
+
+// ---- Schwarp launchers ------------------------------------------------------------------------------
+extern "C" hipError_t nrsfm_swp_eval(double umin, double umax, int nu, double vmin, double vmax, int nv, int P, double fxs, double fys, double lambda,
+                                     const float* kp1, const float* kp2, const float* invsig, const double* x, double* r, double* J, int with_j, hipStream_t st) {
+  SwpPar p = {umin, umax, vmin, vmax, fxs, fys, lambda, nu, nv, nu * nv, P};
+  const int tot = P + p.N, block = 128;
+  if (with_j) {
+    hipError_t e = hipMemsetAsync(J, 0, sizeof(double) * (size_t)(2 * P + 4 * p.N) * 2 * p.N, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(swp_eval_kernel<true>, dim3((tot + block - 1) / block), dim3(block), 0, st, p, kp1, kp2, invsig, x, r, J);
+  } else {
+    hipLaunchKernelGGL(swp_eval_kernel<false>, dim3((tot + block - 1) / block), dim3(block), 0, st, p, kp1, kp2, invsig, x, r, J);
+  }
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_swp_loss(int P2, int m, const double* r, double* scal, hipStream_t st) {
+  hipLaunchKernelGGL(swp_loss_kernel, dim3(1), dim3(64), 0, st, P2, m, r, scal);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_swp_normal(int P2, int m, int n2, double* J, double* r, const double* cs, const double* scal, double* A, double* g, hipStream_t st) {
+  hipLaunchKernelGGL(swp_scale_kernel, dim3(256), dim3(256), 0, st, P2, n2, scal, r, J);
+  const int nt = (n2 + 15) / 16;
+  hipLaunchKernelGGL(swp_normal_kernel, dim3(nt, nt), dim3(16, 16), 0, st, m, n2, J, r, cs, A, g);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_swp_colscale(int n2, const double* A, double* cs, hipStream_t st) {
+  hipLaunchKernelGGL(swp_colscale_kernel, dim3((n2 + 127) / 128), dim3(128), 0, st, n2, A, cs);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, double radius, double* M, double* dx, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), 0, st, n2, A, g, radius, M, dx, out);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_swp_step(int n2, const double* x, const double* dx, const double* cs, const double* g, double* xn, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(swp_step_kernel, dim3(1), dim3(64), 0, st, n2, x, dx, cs, g, xn, out);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_swp_diffprop(double umin, double umax, int nu, double vmin, double vmax, int nv, int P, const float* kp1, const float* kp2,
+                                         const double* x, float fx_true, float fy_true, float* diff, uint8_t* drop, hipStream_t st) {
+  SwpPar p = {umin, umax, vmin, vmax, 0.0, 0.0, 0.0, nu, nv, nu * nv, P};
+  hipLaunchKernelGGL(swp_diffprop_kernel, dim3((P + 127) / 128), dim3(128), 0, st, p, kp1, kp2, x, fx_true, fy_true, diff, drop);
   return hipGetLastError();
 }

@@ -91,3 +91,36 @@ def ObtainK1K2(ctx: Context, rec_ptr, recs, rec_is_ref, rec_first_normal, rec_ha
                                            _ptr(out.normal_ref, C.c_float), _ptr(out.normal_rec, C.c_float), _ptr(out.rec_written, C.c_uint8),
                                            _ptr(out.iters, C.c_int32)), "dsh_normals_estimate")
     return out
+
+
+def schwarp_eval(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot, lam, x, want_jacobian=True):
+    """Warps::Warp::Evaluate + Warps::Schwarzian::Evaluate once: (residuals[2P+4N], J[(2P+4N), 2N] or None)."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    invsig = np.ascontiguousarray(invsig, np.float32)
+    x = np.ascontiguousarray(x, np.float64)
+    P, N = kp1.shape[0], bbs.nptsu * bbs.nptsv
+    r = np.zeros(2 * P + 4 * N)
+    J = np.zeros((2 * P + 4 * N, 2 * N)) if want_jacobian else None
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_schwarp_eval(ctx._h, C.byref(b), P, _ptr(kp1, C.c_float), _ptr(kp2, C.c_float), _ptr(invsig, C.c_float), float(fx_slot),
+                                       float(fy_slot), float(lam), _ptr(x, C.c_double), _ptr(r, C.c_double), _ptr(J, C.c_double)), "dsh_schwarp_eval")
+    return r, J
+
+
+def calculateSchwarps(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot, lam, fx, fy, x0, max_iters=3):
+    """SchwarpDatabase::calculateSchwarps: returns (x, diffprops[P,18] float32, drop[P], info, costs)."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    invsig = np.ascontiguousarray(invsig, np.float32)
+    x = np.array(x0, np.float64, copy=True)
+    P = kp1.shape[0]
+    diff = np.zeros((P, 18), np.float32)
+    drop = np.zeros(P, np.uint8)
+    info = np.zeros(2, np.int32)
+    costs = np.zeros(2)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_schwarp_fit(ctx._h, C.byref(b), P, _ptr(kp1, C.c_float), _ptr(kp2, C.c_float), _ptr(invsig, C.c_float), float(fx_slot),
+                                      float(fy_slot), float(lam), float(fx), float(fy), int(max_iters), _ptr(x, C.c_double), _ptr(diff, C.c_float),
+                                      _ptr(drop, C.c_uint8), _ptr(info, C.c_int32), _ptr(costs, C.c_double)), "dsh_schwarp_fit")
+    return x, diff, drop.astype(bool), info, costs

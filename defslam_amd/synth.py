@@ -205,3 +205,54 @@ def make_normals_scene(n_points: int = 200, n_views: int = 4, seed: int = 7, non
                 rec_first_normal=np.asarray(first_n, np.float32).reshape(-1, 2), rec_has_first_normal=np.asarray(has_first_n, np.uint8),
                 x0=np.asarray(x0, np.float32), has_x0=np.asarray(has_x0, np.uint8), ref_uv=np.asarray(ref_uv, np.float32),
                 k_true=np.asarray(truth))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Schwarp fit: matches between two keyframes related by a smooth warp (a homography of a plane plus a gentle
+# non-rigid ripple), normalised image coordinates, 13 x 15 control grid as in Thirdparty/BBS/bbs_MAC.h.
+# ---------------------------------------------------------------------------------------------------------
+def _coloc_dense(umin, umax, nu, vmin, vmax, nv, u, v):
+    """Dense colocation matrix of the uniform bicubic B-spline (numpy, for building test inputs only)."""
+    def parts(x, xmin, xmax, npts):
+        t = (x - xmin) * (npts - 3) / (xmax - xmin)
+        i = np.minimum(np.floor(t).astype(int), npts - 4)
+        t = t - i
+        B = np.stack([(1 - t) ** 3, 3 * t**3 - 6 * t**2 + 4, -3 * t**3 + 3 * t**2 + 3 * t + 1, t**3], 1) / 6.0
+        return i, B
+    Iu, Bu = parts(np.asarray(u, float), umin, umax, nu)
+    Iv, Bv = parts(np.asarray(v, float), vmin, vmax, nv)
+    A = np.zeros((len(Iu), nu * nv))
+    for a in range(4):
+        for b in range(4):
+            np.add.at(A, (np.arange(len(Iu)), (Iu + a) * nv + Iv + b), Bu[:, a] * Bv[:, b])
+    return A
+
+
+def make_warp_problem(n_matches: int = 400, seed: int = 3, nu: int = 13, nv: int = 15, noise: float = 5e-4, outliers: float = 0.0):
+    rng = np.random.default_rng(seed)
+    kp1 = np.stack([rng.uniform(-0.55, 0.55, n_matches), rng.uniform(-0.42, 0.42, n_matches)], 1)
+    N = np.array([0.15, -0.1, 1.0]) / 1.1
+    Hm = _rodrigues(np.array([0.02, -0.05, 0.03])) + np.outer(np.array([0.06, -0.04, 0.02]), N)
+    p = np.c_[kp1, np.ones(n_matches)] @ Hm.T
+    kp2 = p[:, :2] / p[:, 2:3]
+    kp2[:, 0] += 0.01 * np.sin(3.0 * kp1[:, 1])
+    kp2 += rng.normal(scale=noise, size=kp2.shape)
+    if outliers > 0:
+        bad = rng.uniform(size=n_matches) < outliers
+        kp2[bad] += rng.uniform(-0.2, 0.2, size=(int(bad.sum()), 2))
+    # domain: bounding box of the key points +- 0.10 (DefKeyFrame.cc:116-131)
+    umin, umax = float(kp1[:, 0].min() - 0.10), float(kp1[:, 0].max() + 0.10)
+    vmin, vmax = float(kp1[:, 1].min() - 0.10), float(kp1[:, 1].max() + 0.10)
+    octave = rng.integers(0, 6, n_matches)
+    invsig = np.sqrt((1.2 ** (-2.0 * octave)).astype(np.float32)).astype(np.float32)
+    # start: what Warp::initialize hands over (Schwarp.cc:99-160) -- a regularised linear least-squares fit of the control
+    # points to the matches; here the regulariser pulls towards the identity map (Greville abscissae).
+    C = _coloc_dense(umin, umax, nu, vmin, vmax, nv, kp1[:, 0], kp1[:, 1])
+    iu, iv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    su, sv = (umax - umin) / (nu - 3), (vmax - vmin) / (nv - 3)
+    ident = np.stack([(umin + su * (iu - 1)).ravel(), (vmin + sv * (iv - 1)).ravel()], 1)
+    mu = 1e-2
+    cp = np.linalg.solve(C.T @ C + mu * np.eye(nu * nv), C.T @ kp2 + mu * ident)
+    x0 = np.concatenate([cp[:, 0], cp[:, 1]])
+    return dict(bbs=(umin, umax, nu, vmin, vmax, nv, 2), kp1=kp1.astype(np.float32), kp2=kp2.astype(np.float32), invsig=invsig, x0=x0,
+                fx=520.0, fy=515.0)

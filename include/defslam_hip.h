@@ -173,6 +173,23 @@ int dsh_normals_estimate(dsh_ctx* ctx, int P, const int32_t* rec_ptr, const dsh_
                          const float* ref_uv, double* k1k2, double* cov, int32_t* status, float* normal_ref, float* normal_rec,
                          uint8_t* rec_written, int32_t* iters);
 
+/* Schwarzian-regularised B-spline warp between two keyframes.
+ * Parameters x[2N], N = nptsu*nptsv: x[0..N) first coordinate of the control points, x[N..2N) second (index iu*nptsv+iv).
+ * kp1 / kp2: P normalised key points (float32 x,y) of the reference / current keyframe; invsig[P] = sqrt(invSigma2[octave]);
+ * fx_slot / fy_slot: the values the reference passes in Warp's (fx, fy) slots (SchwarpDatabase.cc:200-201 passes (fy, fx)).
+ * dsh_schwarp_eval: the two Ceres cost functions evaluated once -- Warps::Warp::Evaluate (Schwarp.cc:235-303) in rows
+ *   [0, 2P) and Warps::Schwarzian::Evaluate (Schwarp.cc:368-543) in rows [2P, 2P+4N); jacobian (may be NULL) is dense
+ *   row-major (2P+4N) x 2N, including the reference's overwritten y-rows of the warp block. */
+int dsh_schwarp_eval(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, const float* invsig, double fx_slot,
+                     double fy_slot, double lambda, const double* x, double* residuals, double* jacobian);
+/* SchwarpDatabase::calculateSchwarps (SchwarpDatabase.cc:145-349): HuberLoss(5.77) on the warp block, Levenberg-Marquardt
+ * (max_iters = 3 in the reference), then the DiffProp record of every match (diff[P], may be NULL together with drop) and
+ * drop[p] = 1 when its reprojection error exceeds 10 px (fx, fy = KF->fx, KF->fy).  x is in/out.
+ * info[0] = iterations, info[1] = accepted steps; costs[0] initial, costs[1] final cost (both may be NULL). */
+int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, const float* invsig, double fx_slot,
+                    double fy_slot, double lambda, float fx, float fy, int max_iters, double* x, dsh_diffprop* diff, uint8_t* drop,
+                    int32_t* info, double* costs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -308,3 +308,39 @@ def poly_eval(q1, q2, x):
     J = np.zeros(4)
     L.nrsfm_oracle_poly_eval(_p(q1, C.c_double), _p(q2, C.c_double), _p(x, C.c_double), _p(e, C.c_double), _p(J, C.c_double))
     return e, J.reshape(2, 2)
+
+
+# ---- Schwarp oracle ----------------------------------------------------------------------------------
+def schwarp_eval(bbs, kp1, kp2, invsig, fxs, fys, lam, x, want_jacobian=True):
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    invsig = np.ascontiguousarray(invsig, np.float32)
+    x = np.ascontiguousarray(x, np.float64)
+    P, N = kp1.shape[0], nu * nv
+    r = np.zeros(2 * P + 4 * N)
+    J = np.zeros((2 * P + 4 * N, 2 * N)) if want_jacobian else None
+    D = C.c_double
+    L.schwarp_oracle_eval(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), P, _p(kp1, C.c_float), _p(kp2, C.c_float), _p(invsig, C.c_float),
+                          D(fxs), D(fys), D(lam), _p(x, D), _p(r, D), _p(J, D))
+    return r, J
+
+
+def schwarp_fit(bbs, kp1, kp2, invsig, fxs, fys, lam, fx, fy, x0, max_iters=3):
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    invsig = np.ascontiguousarray(invsig, np.float32)
+    x = np.array(x0, np.float64, copy=True)
+    P = kp1.shape[0]
+    diff = np.zeros((P, 18), np.float32)
+    drop = np.zeros(P, np.uint8)
+    info = np.zeros(2, np.int32)
+    costs = np.zeros(2)
+    D = C.c_double
+    L.schwarp_oracle_fit(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), P, _p(kp1, C.c_float), _p(kp2, C.c_float), _p(invsig, C.c_float),
+                         D(fxs), D(fys), D(lam), C.c_float(fx), C.c_float(fy), int(max_iters), _p(x, D), _p(diff, C.c_float), _p(drop, C.c_uint8),
+                         _p(info, C.c_int32), _p(costs, D))
+    return x, diff, drop.astype(bool), info, costs

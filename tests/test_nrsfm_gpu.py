@@ -98,3 +98,49 @@ def test_normals_degenerate_inputs(gpu_ctx, oracle_mod):
     assert g.status.tolist() == o["status"].tolist() == [1, 2, 1]
     assert g.rec_written.tolist() == o["rec_written"].tolist() == [0, 1, 0]
     np.testing.assert_array_equal(g.normal_rec[1], o["normal_rec"][1])
+
+
+@pytest.mark.parametrize("P,seed,lam", [(300, 3, 0.1), (57, 8, 1.0), (1200, 1, 0.3)])
+def test_schwarp_residuals_and_jacobian_match_oracle(gpu_ctx, oracle_mod, P, seed, lam):
+    """Warps::Warp::Evaluate + Warps::Schwarzian::Evaluate (rows B1a, B1b), including the reference's overwritten warp y-rows."""
+    from defslam_amd import nrsfm, synth
+    pr = synth.make_warp_problem(P, seed)
+    x = pr["x0"] + np.random.default_rng(seed).normal(scale=5e-3, size=pr["x0"].shape)
+    ro, Jo = oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, x)
+    rg, Jg = nrsfm.schwarp_eval(gpu_ctx, nrsfm.Bbs(*pr["bbs"]), pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, x)
+    np.testing.assert_array_equal(Jg != 0, Jo != 0)                       # sparsity: bit-exact tap indexing
+    np.testing.assert_allclose(rg, ro, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(Jg, Jo, rtol=1e-13, atol=1e-15)
+    N = pr["bbs"][2] * pr["bbs"][5]
+    np.testing.assert_array_equal(Jg[:P], Jg[P:2 * P])                     # quirk: y rows are copies of the x rows
+    assert (Jg[:2 * P, N:] == 0).all()
+    # the Schwarzian block is the true derivative (central differences)
+    for k in [3, N + 7, 2 * N - 1]:
+        d = np.zeros_like(x)
+        d[k] = 1e-6
+        fd = (nrsfm.schwarp_eval(gpu_ctx, nrsfm.Bbs(*pr["bbs"]), pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, x + d, False)[0] -
+              nrsfm.schwarp_eval(gpu_ctx, nrsfm.Bbs(*pr["bbs"]), pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, x - d, False)[0]) / 2e-6
+        np.testing.assert_allclose(fd[2 * P:], Jg[2 * P:, k], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("P,seed,lam,outl,iters", [(300, 3, 0.1, 0.0, 3), (300, 3, 1.0, 0.05, 3), (150, 5, 1.0, 0.0, 12), (40, 9, 0.5, 0.1, 3)])
+def test_schwarp_fit_matches_oracle(gpu_ctx, oracle_mod, P, seed, lam, outl, iters):
+    """SchwarpDatabase::calculateSchwarps (row B1c): same accept/reject sequence, same control points, same DiffProp records."""
+    from defslam_amd import nrsfm, synth
+    pr = synth.make_warp_problem(P, seed, outliers=outl)
+    xo, do, dro, io, co = oracle_mod.schwarp_fit(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, pr["fx"], pr["fy"], pr["x0"], iters)
+    xg, dg, drg, ig, cg = nrsfm.calculateSchwarps(gpu_ctx, nrsfm.Bbs(*pr["bbs"]), pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, pr["fx"], pr["fy"],
+                                                  pr["x0"], iters)
+    np.testing.assert_array_equal(ig, io)                                   # iterations and accepted steps
+    np.testing.assert_allclose(cg, co, rtol=1e-10)
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-9 * max(1.0, np.abs(xo).max()))
+    np.testing.assert_array_equal(drg, dro)                                 # which matches are dropped (> 10 px)
+    np.testing.assert_allclose(dg, do, rtol=2e-6, atol=1e-6)                # float32 DiffProp fields
+    # J21 fields exactly as SchwarpDatabase.cc:322-329 assigns them (note: b and c trade places w.r.t. the matrix inverse)
+    a, b, c, d = dg[:, 4], dg[:, 5], dg[:, 6], dg[:, 7]
+    det = a * d - c * b
+    good = np.abs(det) > 0.2
+    np.testing.assert_allclose(dg[good, 8], (d / det)[good], rtol=1e-5)
+    np.testing.assert_allclose(dg[good, 9], (-c / det)[good], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dg[good, 10], (-b / det)[good], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dg[good, 11], (a / det)[good], rtol=1e-5)

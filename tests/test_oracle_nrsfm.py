@@ -130,3 +130,36 @@ def test_normals_status_codes_and_propagation(oracle_mod):
     o2 = oracle_mod.normals(np.array([0, 1], np.int32), recs, np.array([1], np.uint8), np.zeros((1, 2), np.float32), np.array([0], np.uint8),
                             np.zeros((1, 2), np.float32), np.array([0], np.uint8), np.zeros((1, 2), np.float32))
     assert o2["status"][0] == 2 and not o2["rec_written"][0]
+
+
+def test_schwarp_oracle_schwarzian_jacobian_is_exact_and_warp_rows_follow_the_reference_quirks(oracle_mod):
+    from defslam_amd import synth
+    pr = synth.make_warp_problem(120, 4)
+    P, N = 120, 195
+    x = pr["x0"] + np.random.default_rng(4).normal(scale=5e-3, size=390)
+    r, J = oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], 0.7, x)
+    for k in [0, 97, 194, 195, 300, 389]:
+        d = np.zeros(390)
+        d[k] = 1e-6
+        fd = (oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], 0.7, x + d, False)[0] -
+              oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], 0.7, x - d, False)[0]) / 2e-6
+        np.testing.assert_allclose(fd[2 * P:], J[2 * P:, k], rtol=1e-5, atol=1e-7)     # Schwarzian: true derivative
+        if k < N:   # warp x rows: -coloc*fx_slot, i.e. the true derivative divided by invSigma (the constant Jacobian has no invSigma)
+            np.testing.assert_allclose(fd[:P], J[:P, k] * pr["invsig"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(J[:P], J[P:2 * P])            # Schwarp.cc:291-298 copies the x rows over the y rows
+    assert (J[:2 * P, N:] == 0).all()
+    # an affine warp has zero Schwarzian derivative
+    iu, iv = np.meshgrid(np.arange(13), np.arange(15), indexing="ij")
+    aff = np.concatenate([(0.3 + 1.1 * iu - 0.2 * iv).ravel(), (-0.1 + 0.4 * iu + 0.9 * iv).ravel()])
+    ra, _ = oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], 0.7, aff, False)
+    assert np.abs(ra[2 * P:]).max() < 1e-9
+
+
+def test_schwarp_fit_never_increases_the_cost(oracle_mod):
+    from defslam_amd import synth
+    for seed, lam, outl in [(3, 0.1, 0.0), (3, 1.0, 0.05), (6, 2.0, 0.0)]:
+        pr = synth.make_warp_problem(200, seed, outliers=outl)
+        x, diff, drop, info, costs = oracle_mod.schwarp_fit(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, pr["fx"], pr["fy"], pr["x0"], 3)
+        assert info[0] <= 3 and costs[1] <= costs[0]
+        if info[1] == 0:
+            np.testing.assert_array_equal(x, pr["x0"])
