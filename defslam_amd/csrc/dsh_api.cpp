@@ -466,7 +466,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * SFT_BORDER * Dnp); w.Lc = a.take(8 * 56);
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.x = a.take(8 * (Dnp + 8)); w.chi2 = a.take(8 * (size_t)h.M); w.ferr = a.take(8 * (size_t)h.M);
-    w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(64);
+    w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(1024);
     max_kd = std::max(max_kd, h.kd);
   }
   if (sft_lm_kernel_lds_bytes(max_kd, jl_doubles) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
@@ -547,6 +547,17 @@ int dsh_sft_batch_phase_ms(dsh_ctx* c, int b, double* out8) {
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out8, c->h_probs[b].dbg, 8 * sizeof(double), hipMemcpyDeviceToHost));
+  if (std::getenv("DSH_STEP_TRACE")) {   // tuning aid: per-wave shader-clock stamps of factorisation step 40 (-DSFT_STEP_TRACE builds)
+    double t[96];
+    HIPCHK(c, hipMemcpy(t, c->h_probs[b].dbg, sizeof(t), hipMemcpyDeviceToHost));
+    double t0 = 1e300;
+    for (int w = 0; w < 8; w++) if (t[16 + 8 * w] > 0 && t[16 + 8 * w] < t0) t0 = t[16 + 8 * w];
+    for (int w = 0; w < 8; w++) {
+      std::printf("wave %d:", w);
+      for (int e = 0; e < 8; e++) std::printf(" %8.0f", t[16 + 8 * w + e] > 0 ? t[16 + 8 * w + e] - t0 : -1.0);
+      std::printf("\n");
+    }
+  }
   for (int i = 0; i < 8; i++) out8[i] *= 1e-5;  // 100 MHz ticks -> ms
   return DSH_OK;
 }
@@ -658,7 +669,7 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
   std::vector<double> Hb(band_elems), Hbord(SFT_BORDER * Dnp), Hc(56);
   auto hidx = [&](int r, int cc) -> size_t {
-    if (h.tile_mode) return ((size_t)(r >> 4) * (kBT + 1) + ((r >> 4) - (cc >> 4))) * (kTS * kTS) + (size_t)(r & 15) * kTS + (cc & 15);
+    if (h.tile_mode) return ((size_t)(r >> 4) * (kBT + 1) + ((r >> 4) - (cc >> 4))) * (kTS * kTS) + ((((r & 15) & 3) << 4) + (cc & 15)) * 4 + ((r & 15) >> 2);
     return (size_t)r * h.ldh + (cc - r + h.kd);
   };
   HIPCHK(c, hipMemcpy(Hb.data(), h.Hb, 8 * Hb.size(), hipMemcpyDeviceToHost));

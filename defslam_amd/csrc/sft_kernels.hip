@@ -39,6 +39,19 @@
 #define PH_RESET() do {} while (0)
 #endif
 
+// Per-wave time stamps of one factorisation step (shader clock), for tuning: -DSFT_STEP_TRACE
+#ifdef SFT_STEP_TRACE
+#define ST_MARK(ev) do { if (st_on && k == 40 && (threadIdx.x & 63) == 0) st_buf[(threadIdx.x >> 6) * 8 + (ev)] = (double)clock64(); } while (0)
+#define ST_DONE() do {} while (0)
+#define ST_BEGIN() double* st_buf = ws + 8000; const bool st_on = P.dbg[8] < 0.5   /* LDS scratch: stamps must not add global traffic */
+#define ST_END() do { __syncthreads(); if (st_on && threadIdx.x < 64) P.dbg[16 + threadIdx.x] = st_buf[threadIdx.x]; if (threadIdx.x == 0) P.dbg[8] = 1.0; } while (0)
+#else
+#define ST_MARK(ev) do {} while (0)
+#define ST_DONE() do {} while (0)
+#define ST_BEGIN() do {} while (0)
+#define ST_END() do {} while (0)
+#endif
+
 #define TS 16   // MFMA tile edge (v_mfma_f64_16x16x4_f64)
 #define TP 17   // padded leading dimension of a k-major tile in LDS
 #define BT 8    // sub-diagonal tiles per block column in tile mode (half-bandwidth <= 16*BT)
@@ -52,8 +65,12 @@ namespace {
 __device__ __forceinline__ size_t tile_off(int I, int d) { return ((size_t)I * (BT + 1) + d) * (TS * TS); }
 
 // Address of H(r, c), c <= r, in either storage mode.
+// Inside a tile the element (row, col) sits at ((row & 3) * 16 + col) * 4 + (row >> 2): the four doubles a lane holds in the
+// MFMA accumulator layout (rows (lane>>4) + 4q, column lane & 15) are contiguous -> two 16-byte accesses per lane and tile.
+__device__ __forceinline__ int tile_elem(int row, int col) { return (((row & 3) << 4) + col) * 4 + (row >> 2); }
+
 __device__ __forceinline__ size_t h_index(const SftDev& P, int r, int c) {
-  if (P.tile_mode) return tile_off(r >> 4, (r >> 4) - (c >> 4)) + (size_t)(r & 15) * TS + (c & 15);
+  if (P.tile_mode) return tile_off(r >> 4, (r >> 4) - (c >> 4)) + tile_elem(r & 15, c & 15);
   return (size_t)r * P.ldh + (c - r + P.kd);
 }
 
@@ -416,7 +433,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
         const int c = 3 * bj + b;
         if (c <= r) {
           P.Hb[h_index(P, r, c)] = H[3 * a + b];
-          if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) P.Hb[tile_off(r >> 4, 0) + (size_t)(c & 15) * TS + (r & 15)] = H[3 * a + b];
+          if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) P.Hb[tile_off(r >> 4, 0) + tile_elem(c & 15, r & 15)] = H[3 * a + b];
         }
       }
     }
@@ -786,6 +803,9 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   const double* Hbord = P.Hbord;
   double* Lg = P.Lb;
   double* Lbord = P.Lbord;
+  double* Linv_g = P.Linv;
+  const int mode = P.mode;   // every P.* used inside the step loop is hoisted: the struct lives in global memory
+  ST_BEGIN();
   v4d acc[BT];
 #pragma unroll
   for (int t = 0; t < BT; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -794,9 +814,7 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   auto fresh_tile = [&](int I, int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
     if (I < nT && J >= 0 && J <= I && I - J <= BT) {
-      const double* src = Hg + tile_off(I, I - J) + crow * TS + ccol;
-#pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = src[4 * q * TS];
+      v = *reinterpret_cast<const v4d*>(Hg + tile_off(I, I - J) + 4 * lane);
     }
     return v;
   };
@@ -835,35 +853,52 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
 #pragma unroll 1
   for (int k = -1; k < nT; k++) {
     const int kc = k + 1;                  // block column published / factored in this D phase
-    if (k >= 0 && !(P.mode & 16)) {
-      // ---- C(k): X_i = A_i Linv^T (one wave per sub-diagonal tile), border panel on 112 lanes ------
+    v4d x_keep = {0.0, 0.0, 0.0, 0.0};     // X tile / border value of this step, stored to global memory at the end of D
+    double xb_keep = 0.0;
+    ST_DONE();
+    ST_MARK(0);
+    if (k >= 0 && !(mode & 16)) {
+      // ---- C(k): X_i = A_i Linv^T (one wave per sub-diagonal tile), border panel on 16 lanes of 7 waves ------
+      if (wave == (k & (BT - 1))) {   // the wave that factored column k recycles its ring row now, off the critical path
+        load_row(k + BT);
+        bacc = fresh_border(k + BT);
+      }
       const int i = wave + 1;
-      v4d x = {0.0, 0.0, 0.0, 0.0};
+      v4d x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+      {
+        double av[4], bv[4];
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const double av = Araw[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
-        const double bv = LinvK[(4 * kk + crow) * TP + ccol];
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+        for (int kk = 0; kk < 4; kk++) {
+          av[kk] = Araw[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
+          bv[kk] = LinvK[(4 * kk + crow) * TP + ccol];
+        }
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], x, 0, 0, 0);     // two independent accumulation chains
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], x2, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], x2, 0, 0, 0);
       }
-      if (tid < SFT_BORDER * TS) {
-        const int r = tid / TS, j = tid % TS;
-        double sacc = 0.0;
+      if (wave < SFT_BORDER && lane < TS) {   // border row `wave`, column `lane` (overlaps the MFMAs above)
+        const int r = wave, j = lane;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < TS; kk++) sacc = fma(Abord[r * TS + kk], LinvK[kk * TP + j], sacc);
+        for (int kk = 0; kk < TS; kk += 2) {
+          s0 = fma(Abord[r * TS + kk], LinvK[kk * TP + j], s0);
+          s1 = fma(Abord[r * TS + kk + 1], LinvK[(kk + 1) * TP + j], s1);
+        }
+        const double sacc = s0 + s1;
         Xp[j * TP + r] = sacc;      // slot 0 of Xp, k-major like the other panel tiles
-        Lbord[(size_t)r * Dnp + TS * k + j] = sacc;
+        xb_keep = sacc;
       }
+      x += x2;
       double* dst = Xp + i * TILE_LDS + ccol * TP + crow;
 #pragma unroll
       for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
-      if (k + i < nT) {
-        double* g = Lg + tile_off(k + i, i) + crow * TS + ccol;
-#pragma unroll
-        for (int q = 0; q < 4; q++) g[4 * q * TS] = x[q];
-      }
+      x_keep = x;
+      ST_MARK(1);
       lds_barrier();
       PH_ADD(0);
     }
+    ST_MARK(2);
     // ---- D(k): trailing update of window / border / corner, look-ahead factorisation of column kc --
     const int I = kc + ((wave - kc) & (BT - 1));   // tile row held by this wave inside the window [kc, kc+BT-1]
     if (k >= 0) {
@@ -874,39 +909,29 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
         an[kk] = -Xp[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
         bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];                 // border panel
       }
-      if (I < nT && !(P.mode & 4)) {
+      const bool upd = I < nT && !(mode & 4);
+      const int Jb = kc + ((wave - kc) & (BT - 1));     // border tile of ring column `wave`: global tile column Jb
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        // one batch of LDS reads per k-chunk (a single wait), then MFMAs on independent accumulators back to back
+        double bb[BT + 1];
+#pragma unroll
+        for (int b = 0; b < BT; b++) bb[b] = Xp[(kc + ((b - kc) & (BT - 1)) - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+        bb[BT] = Xp[(Jb - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
 #pragma unroll
         for (int b = 0; b < BT; b++) {
           const int J = kc + ((b - kc) & (BT - 1));
-          if (J <= I) {
-            const int j = J - k;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-              const double bv = Xp[j * TILE_LDS + (4 * kk + crow) * TP + ccol];
-              acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bv, acc[b], 0, 0, 0);
-            }
-          }
+          if (upd && J <= I) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[b], acc[b], 0, 0, 0);
         }
-      }
-      {  // border tile of ring column `wave`: global tile column Jb in [kc, kc+BT-1]
-        const int Jb = kc + ((wave - kc) & (BT - 1));
-        const int j = Jb - k;
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const double bv = Xp[j * TILE_LDS + (4 * kk + crow) * TP + ccol];
-          bacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bv, bacc, 0, 0, 0);
-        }
-      }
-      if (wave == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
+        bacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bb[BT], bacc, 0, 0, 0);
+        if (wave == 0) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
       }
     }
+    ST_MARK(3);
     if (kc < nT) {
       if (I == kc) {
-        // owner of tile row kc: publish its border block, factor the diagonal tile, then recycle the ring row
-        if (crow + 0 < SFT_BORDER) Abord[(crow + 0) * TS + ccol] = bacc[0];
-        if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[1];
+        // owner of tile row kc: factor the diagonal tile first (critical path), publish its border block, recycle the ring row
+        __builtin_amdgcn_s_setprio(3);
         v4d dtile = acc[0];
         switch (wave) {
           case 1: dtile = acc[1]; break; case 2: dtile = acc[2]; break; case 3: dtile = acc[3]; break; case 4: dtile = acc[4]; break;
@@ -916,14 +941,17 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
         for (int q = 0; q < 4; q++)
           if (crow + 4 * q == ccol && TS * kc + ccol < Dn) dtile[q] += lambda;
         v4d w = dtile;
-        const bool ok = (P.mode & 8) ? true : chol_inv_mfma(dtile, w);
+        ST_MARK(4);
+        const bool ok = (mode & 8) ? true : chol_inv_mfma(dtile, w);
+        ST_MARK(5);
         if (!ok && lane == 0) ctl->fact_ok = 0;
         double* dst = LinvK + ccol * TP + crow;
-        double* g = P.Linv + (size_t)kc * TS * TS + crow * TS + ccol;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { dst[4 * q] = w[q]; g[4 * q * TS] = w[q]; }
-        load_row(kc + BT);
-        bacc = fresh_border(kc + BT);
+        for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
+        *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
+        __builtin_amdgcn_s_setprio(0);
+        if (crow + 0 < SFT_BORDER) Abord[(crow + 0) * TS + ccol] = bacc[0];
+        if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[1];
       } else {
         // publish tile (I, kc) of block column kc
         v4d t = acc[0];
@@ -942,9 +970,16 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
         fr8 = fresh_tile(kc + 1 + BT, kc + 1);
       }
     }
+    if (k >= 0 && !(mode & 16) && !(mode & 32)) {
+      if (k + wave + 1 < nT) *reinterpret_cast<v4d*>(Lg + tile_off(k + wave + 1, wave + 1) + 4 * lane) = x_keep;
+      if (wave < SFT_BORDER && lane < TS) Lbord[(size_t)wave * Dnp + TS * k + lane] = xb_keep;
+    }
+    ST_MARK(6);
     lds_barrier();
+    ST_MARK(7);
     PH_ADD(5);
   }
+  ST_END();
   if (wave == 0) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -996,6 +1031,8 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   for (int r = 0; r < 6; r++) xcr[r] = bcast_lane(xc, r);
   const double* Lg = P.Lb;
   const double* Lbord = P.Lbord;
+  const double* Linv_g = P.Linv;
+  double* xg = P.x;
   const int d = wave + 1;
   struct Pre { v4d t, li; double y, b[6]; };
   auto fetch = [&](int J) -> Pre {
@@ -1005,14 +1042,10 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
     for (int r = 0; r < 6; r++) p.b[r] = 0.0;
     if (J < 0) return p;
     if (J + d < nT) {
-      const double* g = Lg + tile_off(J + d, d) + crow * TS + ccol;
-#pragma unroll
-      for (int q = 0; q < 4; q++) p.t[q] = g[4 * q * TS];
+      p.t = *reinterpret_cast<const v4d*>(Lg + tile_off(J + d, d) + 4 * lane);
     }
     if (wave == 0) {
-      const double* g = P.Linv + (size_t)J * TS * TS + crow * TS + ccol;
-#pragma unroll
-      for (int q = 0; q < 4; q++) p.li[q] = g[4 * q * TS];
+      p.li = *reinterpret_cast<const v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
       p.y = Lbord[(size_t)6 * Dnp + TS * J + ccol];
     } else if (wave == 1) {
 #pragma unroll
@@ -1053,7 +1086,7 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
       for (int q = 0; q < 4; q++) p = fma(cur.li[q], __shfl(v, crow + 4 * q, 64), p);
       p += __shfl_xor(p, 16, 64);
       p += __shfl_xor(p, 32, 64);
-      if (lane < TS) { xw[(J & (BT - 1)) * TS + lane] = p; P.x[TS * J + lane] = p; }
+      if (lane < TS) { xw[(J & (BT - 1)) * TS + lane] = p; xg[TS * J + lane] = p; }
     }
     lds_barrier();
     cur = nxt;
@@ -1083,7 +1116,8 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
     const size_t nel = (size_t)(Dnp / TS) * (BT + 1) * TS * TS;
     for (size_t i = tid; i < nel; i += SFT_NT) {
       const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % (BT + 1)), I = (int)(i / ((size_t)(BT + 1) * TS * TS));
-      const bool pad_diag = td == 0 && (e / TS) == (e % TS) && TS * I + (e % TS) >= Dn;
+      const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
+      const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn;
       P.Hb[i] = pad_diag ? 1.0 : 0.0;
     }
   } else {
@@ -1097,7 +1131,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   if (tid == 0) {
     ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
     P.info[0] = 0; P.info[1] = 0; P.info[2] = 0;
-    for (int i = 0; i < 8; i++) P.dbg[i] = 0.0;
+    for (int i = 0; i < 96; i++) P.dbg[i] = 0.0;
   }
   __syncthreads();
   PH_T0();
@@ -1231,7 +1265,7 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
   const size_t backsub = NB + (SFT_NT / NB) * NB + NB * NB;
   if (backsub > panel) panel = backsub;
-  const size_t tiles = (size_t)(2 * (BT + 1) + 1) * TILE_LDS + SFT_BORDER * TS + 64;
+  const size_t tiles = (size_t)(2 * (BT + 1) + 1) * TILE_LDS + SFT_BORDER * TS + 64 + 3072;  // + room for the step-trace stamps
   if (kd <= TS * BT) panel = tiles;
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;

@@ -65,7 +65,8 @@ struct SftDev {
   double* Jstr;             // Es*4 (g, e)
   double* Jref;             // V*4  (e)
   double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
-                            // tile mode: nT*(BT+1) row-major 16x16 tiles, tile (I,J) at (I*(BT+1) + I-J)*256
+                            // tile mode: nT*(BT+1) 16x16 tiles, tile (I,J) at (I*(BT+1) + I-J)*256, element (row,col) at
+                            //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register)
   double* Hbord;            // 7*Dn     rows 0-5: camera x node, row 6: b_node
   double* Hcorner;          // 7*7      camera x camera (lower) + b_cam in row 6
   double* Lb;               // Dn*ldh
