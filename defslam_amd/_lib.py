@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdefslam_hip.so")
+# DSH_LIB_PATH: development override to A/B two builds of the same library on one GPU box
+LIB_PATH = os.environ.get("DSH_LIB_PATH") or os.path.join(_HERE, "lib", "libdefslam_hip.so")
 
 DSH_OK = 0
 DSH_TRACE_STRIDE = 8

@@ -15,7 +15,7 @@
 #include "dsh_template.h"
 #include "sft_problem.h"
 
-extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, hipStream_t stream);
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 
 namespace {
@@ -118,6 +118,8 @@ struct dsh_ctx : dsh_ctx_base {
   size_t ro_bytes = 0;             // leading read-only bytes of d_batch (uploaded)
   int max_kd = 0;
   size_t jl_doubles = 0;
+  int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
+  int num_cus = 256;
   bool ran = false;
 };
 
@@ -338,6 +340,8 @@ int dsh_create(dsh_ctx** out, int device) {
     delete c;
     return DSH_ERR_HIP;
   }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
   *out = c;
   return DSH_OK;
 }
@@ -449,10 +453,23 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   std::vector<WOffs> wo(B);
   int max_kd = 0;
   size_t jl_doubles = 0;
-  for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to nothing else (<= 96 KiB)
+  // Launch shape: 8 wavefronts per problem give the lowest latency; with at least two problems per CU, 4 wavefronts
+  // per problem (two problems resident per CU, <= 80 KB of LDS each) give the higher throughput.  Band mode needs 8.
+  int nw = 8;
+  {
+    bool all_tiles = true;
+    for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode;
+    if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
+    if (const char* e = std::getenv("DSH_SFT_WAVES")) {
+      const int v = std::atoi(e);
+      if ((v == 4 && all_tiles) || v == 8) nw = v;
+    }
+  }
+  const size_t jl_cap = (nw == 4 ? 72 : 96) * 1024;
+  for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to the solver workspace
     SftDev& hh = c->packed[b].h;
     const size_t need = 4 * ((size_t)hh.S + hh.Es + hh.V);
-    hh.jl_lds = (need * 8 <= 96 * 1024) ? 1 : 0;
+    hh.jl_lds = (need * 8 <= jl_cap) ? 1 : 0;
     if (hh.jl_lds) jl_doubles = std::max(jl_doubles, need);
   }
   for (int b = 0; b < B; b++) {
@@ -461,9 +478,12 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     WOffs& w = wo[b];
     w.xyz = a.take(8 * 3 * (size_t)h.n); w.bak = a.take(8 * 3 * (size_t)h.n); w.pose = a.take(8 * 8);
     w.Jobs = a.take(8 * (size_t)h.M * SFT_JOBS_STRIDE); w.Jstar = a.take(8 * 4 * (size_t)h.S); w.Jstr = a.take(8 * 4 * (size_t)h.Es); w.Jref = a.take(8 * 4 * (size_t)h.V);
-    const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
-    w.Hb = a.take(8 * band_elems); w.Hbord = a.take(8 * SFT_BORDER * Dnp); w.Hc = a.take(8 * 56);
-    w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * SFT_BORDER * Dnp); w.Lc = a.take(8 * 56);
+    // tile mode: BT+1 zero tile rows below the matrix and an 8th (zero) border row + one window of columns let the
+    // factorisation load every tile of its sliding window unconditionally (SFT_H_PAD_* in sft_problem.h)
+    const size_t band_elems = h.tile_mode ? (Dnp / kTS + SFT_H_PAD_TILE_ROWS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
+    const size_t bord_elems = (SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER;
+    w.Hb = a.take(8 * band_elems); w.Hbord = a.take(8 * bord_elems); w.Hc = a.take(8 * 56);
+    w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * bord_elems); w.Lc = a.take(8 * 56);
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.x = a.take(8 * (Dnp + 8)); w.chi2 = a.take(8 * (size_t)h.M); w.ferr = a.take(8 * (size_t)h.M);
     w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(1024);
@@ -505,6 +525,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->B = B;
   c->max_kd = max_kd;
   c->jl_doubles = jl_doubles;
+  c->nw = nw;
   c->ran = false;
   return DSH_OK;
 }
@@ -514,7 +535,7 @@ int dsh_sft_batch_run(dsh_ctx* c) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
   (void)hipSetDevice(c->device);
-  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->stream));
+  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
   c->ran = true;
   return DSH_OK;
 }
@@ -528,7 +549,7 @@ int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0.f;
@@ -661,7 +682,7 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   // flip the mode of this one problem, run it alone, restore
   h.mode = 1;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
-  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->stream));
+  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h.mode = 0;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));

@@ -1,6 +1,6 @@
 // Shape-from-Template Levenberg-Marquardt solve on gfx950 (MI355X), FP64.
 //
-// One workgroup (SFT_NT = 512 threads = 8 wavefronts, 2 per SIMD, up to 256 VGPRs each) owns one problem and runs the
+// One workgroup (8 wavefronts = 512 threads for latency, or 4 wavefronts so that two problems share a CU) owns one problem and runs the
 // whole optimisation of defSLAM::Optimizer::DefPoseOptimization on the device:
 //
 //   residuals + Jacobians ... sft_types.h:102-133,137-206 (EdgeNodesCamera), :257-311
@@ -16,8 +16,11 @@
 //
 // Every sum is evaluated in a fixed order (no atomics), so a run is bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <math.h>
 #include <float.h>
+#define SFT_KERNEL_SOURCE
 #include "sft_problem.h"
 
 #define NB 32  // panel width of the blocked band Cholesky
@@ -43,7 +46,7 @@
 #ifdef SFT_STEP_TRACE
 #define ST_MARK(ev) do { if (st_on && k == 40 && (threadIdx.x & 63) == 0) st_buf[(threadIdx.x >> 6) * 8 + (ev)] = (double)clock64(); } while (0)
 #define ST_DONE() do {} while (0)
-#define ST_BEGIN() double* st_buf = ws + 8000; const bool st_on = P.dbg[8] < 0.5   /* LDS scratch: stamps must not add global traffic */
+#define ST_BEGIN() lds_double* st_buf = to_lds(ws) + 5376; const bool st_on = P.dbg[8] < 0.5   /* LDS scratch: stamps must not add global traffic */
 #define ST_END() do { __syncthreads(); if (st_on && threadIdx.x < 64) P.dbg[16 + threadIdx.x] = st_buf[threadIdx.x]; if (threadIdx.x == 0) P.dbg[8] = 1.0; } while (0)
 #else
 #define ST_MARK(ev) do {} while (0)
@@ -185,7 +188,7 @@ __device__ void block_sum(double* v, double* red, double* out) {
   __syncthreads();
   if (threadIdx.x < NV) {
     double s = 0;
-    for (int w = 0; w < SFT_NT / 64; w++) s += red[w * NV + threadIdx.x];
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w * NV + threadIdx.x];
     out[threadIdx.x] = s;
   }
   __syncthreads();
@@ -198,7 +201,7 @@ __device__ double block_max(double v, double* red) {
   if (lane == 0) red[wave] = v;
   __syncthreads();
   double m = red[0];
-  for (int w = 1; w < SFT_NT / 64; w++) m = fmax(m, red[w]);
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = fmax(m, red[w]);
   __syncthreads();
   return m;
 }
@@ -232,7 +235,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
   const double* xyz = P.xyz;
   double chi = 0.0;
   const int total = P.M + P.V + P.S + P.Es;
-  for (int idx = threadIdx.x; idx < total; idx += SFT_NT) {
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     if (idx < P.M) {
       const int m = idx;
       const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
@@ -346,7 +349,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0.0;
-    for (int m = threadIdx.x; m < P.M; m += SFT_NT) {
+    for (int m = threadIdx.x; m < P.M; m += blockDim.x) {
       const double* rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
       const double wt = rec[2], e0 = rec[0], e1 = rec[1];
       double j0[6], j1[6];
@@ -443,7 +446,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
   constexpr int DG = 8;
   {
     const int sub = threadIdx.x & (DG - 1), grp = threadIdx.x / DG;
-    for (int a0 = 0; a0 < P.nA; a0 += SFT_NT / DG) {
+    for (int a0 = 0; a0 < P.nA; a0 += (int)blockDim.x / DG) {
       const int a = a0 + grp;
       double acc[30];
 #pragma unroll
@@ -473,7 +476,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
   }
   // ---- off-diagonal blocks: one lane per block, contributions in the reference's edge order
   const int noff = P.nblk - P.nA;
-  for (int o = threadIdx.x; o < noff; o += SFT_NT) {
+  for (int o = threadIdx.x; o < noff; o += blockDim.x) {
     const int q = P.off_blk[o];
     double H[9];
 #pragma unroll
@@ -780,61 +783,137 @@ __device__ __forceinline__ bool chol_inv_mfma(v4d& a, v4d& w) {
   return !bad;
 }
 
-// Tile-mode factorisation, 8 wavefronts.  Wave w owns ring row a = w of the BT x BT accumulator window
-// (slots b = 0..BT-1; tile (I,J) of the window [k+1, k+BT] sits in slot (I mod BT, J mod BT)), the border tile
-// of ring column w (7 camera/rhs rows x 16 columns) and, for wave 0, the 7x7 corner.  One step:
-//   C(k): X_i = A_i Linv_k^T for the published block column k (MFMA GEMM), border panel on 112 lanes
-//   D(k): window, border and corner get  -= X X^T (MFMA);  the owner of tile row k+1 factors the next
-//         diagonal tile while the other waves still update (look-ahead), everybody publishes block column k+1
+// Blocked variant of chol_inv_mfma (4x4 blocks, 13 MFMAs instead of 32 and 4 instead of 16 dependent block steps).
+// Block step J (rows/columns 4J..4J+3 live in register J of lane groups g = 0..3):
+//   1. the 10 entries of the symmetric 4x4 diagonal block are broadcast to every lane; every lane factors it and inverts
+//      the factor redundantly (uniform scalars): D = Ld Ld^T, M = Ld^-1
+//   2. Z  = Mpad * A[4J..4J+3, :]   one MFMA, B operand = register J of `a` as it is; Z[g][c] = L[c][4J+g] comes out
+//      in exactly the lane layout the rank-4 update needs for both of its operands
+//      Zw = Mpad * W[4J..4J+3, :]   the new rows 4J..4J+3 of W = L^-1
+//   3. a -= Z^T Z (rank 4),  W[rows below] -= L[rows below, 4J..4J+3] * Zw,  W[4J..4J+3, :] = Zw
+// Returns false when a pivot is not positive.
+__device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+  w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
+  bool bad = false;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int J = 0; J < 4; J++) {
+    const double aJ = a[J];
+    const int b0 = 4 * J;
+    const double d00 = bcast_lane(aJ, b0), d10 = bcast_lane(aJ, 16 + b0), d11 = bcast_lane(aJ, 16 + b0 + 1);
+    const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
+    const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
+    double i0, i1, i2, i3, sq;
+    if (!(d00 > 0.0)) bad = true;
+    rsqrt_sqrt(d00, i0, sq);
+    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+    const double p1 = fma(-l10, l10, d11);
+    if (!(p1 > 0.0)) bad = true;
+    rsqrt_sqrt(p1, i1, sq);
+    const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
+    const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
+    if (!(p2 > 0.0)) bad = true;
+    rsqrt_sqrt(p2, i2, sq);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
+    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+    if (!(p3 > 0.0)) bad = true;
+    rsqrt_sqrt(p3, i3, sq);
+    // M = Ld^-1 (lower triangular)
+    const double m10 = -(l10 * i0) * i1;
+    const double m21 = -(l21 * i1) * i2;
+    const double m32 = -(l32 * i2) * i3;
+    const double m20 = -fma(l21, m10, l20 * i0) * i2;
+    const double m31 = -fma(l32, m21, l31 * i1) * i3;
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * i0)) * i3;
+    // A operand of Z = Mpad * rows: lane (i = c, k = g) holds M[i][k] for i < 4, k <= i
+    double sel = 0.0;
+    sel = (c == 0 && g == 0) ? i0 : sel;
+    sel = (c == 1) ? (g == 0 ? m10 : (g == 1 ? i1 : 0.0)) : sel;
+    sel = (c == 2) ? (g == 0 ? m20 : (g == 1 ? m21 : (g == 2 ? i2 : 0.0))) : sel;
+    sel = (c == 3) ? (g == 0 ? m30 : (g == 1 ? m31 : (g == 2 ? m32 : i3))) : sel;
+    const v4d zw = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, w[J], zero, 0, 0, 0);
+    if (J < 3) {
+      const v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, aJ, zero, 0, 0, 0);
+      const double lp = z[0];                       // L[c][4J+g]
+      const double nlp = -lp;
+      a = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, lp, a, 0, 0, 0);
+      const double below = (c >= 4 * J + 4) ? nlp : 0.0;
+      w = __builtin_amdgcn_mfma_f64_16x16x4f64(below, zw[0], w, 0, 0, 0);
+    }
+    w[J] = zw[0];
+  }
+  return !bad;
+}
+
+// The solver workspace lives in LDS.  A non-inlined function only sees a generic pointer; the explicit address space keeps
+// its accesses on ds_* instructions (generic = flat_* instructions, which count on both the LDS and the memory counter).
+using lds_double = __attribute__((address_space(3))) double;
+__device__ __forceinline__ lds_double* to_lds(double* p) { return (lds_double*)p; }
+
+// Wave-uniform values that reach a (non-inlined) device function through memory or VGPR arguments: moving them to
+// scalar registers keeps ring bookkeeping, tile addresses and branches on the scalar unit.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// Tile-mode factorisation on NW wavefronts (NW = 8: one ring row per wave, lowest latency; NW = 4: two ring rows per
+// wave so that two problems share a CU).  Wave w owns ring rows a = w + NW*t (t < RPW) of the BT x BT accumulator window
+// (slots b = 0..BT-1; tile (I,J) of the window [k+1, k+BT] sits in slot (I mod BT, J mod BT)), the border tiles of the
+// same ring columns (7 camera/rhs rows x 16 columns) and, for wave 0, the 7x7 corner.  One step:
+//   C(k): X_i = A_i Linv_k^T for the published block column k (MFMA GEMM), border panel on 16 lanes per border row
+//   D(k): block column k+1 of the window is updated first and published; the owner of tile row k+1 factors the next
+//         diagonal tile while the other waves update the rest of the window (look-ahead); border and corner follow
+template <int NW>
 __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws) {
-  static_assert(SFT_NT == 64 * BT, "one wavefront per ring row");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Dn = P.Dn;
+  constexpr int RPW = BT / NW;
+  constexpr int NT = 64 * NW;
+  static_assert(RPW * NW == BT && NW >= 2, "ring rows must divide evenly over the wavefronts");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps ring bookkeeping and branches on the scalar unit
+  const int Dn = uni(P.Dn);
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
   const int nT = Dnp / TS;
-  double* Araw = ws;                         // (BT+1) tiles, k-major padded (slot 0 unused)
-  double* Xp = Araw + (BT + 1) * TILE_LDS;   // (BT+1) tiles; slot 0: border panel as a tile (rows 7..15 zero)
-  double* LinvK = Xp + (BT + 1) * TILE_LDS;  // Linv^T, k-major padded: LinvK[k*TP + j] = Linv[j][k]
-  double* Abord = LinvK + TILE_LDS;          // 7 x 16 border block of the published column, row-major
-  double* Cn = Abord + SFT_BORDER * TS;      // 7 x 7 corner (written once at the end)
+  lds_double* Araw = to_lds(ws);                        // (BT+1) tiles, k-major padded (slot 0 unused)
+  lds_double* Xp = Araw + (BT + 1) * TILE_LDS;   // (BT+1) tiles; slot 0: border panel as a tile (rows 7..15 zero)
+  lds_double* LinvK = Xp + (BT + 1) * TILE_LDS;  // Linv^T, k-major padded: LinvK[k*TP + j] = Linv[j][k]
+  lds_double* Abord = LinvK + TILE_LDS;          // 7 x 16 border block of the published column, row-major
+  lds_double* Cn = Abord + SFT_BORDER * TS;      // 7 x 7 corner (written once at the end)
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;   // accumulator layout: rows crow + 4q, column ccol
-  const double* Hg = P.Hb;
-  const double* Hbord = P.Hbord;
-  double* Lg = P.Lb;
-  double* Lbord = P.Lbord;
-  double* Linv_g = P.Linv;
-  const int mode = P.mode;   // every P.* used inside the step loop is hoisted: the struct lives in global memory
+  const auto Hg = uni(P.Hb);
+  const auto Hbord = uni(P.Hbord);
+  const auto Lg = uni(P.Lb);
+  const auto Lbord = uni(P.Lbord);
+  const auto Linv_g = uni(P.Linv);
+  const int mode = uni(P.mode);   // every P.* used inside the step loop is hoisted: the struct lives in global memory
   ST_BEGIN();
-  v4d acc[BT];
-#pragma unroll
-  for (int t = 0; t < BT; t++) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  v4d acc[RPW][BT];
+  v4d bacc[RPW];                        // border tiles of ring columns (wave + NW*t + BOFF) mod BT: never on the wave that factors that column
+  constexpr int BOFF = 2;
 
-  // raw tile (I, J) of H in accumulator layout (zero outside the matrix / band); no dependent ALU on the loads
-  auto fresh_tile = [&](int I, int J) -> v4d {
-    v4d v = {0.0, 0.0, 0.0, 0.0};
-    if (I < nT && J >= 0 && J <= I && I - J <= BT) {
-      v = *reinterpret_cast<const v4d*>(Hg + tile_off(I, I - J) + 4 * lane);
-    }
-    return v;
-  };
-  // border block of tile column J: rows 0..6 of Hbord, accumulator layout
+  // Raw tile (I, I-d) of H in accumulator layout.  The storage is zero-padded (SFT_H_PAD_*), so every tile the sliding
+  // window can ask for exists: loads are unconditional and nothing touches the loaded registers before the MFMAs do.
+  auto fresh_tile = [&](int I, int d) -> v4d { return *reinterpret_cast<const v4d*>(Hg + tile_off(I, d) + 4 * lane); };
+  // border block of tile column J: rows crow, crow+4 of the 8-row border (row 7 is zero), accumulator layout
   auto fresh_border = [&](int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
-    if (J < nT) {
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-        if (crow + 4 * q < SFT_BORDER) v[q] = Hbord[(size_t)(crow + 4 * q) * Dnp + TS * J + ccol];
-    }
+    v[0] = Hbord[(size_t)crow * Dnp + TS * J + ccol];
+    v[1] = Hbord[(size_t)(crow + 4) * Dnp + TS * J + ccol];
     return v;
   };
-  // tile row I enters the window: the owner of ring row (I mod BT) reloads its slots
-  auto load_row = [&](int I) {
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[b] = fresh_tile(I, I - ((I - b) & (BT - 1)));
-  };
-  load_row(wave);                       // rows 0..BT-1
-  v4d bacc = fresh_border(wave);        // border tile of column `wave`
+  for (int t = 0; t < RPW; t++) {       // rows 0..BT-1
+    const int I = wave + NW * t;
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1));
+    bacc[t] = fresh_border((I + BOFF) & (BT - 1));
+  }
   v4d cacc = {0.0, 0.0, 0.0, 0.0};      // wave 0: corner
   if (wave == 0) {
 #pragma unroll
@@ -843,136 +922,242 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
       if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
     }
   }
-  for (int i = tid; i < TILE_LDS; i += SFT_NT) Xp[i] = 0.0;   // rows 7..15 of the border panel tile stay zero
+  for (int i = tid; i < TILE_LDS; i += NT) Xp[i] = 0.0;   // rows 7..15 of the border panel tile stay zero
   if (tid == 0) ctl->fact_ok = 1;
-  v4d fr8 = {0.0, 0.0, 0.0, 0.0};       // wave 7: tile (kc+BT, kc) prefetched one step ahead
-  if (wave == BT - 1) fr8 = fresh_tile(BT, 0);
   __syncthreads();
   PH_T0();
 
 #pragma unroll 1
   for (int k = -1; k < nT; k++) {
     const int kc = k + 1;                  // block column published / factored in this D phase
-    v4d x_keep = {0.0, 0.0, 0.0, 0.0};     // X tile / border value of this step, stored to global memory at the end of D
-    double xb_keep = 0.0;
+    const int kslot = kc & (BT - 1);       // its ring slot
     ST_DONE();
     ST_MARK(0);
+    // ---- global-memory duties of this step, all on the wave that factored column k (its ring row is free again and it
+    // sits at the far end of the window, off the critical path): recycle the ring row with tile row k+BT, fetch tile
+    // (kc+BT, kc) for the published column, and at the end of D store block column k of L from the LDS panel.
+    // No other wave has vector-memory traffic in flight inside the loop, so the vmcnt waits the compiler places in
+    // front of the accumulator MFMAs cost the other waves nothing (the owner's Linv store precedes its turn here).
+    bool memwave = false;
+    v4d fr8 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < RPW; t++)
+      if (wave + NW * t == (k & (BT - 1))) {
+        memwave = true;
+        if (k >= 0) {
+          const int I = k + BT;
+#pragma unroll
+          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1));
+        }
+      }
+    if (memwave) fr8 = fresh_tile(kc + BT, BT);
+    if (k >= 0) {
+#pragma unroll
+      for (int t = 0; t < RPW; t++)   // the holder of ring column k mod BT (consumed by now) fetches the border block of column k+BT
+        if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
+    }
     if (k >= 0 && !(mode & 16)) {
-      // ---- C(k): X_i = A_i Linv^T (one wave per sub-diagonal tile), border panel on 16 lanes of 7 waves ------
-      if (wave == (k & (BT - 1))) {   // the wave that factored column k recycles its ring row now, off the critical path
-        load_row(k + BT);
-        bacc = fresh_border(k + BT);
-      }
-      const int i = wave + 1;
-      v4d x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
-      {
-        double av[4], bv[4];
+      // ---- C(k): X_i = A_i Linv^T (RPW sub-diagonal tiles per wave), border panel on 16 lanes per border row ------
+      v4d x[RPW], x2[RPW];
+      double bv[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          av[kk] = Araw[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
-          bv[kk] = LinvK[(4 * kk + crow) * TP + ccol];
-        }
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], x, 0, 0, 0);     // two independent accumulation chains
-        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], x2, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], x, 0, 0, 0);
-        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], x2, 0, 0, 0);
-      }
-      if (wave < SFT_BORDER && lane < TS) {   // border row `wave`, column `lane` (overlaps the MFMAs above)
-        const int r = wave, j = lane;
-        double s0 = 0.0, s1 = 0.0;
+      for (int kk = 0; kk < 4; kk++) bv[kk] = LinvK[(4 * kk + crow) * TP + ccol];
 #pragma unroll
-        for (int kk = 0; kk < TS; kk += 2) {
-          s0 = fma(Abord[r * TS + kk], LinvK[kk * TP + j], s0);
-          s1 = fma(Abord[r * TS + kk + 1], LinvK[(kk + 1) * TP + j], s1);
-        }
-        const double sacc = s0 + s1;
-        Xp[j * TP + r] = sacc;      // slot 0 of Xp, k-major like the other panel tiles
-        xb_keep = sacc;
-      }
-      x += x2;
-      double* dst = Xp + i * TILE_LDS + ccol * TP + crow;
+      for (int t = 0; t < RPW; t++) {
+        const int i = wave + 1 + NW * t;
+        double av[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
-      x_keep = x;
+        for (int kk = 0; kk < 4; kk++) av[kk] = Araw[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
+        x[t] = (v4d){0.0, 0.0, 0.0, 0.0}; x2[t] = x[t];
+        x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], x[t], 0, 0, 0);     // two independent accumulation chains
+        x2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], x2[t], 0, 0, 0);
+        x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], x[t], 0, 0, 0);
+        x2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], x2[t], 0, 0, 0);
+      }
+      if (wave == NW - 1) {   // border panel (7 camera/rhs rows) as one more MFMA tile: rows 7..15 of the operand are zero
+        double av[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) av[kk] = (ccol < SFT_BORDER) ? Abord[ccol * TS + 4 * kk + crow] : 0.0;
+        v4d xb = {0.0, 0.0, 0.0, 0.0}, xb2 = xb;
+        xb = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], xb, 0, 0, 0);
+        xb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], xb2, 0, 0, 0);
+        xb = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], xb, 0, 0, 0);
+        xb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], xb2, 0, 0, 0);
+        xb += xb2;
+        Xp[ccol * TP + crow] = xb[0];                                   // slot 0 of Xp, k-major like the other panel tiles
+        if (crow + 4 < SFT_BORDER) Xp[ccol * TP + crow + 4] = xb[1];
+      }
+#pragma unroll
+      for (int t = 0; t < RPW; t++) {
+        x[t] += x2[t];
+        lds_double* dst = Xp + (wave + 1 + NW * t) * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[4 * q] = x[t][q];
+      }
       ST_MARK(1);
       lds_barrier();
       PH_ADD(0);
     }
     ST_MARK(2);
     // ---- D(k): trailing update of window / border / corner, look-ahead factorisation of column kc --
-    const int I = kc + ((wave - kc) & (BT - 1));   // tile row held by this wave inside the window [kc, kc+BT-1]
+    int I[RPW];                                     // tile rows held by this wave inside the window [kc, kc+BT-1]
+#pragma unroll
+    for (int t = 0; t < RPW; t++) I[t] = kc + ((wave + NW * t - kc) & (BT - 1));
+    double an[RPW][4], bn[4];
     if (k >= 0) {
-      double an[4], bn[4];
-      const int i = I - k;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
-        an[kk] = -Xp[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
+#pragma unroll
+        for (int t = 0; t < RPW; t++) an[t][kk] = -Xp[(I[t] - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
         bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];                 // border panel
       }
-      const bool upd = I < nT && !(mode & 4);
-      const int Jb = kc + ((wave - kc) & (BT - 1));     // border tile of ring column `wave`: global tile column Jb
+      // block column kc first: it is what the next step needs published
+      if (!(mode & 4)) {
+        double bc[4];
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        // one batch of LDS reads per k-chunk (a single wait), then MFMAs on independent accumulators back to back
-        double bb[BT + 1];
+        for (int kk = 0; kk < 4; kk++) bc[kk] = Xp[TILE_LDS + (4 * kk + crow) * TP + ccol];
 #pragma unroll
-        for (int b = 0; b < BT; b++) bb[b] = Xp[(kc + ((b - kc) & (BT - 1)) - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
-        bb[BT] = Xp[(Jb - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+        for (int c = 0; c < BT; c++)
+          if (c == kslot) {
 #pragma unroll
-        for (int b = 0; b < BT; b++) {
-          const int J = kc + ((b - kc) & (BT - 1));
-          if (upd && J <= I) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[b], acc[b], 0, 0, 0);
-        }
-        bacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bb[BT], bacc, 0, 0, 0);
-        if (wave == 0) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
+            for (int t = 0; t < RPW; t++)
+              if (I[t] < nT) {   // two accumulation chains halve the dependent-MFMA latency of the critical tile
+                v4d side = {0.0, 0.0, 0.0, 0.0};
+                acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][0], bc[0], acc[t][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the two chains interleaved (the scheduler would serialise them)
+                side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][1], bc[1], side, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][2], bc[2], acc[t][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][3], bc[3], side, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t][c] += side;
+              }
+          }
+#pragma unroll
+        for (int t = 0; t < RPW; t++)
+          if (((wave + NW * t + BOFF) & (BT - 1)) == kslot) {   // holder of the border tile of column kc: update, publish below
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) bacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bc[kk], bacc[t], 0, 0, 0);
+          }
       }
     }
     ST_MARK(3);
+    bool owner = false;
     if (kc < nT) {
-      if (I == kc) {
-        // owner of tile row kc: factor the diagonal tile first (critical path), publish its border block, recycle the ring row
-        __builtin_amdgcn_s_setprio(3);
-        v4d dtile = acc[0];
-        switch (wave) {
-          case 1: dtile = acc[1]; break; case 2: dtile = acc[2]; break; case 3: dtile = acc[3]; break; case 4: dtile = acc[4]; break;
-          case 5: dtile = acc[5]; break; case 6: dtile = acc[6]; break; case 7: dtile = acc[7]; break; default: break;
+      v4d colt[RPW];
+#pragma unroll
+      for (int t = 0; t < RPW; t++) colt[t] = acc[t][0];
+#pragma unroll
+      for (int c = 1; c < BT; c++)
+        if (c == kslot) {
+#pragma unroll
+          for (int t = 0; t < RPW; t++) colt[t] = acc[t][c];
         }
+      v4d dtile = colt[0];
+#pragma unroll
+      for (int t = 0; t < RPW; t++) {
+        if (I[t] == kc) {
+          owner = true;
+          dtile = colt[t];
+        } else {
+          // publish tile (I, kc) of block column kc
+          lds_double* dst = Araw + (I[t] - kc) * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+          for (int q = 0; q < 4; q++) dst[4 * q] = colt[t][q];
+        }
+      }
+      if (memwave) {
+        lds_double* dst = Araw + BT * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[4 * q] = fr8[q];
+      }
+#pragma unroll
+      for (int t = 0; t < RPW; t++)
+        if (((wave + NW * t + BOFF) & (BT - 1)) == kslot) {   // border block of column kc for the next C phase
+          Abord[crow * TS + ccol] = bacc[t][0];
+          if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[t][1];
+        }
+      if (owner) {
+        // owner of tile row kc: factor the diagonal tile (critical path)
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int q = 0; q < 4; q++)
           if (crow + 4 * q == ccol && TS * kc + ccol < Dn) dtile[q] += lambda;
         v4d w = dtile;
         ST_MARK(4);
-        const bool ok = (mode & 8) ? true : chol_inv_mfma(dtile, w);
+        const bool ok = (mode & 8) ? true : ((mode & 64) ? chol_inv_mfma(dtile, w) : chol_inv_blocked(dtile, w));
         ST_MARK(5);
         if (!ok && lane == 0) ctl->fact_ok = 0;
-        double* dst = LinvK + ccol * TP + crow;
+        lds_double* dst = LinvK + ccol * TP + crow;
 #pragma unroll
         for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
         *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
         __builtin_amdgcn_s_setprio(0);
-        if (crow + 0 < SFT_BORDER) Abord[(crow + 0) * TS + ccol] = bacc[0];
-        if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[1];
-      } else {
-        // publish tile (I, kc) of block column kc
-        v4d t = acc[0];
-        switch (kc & (BT - 1)) {
-          case 1: t = acc[1]; break; case 2: t = acc[2]; break; case 3: t = acc[3]; break; case 4: t = acc[4]; break;
-          case 5: t = acc[5]; break; case 6: t = acc[6]; break; case 7: t = acc[7]; break; default: break;
-        }
-        double* dst = Araw + (I - kc) * TILE_LDS + ccol * TP + crow;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dst[4 * q] = t[q];
-      }
-      if (wave == BT - 1) {
-        double* dst = Araw + BT * TILE_LDS + ccol * TP + crow;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dst[4 * q] = fr8[q];
-        fr8 = fresh_tile(kc + 1 + BT, kc + 1);
       }
     }
-    if (k >= 0 && !(mode & 16) && !(mode & 32)) {
-      if (k + wave + 1 < nT) *reinterpret_cast<v4d*>(Lg + tile_off(k + wave + 1, wave + 1) + 4 * lane) = x_keep;
-      if (wave < SFT_BORDER && lane < TS) Lbord[(size_t)wave * Dnp + TS * k + lane] = xb_keep;
+    if (k >= 0) {
+      // rest of the window (columns kc+1 ..), remaining border tiles, corner
+      bool more = false;    // does any ring row of this wave reach beyond block column kc?
+#pragma unroll
+      for (int t = 0; t < RPW; t++) more = more || (I[t] < nT && I[t] > kc);
+      if constexpr (RPW > 1) {   // two ring rows per wave: registers are scarce across the factorisation, re-read the operands
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+          for (int t = 0; t < RPW; t++) an[t][kk] = -Xp[(I[t] - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+          bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];
+        }
+      }
+      if (more && !(mode & 4)) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          // one batch of LDS reads per k-chunk (a single wait), then MFMAs on independent accumulators back to back
+          double bb[BT];
+#pragma unroll
+          for (int b = 0; b < BT; b++) bb[b] = Xp[(kc + ((b - kc) & (BT - 1)) - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+#pragma unroll
+          for (int b = 0; b < BT; b++) {
+            const int J = kc + ((b - kc) & (BT - 1));
+#pragma unroll
+            for (int t = 0; t < RPW; t++)
+              if (I[t] < nT && J <= I[t] && J != kc) acc[t][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][kk], bb[b], acc[t][b], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < RPW; t++) {
+        const int Jb = kc + ((wave + NW * t + BOFF - kc) & (BT - 1));   // global tile column of this border tile
+        if (Jb != kc) {
+          double bbord[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) bbord[kk] = Xp[(Jb - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) bacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bbord[kk], bacc[t], 0, 0, 0);
+        }
+      }
+      if (wave == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
+      }
+    }
+    if (memwave && k >= 0 && !(mode & 16) && !(mode & 32)) {
+      // block column k of L goes to global memory from the LDS panel (native tile layout), border rows included
+#pragma unroll
+      for (int i = 1; i <= BT; i++)
+        if (k + i < nT) {
+          const lds_double* src = Xp + i * TILE_LDS + ccol * TP + crow;
+          v4d x;
+#pragma unroll
+          for (int q = 0; q < 4; q++) x[q] = src[4 * q];
+          *reinterpret_cast<v4d*>(Lg + tile_off(k + i, i) + 4 * lane) = x;
+        }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int e = lane + 64 * h, r = e >> 4, j = e & 15;
+        if (r < SFT_BORDER) Lbord[(size_t)r * Dnp + TS * k + j] = Xp[j * TP + r];
+      }
     }
     ST_MARK(6);
     lds_barrier();
@@ -1015,34 +1200,40 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
 }
 
 // Back substitution in tile mode: x_J = Linv_J^T (y_J - sum_{I>J} X_{I,J}^T x_I - Lcn_J^T x_cam).
-// Wave w forms the partial product of tile (J+w+1, J); wave 0 finishes the block.  The tiles of block J-1 are
-// prefetched while block J is processed (LDS-only barriers keep the loads in flight).
+// Wave w forms the partial products of tiles (J+d, J), d = w+1+NW*t; wave 0 finishes the block.  The tiles of block J-1
+// are prefetched while block J is processed (LDS-only barriers keep the loads in flight).
+template <int NW>
 __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws) {
+  constexpr int RPW = BT / NW;
   if (!ctl->fact_ok) return;   // like g2o, x keeps its previous content when the factorisation failed
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps ring bookkeeping and branches on the scalar unit
+  const int Dnp = ((uni(P.Dn) + NB - 1) / NB) * NB;
   const int nT = Dnp / TS;
-  double* xw = ws;                 // ring of BT x-tiles
-  double* part = xw + TS * BT;     // (BT+1) partial vectors
+  lds_double* xw = to_lds(ws);                // ring of BT x-tiles
+  lds_double* part = xw + TS * BT;     // (BT+1) partial vectors
   const int crow = lane >> 4, ccol = lane & 15;
   const double xc = (lane < 6) ? P.x[Dnp + lane] : 0.0;
   double xcr[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) xcr[r] = bcast_lane(xc, r);
-  const double* Lg = P.Lb;
-  const double* Lbord = P.Lbord;
-  const double* Linv_g = P.Linv;
-  double* xg = P.x;
-  const int d = wave + 1;
-  struct Pre { v4d t, li; double y, b[6]; };
+  const auto Lg = uni(P.Lb);
+  const auto Lbord = uni(P.Lbord);
+  const auto Linv_g = uni(P.Linv);
+  const auto xg = uni(P.x);
+  struct Pre { v4d t[RPW], li; double y, b[6]; };
   auto fetch = [&](int J) -> Pre {
     Pre p;
-    p.t = (v4d){0.0, 0.0, 0.0, 0.0}; p.li = p.t; p.y = 0.0;
+    p.li = (v4d){0.0, 0.0, 0.0, 0.0}; p.y = 0.0;
+#pragma unroll
+    for (int t = 0; t < RPW; t++) p.t[t] = p.li;
 #pragma unroll
     for (int r = 0; r < 6; r++) p.b[r] = 0.0;
     if (J < 0) return p;
-    if (J + d < nT) {
-      p.t = *reinterpret_cast<const v4d*>(Lg + tile_off(J + d, d) + 4 * lane);
+#pragma unroll
+    for (int t = 0; t < RPW; t++) {
+      const int d = wave + 1 + NW * t;
+      if (J + d < nT) p.t[t] = *reinterpret_cast<const v4d*>(Lg + tile_off(J + d, d) + 4 * lane);
     }
     if (wave == 0) {
       p.li = *reinterpret_cast<const v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
@@ -1057,13 +1248,15 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 #pragma unroll 1
   for (int J = nT - 1; J >= 0; J--) {
     const Pre nxt = fetch(J - 1);
-    {
+#pragma unroll
+    for (int t = 0; t < RPW; t++) {
+      const int d = wave + 1 + NW * t;
       const int I = J + d;
       double p = 0.0;
       if (I < nT) {
-        const double* xi = xw + (I & (BT - 1)) * TS + crow;
+        const lds_double* xi = xw + (I & (BT - 1)) * TS + crow;
 #pragma unroll
-        for (int q = 0; q < 4; q++) p = fma(cur.t[q], xi[4 * q], p);
+        for (int q = 0; q < 4; q++) p = fma(cur.t[t][q], xi[4 * q], p);
         p += __shfl_xor(p, 16, 64);
         p += __shfl_xor(p, 32, 64);
       }
@@ -1097,7 +1290,9 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 // ------------------------------------------------------------------------------------------
 // The persistent per-problem kernel
 // ------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev* __restrict__ probs) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void sft_lm_kernel(const SftDev* __restrict__ probs) {
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const SftDev& P = probs[blockIdx.x];
   Ctl* ctl = reinterpret_cast<Ctl*>(smem);
@@ -1110,24 +1305,24 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
 
   // ---- initial state, zeroed system with identity padding --------------------------------
-  for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz[i] = P.xyz_init[i];
+  for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
   if (P.tile_mode) {
-    const size_t nel = (size_t)(Dnp / TS) * (BT + 1) * TS * TS;
-    for (size_t i = tid; i < nel; i += SFT_NT) {
+    const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * (BT + 1) * TS * TS;   // incl. the zero tile rows below the matrix
+    for (size_t i = tid; i < nel; i += NT) {
       const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % (BT + 1)), I = (int)(i / ((size_t)(BT + 1) * TS * TS));
       const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
-      const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn;
+      const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn && I < Dnp / TS;
       P.Hb[i] = pad_diag ? 1.0 : 0.0;
     }
   } else {
-    for (size_t i = tid; i < (size_t)Dnp * ldh; i += SFT_NT) {
+    for (size_t i = tid; i < (size_t)Dnp * ldh; i += NT) {
       const int k = (int)(i % ldh), r = (int)(i / ldh);
       P.Hb[i] = (k == kd && r >= Dn) ? 1.0 : 0.0;
     }
   }
-  for (size_t i = tid; i < (size_t)SFT_BORDER * Dnp; i += SFT_NT) P.Hbord[i] = 0.0;
-  for (int i = tid; i < Dnp + 6; i += SFT_NT) P.x[i] = 0.0;
+  for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
+  for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
   if (tid == 0) {
     ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
     P.info[0] = 0; P.info[1] = 0; P.info[2] = 0;
@@ -1151,7 +1346,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
     PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
-      for (int r = tid; r < Dn; r += SFT_NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
+      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
       if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
       mx = block_max(mx, red);
       if (tid == 0) { ctl->lambda = 1e-5 * mx; ctl->ni = 2.0; ctl->nbad = 0; }
@@ -1163,22 +1358,22 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
     bool again;
     do {
       // push
-      for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz_bak[i] = P.xyz[i];
+      for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];
       double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
       PH_ADD(7);
       if (P.tile_mode) {
-        factor_tiles(P, ctl, panel);
+        factor_tiles<NW>(P, ctl, panel);
         PH_RESET();
-        backsub_tiles(P, ctl, panel);
+        backsub_tiles<NW>(P, ctl, panel);
         PH_ADD(6);
       } else {
-        factor_and_solve(P, ctl, panel, red);
+        if constexpr (NW == 8) factor_and_solve(P, ctl, panel, red);   // band mode always runs the 512-thread kernel
       }
       PH_RESET();
       const int ok = ctl->fact_ok;
       all_ok &= ok;
       // update
-      for (int i = tid; i < 3 * P.n; i += SFT_NT) {
+      for (int i = tid; i < 3 * P.n; i += NT) {
         const int a = P.act[i / 3];
         if (a >= 0) P.xyz[i] += P.x[3 * a + (i % 3)];
       }
@@ -1186,7 +1381,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
       // scale = sum_j x_j (lambda x_j + b_j)
       double sc = 0.0;
       const double lam = ctl->lambda;
-      for (int r = tid; r < Dn; r += SFT_NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
+      for (int r = tid; r < Dn; r += NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
       if (tid < 6) { const double xv = P.x[Dnp + tid]; sc += xv * (lam * xv + P.Hcorner[42 + tid]); }
       __syncthreads();
       block_sum<1>(&sc, red, out);
@@ -1214,7 +1409,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
       }
       __syncthreads();
       if (ctl->stop) {  // pop
-        for (int i = tid; i < 3 * P.n; i += SFT_NT) P.xyz[i] = P.xyz_bak[i];
+        for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
         if (tid < 7) P.pose[tid] = pose_bak;
       }
       again = (ctl->rho < 0) && (ctl->qmax < 10);
@@ -1243,7 +1438,7 @@ extern "C" __global__ __launch_bounds__(SFT_NT) void sft_lm_kernel(const SftDev*
   // final reprojection error norms at the final estimate (DefOptimizer.cc:538-559)
   if (tid == 0) { quat_to_R(P.pose + 3, ctl->R); ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2]; }
   __syncthreads();
-  for (int m = tid; m < P.M; m += SFT_NT) {
+  for (int m = tid; m < P.M; m += NT) {
     const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
     const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
     double pw[3], pc[3];
@@ -1265,20 +1460,28 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
   const size_t backsub = NB + (SFT_NT / NB) * NB + NB * NB;
   if (backsub > panel) panel = backsub;
-  const size_t tiles = (size_t)(2 * (BT + 1) + 1) * TILE_LDS + SFT_BORDER * TS + 64 + 3072;  // + room for the step-trace stamps
+  const size_t tiles = (size_t)(2 * (BT + 1) + 1) * TILE_LDS + SFT_BORDER * TS + 64 + 128;  // + room for the step-trace stamps
   if (kd <= TS * BT) panel = tiles;
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
 
-extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, hipStream_t stream) {
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
   const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t configured[2] = {0, 0};
+  const int slot = nw == 4 ? 0 : 1;
+  if (lds > configured[slot]) {
+    const void* fn = nw == 4 ? reinterpret_cast<const void*>(sft_lm_kernel<4>) : reinterpret_cast<const void*>(sft_lm_kernel<8>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
+    configured[slot] = lds;
+    if (std::getenv("DSH_SFT_VERBOSE")) {
+      int nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * nw, lds);
+      std::fprintf(stderr, "[defslam_hip] sft_lm_kernel<%d>: %zu B LDS per workgroup, %d resident workgroups per CU\n", nw, lds, nb);
+    }
   }
-  hipLaunchKernelGGL(sft_lm_kernel, dim3(B), dim3(SFT_NT), lds, stream, d_probs);
+  if (nw == 4) hipLaunchKernelGGL(sft_lm_kernel<4>, dim3(B), dim3(256), lds, stream, d_probs);
+  else hipLaunchKernelGGL(sft_lm_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs);
   return hipGetLastError();
 }

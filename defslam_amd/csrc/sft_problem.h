@@ -12,9 +12,12 @@
 #pragma once
 #include <stdint.h>
 
-#define SFT_NT 512             // threads of the per-problem workgroup (8 wavefronts: 2 per SIMD, 256-VGPR budget)
+#define SFT_NT 512             // threads of the band-mode workgroup / upper bound of the tile-mode one (8 wavefronts)
 #define SFT_JOBS_STRIDE 36     // doubles per observation Jacobian record
 #define SFT_BORDER 7           // 6 camera rows + the right-hand side carried through the factorisation
+// tile mode keeps zero padding around H so that the sliding window loads every tile unconditionally:
+#define SFT_H_PAD_TILE_ROWS 9  // zero tile rows below the band matrix (window height BT + the look-ahead tile)
+#define SFT_H_PAD_BORDER 160   // doubles after the 8th (zero) border row: one window of tile columns
 
 // contribution record: kind(2) | slot_row(4) | slot_col(4) | edge(22)
 #define SFT_KIND_OBS 0u
@@ -23,6 +26,15 @@
 #define SFT_KIND_STR 3u
 #define SFT_REC(kind, s, t, e) (((uint32_t)(kind) << 30) | ((uint32_t)(s) << 26) | ((uint32_t)(t) << 22) | (uint32_t)(e))
 
+// Every pointer below addresses global (HBM) memory.  Saying so in the device pass makes the compiler emit global_*
+// instead of flat_* memory instructions: flat loads count on the LDS counter too, so every LDS wait would also wait
+// for all outstanding HBM traffic.  The host pass sees plain pointers; the layout is identical.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SFT_KERNEL_SOURCE)   // sft_kernels.hip only; host sources see plain pointers
+#define SFT_G __attribute__((address_space(1)))
+#else
+#define SFT_G
+#endif
+
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
@@ -30,54 +42,54 @@ struct SftDev {
   double fx, fy, cx, cy;
   double w_ref, w_curv, w_str, hub_delta, hub_dsqr;
   // template (shared by every problem of a batch)
-  const double* xyz0;
-  const int32_t* nbr_ptr;
-  const int32_t* nbr_idx;
-  const double* nbr_w;
-  const double* nbr_c;      // -(w_j / sum_j w_j)
-  const double* nbr_sumw;   // per node
-  const double* k0;
+  const SFT_G double* xyz0;
+  const SFT_G int32_t* nbr_ptr;
+  const SFT_G int32_t* nbr_idx;
+  const SFT_G double* nbr_w;
+  const SFT_G double* nbr_c;      // -(w_j / sum_j w_j)
+  const SFT_G double* nbr_sumw;   // per node
+  const SFT_G double* k0;
   // frame / graph
-  const int32_t* act;       // n: compact index or -1
-  const int32_t* obs_nodes; // M*3
-  const double* obs_bary;   // M*3
-  const double* obs_uv;     // M*2
-  const double* obs_w;      // M  invSigma2 / N_frame
-  const int32_t* ref_node;  // V
-  const int32_t* star_node; // S
-  const double* star_sL;    // S  sum over incident mesh edges of 1/L^2
-  const int32_t* str_nodes; // Es*2
-  const double* str_L0;     // Es
-  const int32_t* blk_rc;    // nblk*2 (block row, block col), lower, sorted
-  const int32_t* blk_ptr;   // nblk+1
-  const int32_t* diag_blk;  // nA: block index of every diagonal block
-  const int32_t* off_blk;   // nblk-nA: block indices of the off-diagonal blocks
-  const uint32_t* contrib;
+  const SFT_G int32_t* act;       // n: compact index or -1
+  const SFT_G int32_t* obs_nodes; // M*3
+  const SFT_G double* obs_bary;   // M*3
+  const SFT_G double* obs_uv;     // M*2
+  const SFT_G double* obs_w;      // M  invSigma2 / N_frame
+  const SFT_G int32_t* ref_node;  // V
+  const SFT_G int32_t* star_node; // S
+  const SFT_G double* star_sL;    // S  sum over incident mesh edges of 1/L^2
+  const SFT_G int32_t* str_nodes; // Es*2
+  const SFT_G double* str_L0;     // Es
+  const SFT_G int32_t* blk_rc;    // nblk*2 (block row, block col), lower, sorted
+  const SFT_G int32_t* blk_ptr;   // nblk+1
+  const SFT_G int32_t* diag_blk;  // nA: block index of every diagonal block
+  const SFT_G int32_t* off_blk;   // nblk-nA: block indices of the off-diagonal blocks
+  const SFT_G uint32_t* contrib;
   // initial state (restored at the start of every run)
-  const double* xyz_init;   // n*3
-  const double* pose_init;  // 7: t, q(x,y,z,w)
+  const SFT_G double* xyz_init;   // n*3
+  const SFT_G double* pose_init;  // 7: t, q(x,y,z,w)
   // state + workspace
-  double* xyz;              // n*3
-  double* xyz_bak;          // n*3
-  double* pose;             // 7
-  double* Jobs;             // M*SFT_JOBS_STRIDE
-  double* Jstar;            // S*4  (u, r)
-  double* Jstr;             // Es*4 (g, e)
-  double* Jref;             // V*4  (e)
-  double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
+  SFT_G double* xyz;              // n*3
+  SFT_G double* xyz_bak;          // n*3
+  SFT_G double* pose;             // 7
+  SFT_G double* Jobs;             // M*SFT_JOBS_STRIDE
+  SFT_G double* Jstar;            // S*4  (u, r)
+  SFT_G double* Jstr;             // Es*4 (g, e)
+  SFT_G double* Jref;             // V*4  (e)
+  SFT_G double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
                             // tile mode: nT*(BT+1) 16x16 tiles, tile (I,J) at (I*(BT+1) + I-J)*256, element (row,col) at
                             //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register)
-  double* Hbord;            // 7*Dn     rows 0-5: camera x node, row 6: b_node
-  double* Hcorner;          // 7*7      camera x camera (lower) + b_cam in row 6
-  double* Lb;               // Dn*ldh
-  double* Lbord;            // 7*Dn
-  double* Lcorner;          // 7*7
-  double* Linv;             // tile mode: nT inverse diagonal tiles (16x16 row-major)
-  double* x;                // Dn+6
+  SFT_G double* Hbord;            // 7*Dn     rows 0-5: camera x node, row 6: b_node
+  SFT_G double* Hcorner;          // 7*7      camera x camera (lower) + b_cam in row 6
+  SFT_G double* Lb;               // Dn*ldh
+  SFT_G double* Lbord;            // 7*Dn
+  SFT_G double* Lcorner;          // 7*7
+  SFT_G double* Linv;             // tile mode: nT inverse diagonal tiles (16x16 row-major)
+  SFT_G double* x;                // Dn+6
   // outputs
-  double* chi2_obs;         // M
-  double* final_err;        // M  reprojection error norm at the final estimate
-  double* trace;            // max_iters*8
-  int32_t* info;            // [0] iters [1] trials [2] status
-  double* dbg;              // [0] robust chi2 of the debug assembly
+  SFT_G double* chi2_obs;         // M
+  SFT_G double* final_err;        // M  reprojection error norm at the final estimate
+  SFT_G double* trace;            // max_iters*8
+  SFT_G int32_t* info;            // [0] iters [1] trials [2] status
+  SFT_G double* dbg;              // [0] robust chi2 of the debug assembly
 };

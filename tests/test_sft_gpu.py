@@ -150,6 +150,33 @@ def test_batch_equals_single_and_is_reproducible(gpu_ctx):
         np.testing.assert_array_equal(f1.pose7, frames[p].pose7)
 
 
+@pytest.mark.parametrize("cfg,pid", [("smoke", 3), ("C2", 5)])
+def test_four_wavefront_launch_shape_matches_eight(gpu_ctx, oracle_mod, cfg, pid, monkeypatch):
+    """The throughput launch shape (4 wavefronts per problem, two ring rows per wave, chosen by the library once a batch
+    holds >= 2 problems per CU) runs the same factorisation as the latency shape: same LM trajectory as the oracle,
+    vertices equal to the 8-wavefront result to rounding."""
+    from defslam_amd import sft, synth
+    tmpl, fr = synth.make_problem(cfg, pid)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    out = {}
+    for nw in ("8", "4"):
+        monkeypatch.setenv("DSH_SFT_WAVES", nw)     # read by dsh_sft_batch_upload
+        f = sft.frame_from_synth(fr)
+        inl = sft.DefPoseOptimization(gpu_ctx, f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        out[nw] = (f, inl)
+    monkeypatch.delenv("DSH_SFT_WAVES")
+    f8, i8 = out["8"]
+    f4, i4 = out["4"]
+    assert i4 == i8 and f4.iters == f8.iters and f4.trials == f8.trials
+    np.testing.assert_array_equal(f4.mvbOutlier, f8.mvbOutlier)
+    assert np.abs(f4.nodes_xyz - f8.nodes_xyz).max() < 1e-10 * np.abs(f8.nodes_xyz).max()
+    np.testing.assert_allclose(f4.trace, f8.trace, rtol=1e-8, atol=1e-12)
+    tc, args = oracle_args(oracle_mod, tmpl, fr)
+    r = oracle_mod.sft_solve(*args, ldlt_mode=1)
+    assert f4.iters == r.iters
+    assert np.abs(f4.nodes_xyz - r.xyz).max() < 1e-9 * np.abs(r.xyz).max()
+
+
 def test_mappoint_writeback_float32(gpu_ctx):
     from defslam_amd import sft, synth
     tmpl, fr = synth.make_problem("smoke", 2)
