@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="independent problems per GPU per step (256 = one per CU)")
+    ap.add_argument("--batch", type=int, default=2048, help="independent problems per GPU per step (2048 = 8 per CU: the launch tail of the slowest problems amortises)")
     ap.add_argument("--config", default="C2", choices=["smoke", "C2", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -100,8 +100,9 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     iters, trials = ctx.batch_counts()              # per step (every step restarts from the uploaded state)
-    alg_bytes = sum(ctx.problem_info(b)[0] for b in range(args.batch))
-    _, counts = ctx.problem_info(0)
+    infos = [ctx.problem_info(b) for b in range(args.batch)]
+    alg_bytes = sum(i[0] for i in infos)
+    _, counts = infos[0]
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     tot = torch.tensor([iters, trials, args.batch], dtype=torch.float64, device="cuda")
@@ -124,29 +125,36 @@ def main():
         ms_per_step = 1e3 * wall / args.steps
         value = g_iters * args.steps / wall
         kern_ms = kernel_ms / args.steps            # avg duration of the persistent kernel (rank 0)
-        # roofline of the dominant (only) kernel: algorithmic assembly bytes per launch (per-iteration
-        # figure x iterations the launch executes) over its measured duration
+        # The one persistent kernel is ~70% banded-arrowhead Cholesky (FP64 MFMA) and ~15% assembly (HBM-bound in principle,
+        # SURVEY 8d "state both fractions").  roofline = the dominant part: algorithmic solve flops per launch
+        # (SURVEY 8d block-banded convention D*beta^2, with the half-bandwidth this ordering actually has, plus the 7 border
+        # rows and the two triangular solves; padding and zero tiles the MFMAs also execute are NOT counted) over the kernel time.
+        Dn, kd = int(counts[5]) - 6, int(counts[6])
+        flops_trial = Dn * kd * kd + 2 * 7 * Dn * kd + 4 * Dn * kd + 4 * 7 * Dn
+        flops_per_launch = flops_trial * (trials / 1.0)
+        achieved_tf = flops_per_launch / (kern_ms * 1e-3) / 1e12
+        # assembly: algorithmic bytes per launch (SURVEY 8d per-iteration figure x iterations the launch executes)
         bytes_per_launch = (alg_bytes / args.batch) * iters
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-        # solve-inclusive algorithmic stream of the tile-mode factorisation: H tiles read once, L written once and read once per trial
-        Dn = int(counts[5]) - 6
-        nT = ((Dn + 31) // 32) * 2
-        solver_bytes = trials * (3 * nT * 9 * 2048 + 2 * nT * 2048 + 3 * 7 * 16 * nT * 8)
+        hbm_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "SfT GN iters/sec (500-node mesh, 1k matches)", "value": value, "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: single-frame SfT, {rows * cols}-node template ({rows}x{cols}), {m} matches, 640x480",
                        "problems_per_gpu": args.batch, "parallelism": f"{world} x independent problems (no collective)",
-                       "max_lm_iters": 50, "regularisers": [synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP]},
+                       "max_lm_iters": 50, "regularisers": [synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP],
+                       "wavefronts_per_problem": int(counts[7])},
             "frames_per_s": g_problems * args.steps / wall,
             "lm_trials_per_s": g_trials * args.steps / wall,
             "iters_per_frame": g_iters / g_problems,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel": "sft_lm_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "solver_stream_GBps": (bytes_per_launch + solver_bytes) / (kern_ms * 1e-3) / 1e9,
-                         "note": "persistent kernel = residuals + Jacobian assembly + banded Cholesky + LM control; bytes count assembly only (SURVEY 8d)"},
+                         "algorithmic_flops_per_launch": flops_per_launch, "flops_per_lm_trial": flops_trial, "dim": Dn + 6, "half_bandwidth": kd,
+                         "hbm_assembly": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                                          "measured_traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None},
+                         "note": "one persistent kernel = residuals + Jacobian assembly + banded-arrowhead Cholesky (FP64 MFMA) + LM control; "
+                                 "frac = algorithmic solve flops / FP64 peak over the WHOLE kernel time; hbm_assembly = SURVEY 8d assembly bytes over the same time"},
         }
         # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
         ctx.batch_upload(frames[:1], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)

@@ -120,7 +120,8 @@ int dsh_sft_batch_phase_ms(dsh_ctx* ctx, int b, double* out8);
 /* Totals of the last completed run (valid after a synchronise): outer iterations and trials over the batch. */
 int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
 /* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts
- * counts[6] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim. */
+ * counts[8] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim,
+ * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload. */
 int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int32_t* counts);
 
 /* Test hook: run only "residuals + Jacobians + normal equations" once at the uploaded state of
