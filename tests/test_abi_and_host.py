@@ -123,7 +123,8 @@ def test_packer_counts_and_algorithmic_bytes(host_ctx, oracle_mod):
     r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz,
                              synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, max_iters=0)
     D, nopt, nview, ncurv, nstr, _ = r.dims
-    assert list(counts) == [1000, nopt, ncurv, nstr, nview, D]
+    assert list(counts[:6]) == [1000, nopt, ncurv, nstr, nview, D]
+    assert 0 < counts[6] <= 128 and counts[7] == 8     # half-bandwidth of the node block (tile mode), latency launch shape for one problem
     M, n, Cc, E, V = 1000, 500, int(ncurv), int(nstr), int(nview)
     expect = (60 * M + 24 * n + 88 + 92 * Cc + 16 * E + 28 * V) + 8 * (30 * M + 21 * Cc + 6 * E + 9 * V) + 8 * (2 * M + Cc + E + 3 * V) + 8 * M
     assert nbytes == expect
