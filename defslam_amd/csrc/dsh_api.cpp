@@ -352,6 +352,7 @@ int dsh_destroy(dsh_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (c->d_tmpl) (void)hipFree(c->d_tmpl);
+  c->scratch.release();
   if (c->d_batch) (void)hipFree(c->d_batch);
   delete c;
   return DSH_OK;

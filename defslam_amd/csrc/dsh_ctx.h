@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "dsh_template.h"
@@ -12,7 +13,41 @@ namespace dsh {
 struct PackedSft;   // defined in dsh_api.cpp
 }
 
+// Grow-only device scratch of a context: the one-shot calls (BBS, normals, Schwarp) carve their temporaries out of it
+// instead of paying a dozen hipMalloc/hipFree per call.  reset() at the start of a call, release() in dsh_destroy.
+// A context serves one host thread at a time (it also owns one stream).
+struct dsh_scratch {
+  std::vector<std::pair<char*, size_t>> chunks;
+  size_t chunk = 0, off = 0;
+  void reset() { chunk = 0; off = 0; }
+  hipError_t take(size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (; chunk < chunks.size(); chunk++, off = 0)
+      if (off + bytes <= chunks[chunk].second) {
+        *out = chunks[chunk].first + off;
+        off += bytes;
+        return hipSuccess;
+      }
+    const size_t cap = bytes > ((size_t)8 << 20) ? bytes : ((size_t)8 << 20);
+    char* p = nullptr;
+    const hipError_t e = hipMalloc((void**)&p, cap);
+    if (e != hipSuccess) return e;
+    chunks.emplace_back(p, cap);
+    chunk = chunks.size() - 1;
+    *out = p;
+    off = bytes;
+    return hipSuccess;
+  }
+  void release() {
+    for (auto& c : chunks) (void)hipFree(c.first);
+    chunks.clear();
+    reset();
+  }
+};
+
 struct dsh_ctx_base {
+  dsh_scratch scratch;
   int device = 0;
   bool host_only = false;   // device == -1: template + packer only (CPU tests of the host logic)
   hipStream_t stream = nullptr;

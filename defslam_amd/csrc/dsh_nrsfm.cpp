@@ -25,10 +25,9 @@ namespace {
   } while (0)
 
 // scoped device buffer
-struct DevBuf {
+struct DevBuf {   // a slice of the context's scratch (dsh_ctx.h); nothing to free
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  hipError_t alloc(dsh_ctx_base* c, size_t bytes) { return c->scratch.take(bytes, &p); }
   template <class T> T* as() { return static_cast<T*>(p); }
 };
 
@@ -36,6 +35,7 @@ int gpu_ready(dsh_ctx_base* c, const char* who) {
   if (!c) return DSH_ERR_ARG;
   if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, std::string(who) + ": host-only context, no GPU (there is no CPU fallback)");
   if (hipSetDevice(c->device) != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, std::string(who) + ": hipSetDevice failed");
+  c->scratch.reset();   // temporaries of this call come out of the context's scratch
   return DSH_OK;
 }
 
@@ -53,8 +53,8 @@ int dsh_bbs_eval(dsh_ctx* ctx, const dsh_bbs* bbs, const double* ctrl, const dou
   if (n == 0) return DSH_OK;
   const size_t nctrl = (size_t)bbs->valdim * bbs->nptsu * bbs->nptsv;
   DevBuf dctrl, du_, dv_, dval, dout;
-  HIPCHK(c, dctrl.alloc(8 * nctrl)); HIPCHK(c, du_.alloc(8 * (size_t)n)); HIPCHK(c, dv_.alloc(8 * (size_t)n));
-  HIPCHK(c, dval.alloc(8 * (size_t)n * bbs->valdim)); HIPCHK(c, dout.alloc(n));
+  HIPCHK(c, dctrl.alloc(c, 8 * nctrl)); HIPCHK(c, du_.alloc(c, 8 * (size_t)n)); HIPCHK(c, dv_.alloc(c, 8 * (size_t)n));
+  HIPCHK(c, dval.alloc(c, 8 * (size_t)n * bbs->valdim)); HIPCHK(c, dout.alloc(c, n));
   HIPCHK(c, hipMemcpyAsync(dctrl.p, ctrl, 8 * nctrl, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(du_.p, u, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dv_.p, v, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -74,8 +74,8 @@ int dsh_bbs_coloc(dsh_ctx* ctx, const dsh_bbs* bbs, const double* u, const doubl
   if (n_outside) *n_outside = 0;
   if (n == 0) return DSH_OK;
   DevBuf du_, dv_, dcols, dw, dcnt;
-  HIPCHK(c, du_.alloc(8 * (size_t)n)); HIPCHK(c, dv_.alloc(8 * (size_t)n)); HIPCHK(c, dcols.alloc(4 * 16 * (size_t)n)); HIPCHK(c, dw.alloc(8 * 16 * (size_t)n));
-  HIPCHK(c, dcnt.alloc(4));
+  HIPCHK(c, du_.alloc(c, 8 * (size_t)n)); HIPCHK(c, dv_.alloc(c, 8 * (size_t)n)); HIPCHK(c, dcols.alloc(c, 4 * 16 * (size_t)n)); HIPCHK(c, dw.alloc(c, 8 * 16 * (size_t)n));
+  HIPCHK(c, dcnt.alloc(c, 4));
   HIPCHK(c, hipMemcpyAsync(du_.p, u, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dv_.p, v, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(dcnt.p, 0, 4, c->stream));
@@ -115,10 +115,10 @@ int dsh_normals_estimate(dsh_ctx* ctx, int P, const int32_t* rec_ptr, const dsh_
   }
   DevBuf d_ptr, d_owner, d_rec, d_isref, d_fn, d_hfn, d_x0, d_hx0, d_uv, d_Q, d_k, d_cov, d_st, d_nref, d_nrec, d_wr, d_it;
   const size_t Rn = R > 0 ? R : 1;
-  HIPCHK(c, d_ptr.alloc(4 * (size_t)(P + 1))); HIPCHK(c, d_owner.alloc(4 * Rn)); HIPCHK(c, d_rec.alloc(4 * NF * Rn)); HIPCHK(c, d_isref.alloc(Rn));
-  HIPCHK(c, d_fn.alloc(8 * Rn)); HIPCHK(c, d_hfn.alloc(Rn)); HIPCHK(c, d_x0.alloc(8 * (size_t)P)); HIPCHK(c, d_hx0.alloc(P)); HIPCHK(c, d_uv.alloc(8 * (size_t)P));
-  HIPCHK(c, d_Q.alloc(8 * 20 * Rn)); HIPCHK(c, d_k.alloc(16 * (size_t)P)); HIPCHK(c, d_cov.alloc(32 * (size_t)P)); HIPCHK(c, d_st.alloc(4 * (size_t)P));
-  HIPCHK(c, d_nref.alloc(12 * (size_t)P)); HIPCHK(c, d_nrec.alloc(12 * Rn)); HIPCHK(c, d_wr.alloc(Rn)); HIPCHK(c, d_it.alloc(4 * (size_t)P));
+  HIPCHK(c, d_ptr.alloc(c, 4 * (size_t)(P + 1))); HIPCHK(c, d_owner.alloc(c, 4 * Rn)); HIPCHK(c, d_rec.alloc(c, 4 * NF * Rn)); HIPCHK(c, d_isref.alloc(c, Rn));
+  HIPCHK(c, d_fn.alloc(c, 8 * Rn)); HIPCHK(c, d_hfn.alloc(c, Rn)); HIPCHK(c, d_x0.alloc(c, 8 * (size_t)P)); HIPCHK(c, d_hx0.alloc(c, P)); HIPCHK(c, d_uv.alloc(c, 8 * (size_t)P));
+  HIPCHK(c, d_Q.alloc(c, 8 * 20 * Rn)); HIPCHK(c, d_k.alloc(c, 16 * (size_t)P)); HIPCHK(c, d_cov.alloc(c, 32 * (size_t)P)); HIPCHK(c, d_st.alloc(c, 4 * (size_t)P));
+  HIPCHK(c, d_nref.alloc(c, 12 * (size_t)P)); HIPCHK(c, d_nrec.alloc(c, 12 * Rn)); HIPCHK(c, d_wr.alloc(c, Rn)); HIPCHK(c, d_it.alloc(c, 4 * (size_t)P));
   hipStream_t st = c->stream;
   HIPCHK(c, hipMemcpyAsync(d_ptr.p, rec_ptr, 4 * (size_t)(P + 1), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_x0.p, x0, 8 * (size_t)P, hipMemcpyHostToDevice, st));

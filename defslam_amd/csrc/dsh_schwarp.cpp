@@ -16,7 +16,8 @@ extern "C" hipError_t nrsfm_swp_eval(double, double, int, double, double, int, i
 extern "C" hipError_t nrsfm_swp_loss(int, int, const double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_normal(int, int, int, double*, double*, const double*, const double*, double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_colscale(int, const double*, double*, hipStream_t);
-extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, hipStream_t);
+extern "C" int nrsfm_swp_solve_np(int);
 extern "C" hipError_t nrsfm_swp_step(int, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_diffprop(double, double, int, double, double, int, int, const float*, const float*, const double*, float, float, float*,
                                          uint8_t*, hipStream_t);
@@ -28,10 +29,9 @@ namespace {
     if (e__ != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
-struct DevBuf {
+struct DevBuf {   // a slice of the context's scratch (dsh_ctx.h); nothing to free
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  hipError_t alloc(dsh_ctx_base* c, size_t bytes) { return c->scratch.take(bytes, &p); }
   template <class T> T* as() { return static_cast<T*>(p); }
 };
 
@@ -40,7 +40,7 @@ struct Fit {
   const dsh_bbs* b;
   int P, N, n2, m;
   double fxs, fys, lambda;
-  DevBuf kp1, kp2, isg, x, xn, cs, g, dx, r, J, A, M, scal;
+  DevBuf kp1, kp2, isg, x, xn, cs, g, dx, r, J, A, M, W, scal;
   hipStream_t st;
 
   int eval(const double* xdev, bool with_j) {
@@ -61,10 +61,15 @@ int setup(Fit& f, dsh_ctx_base* c, const dsh_bbs* bbs, int P, const float* kp1, 
           const double* x) {
   f.c = c; f.b = bbs; f.P = P; f.N = bbs->nptsu * bbs->nptsv; f.n2 = 2 * f.N; f.m = 2 * P + 4 * f.N;
   f.fxs = fxs; f.fys = fys; f.lambda = lambda; f.st = c->stream;
-  HIPCHK(c, f.kp1.alloc(8 * (size_t)P)); HIPCHK(c, f.kp2.alloc(8 * (size_t)P)); HIPCHK(c, f.isg.alloc(4 * (size_t)P));
-  HIPCHK(c, f.x.alloc(8 * (size_t)f.n2)); HIPCHK(c, f.xn.alloc(8 * (size_t)f.n2)); HIPCHK(c, f.cs.alloc(8 * (size_t)f.n2)); HIPCHK(c, f.g.alloc(8 * (size_t)f.n2));
-  HIPCHK(c, f.dx.alloc(8 * (size_t)f.n2)); HIPCHK(c, f.r.alloc(8 * (size_t)f.m)); HIPCHK(c, f.J.alloc(8 * (size_t)f.m * f.n2));
-  HIPCHK(c, f.A.alloc(8 * (size_t)f.n2 * f.n2)); HIPCHK(c, f.M.alloc(8 * (size_t)f.n2 * f.n2)); HIPCHK(c, f.scal.alloc(64));
+  c->scratch.reset();
+  HIPCHK(c, f.kp1.alloc(c, 8 * (size_t)P)); HIPCHK(c, f.kp2.alloc(c, 8 * (size_t)P)); HIPCHK(c, f.isg.alloc(c, 4 * (size_t)P));
+  HIPCHK(c, f.x.alloc(c, 8 * (size_t)f.n2)); HIPCHK(c, f.xn.alloc(c, 8 * (size_t)f.n2)); HIPCHK(c, f.cs.alloc(c, 8 * (size_t)f.n2)); HIPCHK(c, f.g.alloc(c, 8 * (size_t)f.n2));
+  HIPCHK(c, f.dx.alloc(c, 8 * (size_t)f.n2)); HIPCHK(c, f.r.alloc(c, 8 * (size_t)f.m)); HIPCHK(c, f.J.alloc(c, 8 * (size_t)f.m * f.n2));
+  HIPCHK(c, f.A.alloc(c, 8 * (size_t)f.n2 * f.n2)); {
+    const size_t np = (size_t)nrsfm_swp_solve_np(f.n2);
+    HIPCHK(c, f.M.alloc(c, 8 * np * np)); HIPCHK(c, f.W.alloc(c, 8 * np * 16));
+  }
+  HIPCHK(c, f.scal.alloc(c, 64));
   HIPCHK(c, hipMemcpyAsync(f.kp1.p, kp1, 8 * (size_t)P, hipMemcpyHostToDevice, f.st));
   HIPCHK(c, hipMemcpyAsync(f.kp2.p, kp2, 8 * (size_t)P, hipMemcpyHostToDevice, f.st));
   HIPCHK(c, hipMemcpyAsync(f.isg.p, invsig, 4 * (size_t)P, hipMemcpyHostToDevice, f.st));
@@ -108,6 +113,7 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
   if (!c) return DSH_ERR_ARG;
   if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_schwarp_fit: host-only context, no GPU (there is no CPU fallback)");
   if (!args_ok(bbs, P, kp1, kp2, invsig, x) || max_iters < 0) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit: bad argument");
+  if (bbs->nptsu * bbs->nptsv > 256) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit: more than 256 control points (the one-workgroup solve handles 2N <= 512 unknowns; the reference uses 13 x 15 = 195)");
   (void)hipSetDevice(c->device);
   Fit f;
   int rc = setup(f, c, bbs, P, kp1, kp2, invsig, fx_slot, fy_slot, lambda, x);
@@ -129,7 +135,7 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
   if (s[6] > gtol)
     while (it < max_iters) {
       it++;
-      HIPCHK(c, nrsfm_swp_solve(f.n2, f.A.as<double>(), f.g.as<double>(), radius, f.M.as<double>(), f.dx.as<double>(), scal + 2, f.st));
+      HIPCHK(c, nrsfm_swp_solve(f.n2, f.A.as<double>(), f.g.as<double>(), radius, f.M.as<double>(), f.W.as<double>(), f.dx.as<double>(), scal + 2, f.st));
       HIPCHK(c, nrsfm_swp_step(f.n2, f.x.as<double>(), f.dx.as<double>(), f.cs.as<double>(), f.g.as<double>(), f.xn.as<double>(), scal + 2, f.st));
       if ((rc = f.scalars(s)) != DSH_OK) return rc;
       const bool ok = s[2] != 0.0;
@@ -163,7 +169,7 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
   HIPCHK(c, hipMemcpyAsync(x, f.x.p, 8 * (size_t)f.n2, hipMemcpyDeviceToHost, f.st));
   if (diff && drop) {
     DevBuf dd, dr;
-    HIPCHK(c, dd.alloc(72 * (size_t)P)); HIPCHK(c, dr.alloc(P));
+    HIPCHK(c, dd.alloc(c, 72 * (size_t)P)); HIPCHK(c, dr.alloc(c, P));
     HIPCHK(c, nrsfm_swp_diffprop(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, P, f.kp1.as<float>(), f.kp2.as<float>(), f.x.as<double>(), fx,
                                  fy, dd.as<float>(), dr.as<uint8_t>(), f.st));
     HIPCHK(c, hipMemcpyAsync(diff, dd.p, 72 * (size_t)P, hipMemcpyDeviceToHost, f.st));

@@ -12,6 +12,7 @@
 // All kernels are embarrassingly parallel and bandwidth-trivial; records are stored SoA so neighbouring
 // threads read neighbouring addresses.
 #include <hip/hip_runtime.h>
+#include "tile_chol.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -417,18 +418,41 @@ __global__ void swp_eval_kernel(SwpPar p, const float* __restrict__ kp1, const f
   }
 }
 
-// scal[0] = cost = 1/2 (rho(|r_warp|^2) + |r_schw|^2), scal[1] = sqrt(rho'), sequential sums (oracle order), one lane.
-__global__ void swp_loss_kernel(int P2, int m, const double* __restrict__ r, double* __restrict__ scal) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Fixed-tree block sum: lane t sums its contiguous chunk in ascending order, then a binary tree over the 256 partial
+// sums (bit-reproducible run to run; differs from a sequential sum only in the last bits).
+__device__ double swp_block_sum256(double v, double* red) {
+  const int t = threadIdx.x;
+  red[t] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const double tot = red[0];
+  __syncthreads();
+  return tot;
+}
+
+// scal[0] = cost = 1/2 (rho(|r_warp|^2) + |r_schw|^2), scal[1] = sqrt(rho'); one 256-thread workgroup.
+__global__ __launch_bounds__(256) void swp_loss_kernel(int P2, int m, const double* __restrict__ r, double* __restrict__ scal) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
   const double a = 5.77;   // HuberLoss(5.77), SchwarpDatabase.cc:208
-  double sq = 0.0;
-  for (int i = 0; i < P2; i++) sq += r[i] * r[i];
-  double rho0 = sq, rho1 = 1.0;
-  if (sq > a * a) { const double rt = sqrt(sq); rho0 = 2 * a * rt - a * a; rho1 = a / rt; }
-  double cost = rho0;
-  for (int i = P2; i < m; i++) cost += r[i] * r[i];
-  scal[0] = cost * 0.5;
-  scal[1] = sqrt(rho1);
+  double s1 = 0.0, s2 = 0.0;
+  {
+    const int ch = (P2 + 255) / 256;
+    for (int i = t * ch; i < min(P2, (t + 1) * ch); i++) s1 += r[i] * r[i];
+    const int m2 = m - P2, ch2 = (m2 + 255) / 256;
+    for (int i = t * ch2; i < min(m2, (t + 1) * ch2); i++) s2 += r[P2 + i] * r[P2 + i];
+  }
+  const double sq = swp_block_sum256(s1, red);
+  const double rest = swp_block_sum256(s2, red);
+  if (t == 0) {
+    double rho0 = sq, rho1 = 1.0;
+    if (sq > a * a) { const double rt = sqrt(sq); rho0 = 2 * a * rt - a * a; rho1 = a / rt; }
+    scal[0] = (rho0 + rest) * 0.5;
+    scal[1] = sqrt(rho1);
+  }
 }
 
 __global__ void swp_scale_kernel(int P2, int n2, const double* __restrict__ scal, double* __restrict__ r, double* __restrict__ J) {
@@ -438,100 +462,300 @@ __global__ void swp_scale_kernel(int P2, int n2, const double* __restrict__ scal
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)P2; i += (size_t)gridDim.x * blockDim.x) r[i] *= sc;
 }
 
-// A = (J S)^T (J S) (lower and mirrored), g = (J S)^T r; one lane per (a,b), rows summed in ascending order.
-__global__ void swp_normal_kernel(int m, int n2, const double* __restrict__ J, const double* __restrict__ r, const double* __restrict__ cs,
-                                  double* __restrict__ A, double* __restrict__ g) {
-  __shared__ double Ja[16][17], Jb[16][17], rr[16];
-  const int ta = blockIdx.y * 16, tb = blockIdx.x * 16;
-  if (tb > ta) return;
-  const int la = threadIdx.y, lb = threadIdx.x;
-  const int a = ta + la, b = tb + lb;
-  const double csa = a < n2 ? cs[a] : 0.0, csb = b < n2 ? cs[b] : 0.0;
-  double acc = 0.0, gacc = 0.0;
-  for (int i0 = 0; i0 < m; i0 += 16) {
-    // stage 16 rows x 16 columns of both column tiles (thread (la, lb) loads row i0+la)
-    const int i = i0 + la;
-    Ja[la][lb] = (i < m && ta + lb < n2) ? J[(size_t)i * n2 + ta + lb] : 0.0;
-    Jb[la][lb] = (i < m && tb + lb < n2) ? J[(size_t)i * n2 + tb + lb] : 0.0;
-    if (lb == 0) rr[la] = i < m ? r[i] : 0.0;
-    __syncthreads();
+// A = (J S)^T (J S) (lower and mirrored), g = (J S)^T r on FP64 MFMA: one wavefront per 16x16 tile of A (lower triangle),
+// J is read straight from global memory as both operands (lane (i, k) reads J[row0 + k][tile + i]: 16 consecutive doubles
+// of 4 rows per MFMA), four accumulators in flight; the four wavefronts of a workgroup split the rows of J (split-K) and
+// their partial tiles are added in a fixed order (bit-reproducible run to run).  The column scaling S = diag(cs) is
+// applied to the finished tile.  Tiles of block column 0 also accumulate g on the vector ALU.
+__global__ __launch_bounds__(256) void swp_normal_kernel(int m, int n2, int nt, const double* __restrict__ J, const double* __restrict__ r,
+                                                         const double* __restrict__ cs, double* __restrict__ A, double* __restrict__ g) {
+  __shared__ double part[3][4][64];
+  __shared__ double gpart[3][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+  while (ti * (ti + 1) / 2 > t) ti--;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int ta = 16 * ti, tb = 16 * tj;
+  const int i = lane & 15, k = lane >> 4;
+  const bool va = ta + i < n2, vb = tb + i < n2;
+  v4d acc[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const double ja = Ja[k][la], jb = Jb[k][lb];
-      if (ja != 0.0) {
-        const double jas = ja * csa;
-        if (jb != 0.0) acc += jas * (jb * csb);
-        if (tb == 0 && lb == 0) gacc += jas * rr[k];
-      }
+  for (int u = 0; u < 4; u++) acc[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double gacc = 0.0;
+  const double* Ja = J + ta + i;
+  const double* Jb = J + tb + i;
+  for (int r0 = 16 * wave; r0 < m; r0 += 64) {
+    double av[4], bv[4], rv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int row = r0 + 4 * u + k;
+      const bool vr = row < m;
+      av[u] = (vr && va) ? Ja[(size_t)row * n2] : 0.0;
+      bv[u] = (vr && vb) ? Jb[(size_t)row * n2] : 0.0;
+      rv[u] = (tj == 0 && vr) ? r[row] : 0.0;
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc[u], 0, 0, 0);
+      gacc = fma(av[u], rv[u], gacc);
+    }
   }
-  if (a < n2 && b < n2 && b <= a) { A[(size_t)a * n2 + b] = acc; A[(size_t)b * n2 + a] = acc; }
-  if (tb == 0 && lb == 0 && a < n2) g[a] = gacc;
+  v4d tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (tj == 0) {   // g[ta + i]: the four k-groups hold partial sums of disjoint rows
+    gacc += __shfl_xor(gacc, 16, 64);
+    gacc += __shfl_xor(gacc, 32, 64);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) part[wave - 1][q][lane] = tot[q];
+    if (lane < 16) gpart[wave - 1][lane] = gacc;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; w++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) tot[q] += part[w][q][lane];
+    if (lane < 16) gacc += gpart[w][lane];
+  }
+  const int g4 = lane >> 4, c = lane & 15;
+  const double csb = (tb + c < n2) ? cs[tb + c] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ra = ta + g4 + 4 * q, cb = tb + c;
+    if (ra < n2 && cb < n2 && cb <= ra) {
+      const double v = tot[q] * (cs[ra] * csb);
+      A[(size_t)ra * n2 + cb] = v;
+      A[(size_t)cb * n2 + ra] = v;
+    }
+  }
+  if (tj == 0 && lane < 16 && va) g[ta + i] = gacc * cs[ta + i];
 }
 
-// One workgroup: M = A + diag(clamp(diag A)/radius), Cholesky (row-wise left-looking, oracle summation order), solve M dx = -g,
-// model = -(dx.g + 1/2 dx^T A dx).  out[0] = ok, out[1] = model.
-__global__ void swp_solve_kernel(int n, const double* __restrict__ A, const double* __restrict__ g, double radius, double* __restrict__ M,
-                                 double* __restrict__ dx, double* __restrict__ out) {
-  __shared__ int bad;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (size_t i = tid; i < (size_t)n * n; i += nt) {
-    const int rr = (int)(i / n), cc = (int)(i % n);
-    double v = A[i];
+// One workgroup (8 wavefronts): M = A + diag(clamp(diag A)/radius) padded to np = 16*ceil(n/16) with an identity block,
+// right-looking Cholesky on 16x16 FP64 MFMA tiles (M stays in global memory: 1.2 MB at n = 390, L2 resident):
+//   per block column K: wave 0 factors the diagonal tile and inverts the factor in registers (chol_inv_blocked, W = L^-1)
+//   and finishes block K of the forward substitution z_K = W y_K; TRSM X_I = A_IK W^T (4 MFMAs per tile, tiles over the
+//   waves) folds y_I -= X_I z_K in as soon as a tile is known; trailing A_IJ -= X_I X_J^T (4 MFMAs per tile, 4 in flight);
+// then the backward substitution L^T dx = z (operands of the next block prefetched), and the model decrease
+// -(dx.g + 1/2 dx^T A dx).  out[0] = ok, out[1] = model.  Winv: np x 16 doubles, row-major W tiles.  Needs np <= 512.
+#define SWS_TP 17
+#define SWS_TILE (16 * SWS_TP)
+// M = A + diag(clamp(diag A) / radius), padded to np x np with an identity block (whole GPU: one workgroup would be
+// load-latency bound on this 1.2 MB copy)
+__global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, const double* __restrict__ A, double radius, double* __restrict__ M) {
+  const int cc = blockIdx.x * 256 + threadIdx.x, rr = blockIdx.y;
+  if (cc >= np) return;
+  double v = (rr == cc) ? 1.0 : 0.0;
+  if (rr < n && cc < n) {
+    v = A[(size_t)rr * n + cc];
     if (rr == cc) v += fmin(fmax(v, 1e-6), 1e32) / radius;
-    M[i] = v;
   }
+  M[(size_t)rr * np + cc] = v;
+}
+// sum over the 16 lanes of a row group (lanes sharing l >> 4), result in every lane of the group
+__device__ __forceinline__ double swp_row16_sum(double v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const double* __restrict__ A, const double* __restrict__ g, double radius,
+                                                        double* __restrict__ M, double* __restrict__ Winv, double* __restrict__ dx, double* __restrict__ out) {
+  extern __shared__ double sws[];
+  const int NT = np / 16;
+  double* Xp = sws;                       // NT panel tiles, k-major padded: Xp[T*SWS_TILE + k*SWS_TP + i] = X_T[i][k]
+  double* Wk = Xp + (size_t)NT * SWS_TILE;  // W^T of the current block, k-major: Wk[k*SWS_TP + j] = W[j][k]
+  double* yv = Wk + SWS_TILE;             // np: right-hand side -> forward-substituted -> solution
+  double* red = yv + np;                  // 16 partial sums
+  __shared__ int bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int crow = lane >> 4, ccol = lane & 15;
+  for (int i = tid; i < np; i += 512) yv[i] = (i < n) ? -g[i] : 0.0;   // M was prepared by swp_damp_kernel
   if (tid == 0) bad = 0;
   __syncthreads();
-  for (int k = 0; k < n; k++) {
-    // every lane forms the pivot itself (same sequential sum), rows r > k form their entry of column k
-    double d = M[(size_t)k * n + k];
-    for (int j = 0; j < k; j++) d -= M[(size_t)k * n + j] * M[(size_t)k * n + j];
-    if (!(d > 0)) { if (tid == 0) bad = 1; }
-    const double piv = sqrt(d);
-    for (int rI = k + 1 + tid; rI < n; rI += nt) {
-      double v = M[(size_t)rI * n + k];
-      for (int j = 0; j < k; j++) v -= M[(size_t)rI * n + j] * M[(size_t)k * n + j];
-      M[(size_t)rI * n + k] = v / piv;
+  for (int K = 0; K < NT; K++) {
+    if (wave == 0) {
+      v4d a, w;
+#pragma unroll
+      for (int q = 0; q < 4; q++) a[q] = M[(size_t)(16 * K + crow + 4 * q) * np + 16 * K + ccol];
+      if (!chol_inv_blocked(a, w) && lane == 0) bad = 1;
+      const double yk = yv[16 * K + ccol];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        Wk[ccol * SWS_TP + crow + 4 * q] = w[q];
+        Winv[(size_t)(16 * K + crow + 4 * q) * 16 + ccol] = w[q];
+      }
+      double z[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) z[q] = swp_row16_sum(w[q] * yk);     // z_K = W y_K, row crow + 4q
+      if (ccol == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) yv[16 * K + crow + 4 * q] = z[q];
+      }
     }
     __syncthreads();
-    if (tid == 0) M[(size_t)k * n + k] = piv;
+    // TRSM: X_I = A_IK W^T, and the forward substitution of block row I: y_I -= X_I z_K
+    const double zk = yv[16 * K + ccol];
+    constexpr int TU = 4;   // tiles of this wave in flight (NT <= 32)
+    for (int I0 = K + 1 + wave; I0 < NT; I0 += 8 * TU) {
+      double av[TU][4], bv[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) bv[kk] = Wk[(4 * kk + crow) * SWS_TP + ccol];                        // B[k][j] = W[j][k]
+#pragma unroll
+      for (int u = 0; u < TU; u++) {
+        const int I = min(I0 + 8 * u, NT - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) av[u][kk] = M[(size_t)(16 * I + ccol) * np + 16 * K + 4 * kk + crow];   // A operand: lane (i = ccol, k = crow)
+      }
+#pragma unroll
+      for (int u = 0; u < TU; u++) {
+        const int I = I0 + 8 * u;
+        if (I >= NT) break;
+        v4d x = {0.0, 0.0, 0.0, 0.0}, x2 = x;
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[0], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[1], x2, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][2], bv[2], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][3], bv[3], x2, 0, 0, 0);
+        x += x2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          Xp[(size_t)I * SWS_TILE + ccol * SWS_TP + crow + 4 * q] = x[q];
+          M[(size_t)(16 * I + crow + 4 * q) * np + 16 * K + ccol] = x[q];
+          const double d = swp_row16_sum(x[q] * zk);
+          if (ccol == 0) yv[16 * I + crow + 4 * q] -= d;     // only this wave touches block row I in this step
+        }
+      }
+    }
+    __syncthreads();
+    // trailing update of the lower triangle: tiles (I, J), K < J <= I
+    // Tile rows are dealt to the waves from both ends (row lengths grow linearly: pairing a long with a short row
+    // balances the waves); the A operand of a row is read once, 4 tiles of the row are in flight.
+    const int ntr = NT - 1 - K;
+    for (int p = wave; p < (ntr + 1) / 2; p += 8) {
+#pragma unroll 1
+      for (int side = 0; side < 2; side++) {
+        const int ii = side == 0 ? p : ntr - 1 - p;
+        if (side == 1 && ii == p) break;
+        const int I = K + 1 + ii;
+        double an[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) an[kk] = -Xp[(size_t)I * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
+        constexpr int UNR = 4;
+        for (int J0 = K + 1; J0 <= I; J0 += UNR) {
+          v4d acc[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; u++) {
+            const int J = min(J0 + u, I);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[u][q] = M[(size_t)(16 * I + crow + 4 * q) * np + 16 * J + ccol];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+              const int J = min(J0 + u, I);
+              const double bb = Xp[(size_t)J * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
+              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb, acc[u], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; u++)
+            if (J0 + u <= I) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) M[(size_t)(16 * I + crow + 4 * q) * np + 16 * (J0 + u) + ccol] = acc[u][q];
+            }
+        }
+      }
+    }
     __syncthreads();
   }
-  if (tid == 0) {
-    out[0] = bad ? 0.0 : 1.0;
-    out[1] = 0.0;
-    if (!bad) {
-      for (int i = 0; i < n; i++) { double v = -g[i]; for (int j = 0; j < i; j++) v -= M[(size_t)i * n + j] * dx[j]; dx[i] = v / M[(size_t)i * n + i]; }
-      for (int i = n - 1; i >= 0; i--) { double v = dx[i]; for (int j = i + 1; j < n; j++) v -= M[(size_t)j * n + i] * dx[j]; dx[i] = v / M[(size_t)i * n + i]; }
-      double dg = 0, q = 0;
-      for (int a = 0; a < n; a++) {
-        dg += dx[a] * g[a];
-        double t = 0;
-        for (int b = 0; b < n; b++) t += A[(size_t)a * n + b] * dx[b];
-        q += dx[a] * t;
-      }
-      const double model = -(dg + 0.5 * q);
-      out[1] = model;
-      if (!(model > 0)) out[0] = 0.0;
+  // ---- backward substitution L^T x = z, right-looking: x_K = W_K^T z_K, then z_c -= L[16K.., c]^T x_K for c < 16K.
+  //      Thread c owns column c (np <= 512); the operands of block K-1 are fetched while block K is processed. ----------
+  double wt[16], lc[16];
+  auto fetch = [&](int K) {
+    if (K < 0) return;
+    if (tid < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) wt[j] = Winv[(size_t)(16 * K + j) * 16 + tid];     // column tid of W_K = row of W_K^T
     }
+    if (tid < 16 * K) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) lc[j] = M[(size_t)(16 * K + j) * np + tid];
+    }
+  };
+  fetch(NT - 1);
+  for (int K = NT - 1; K >= 0; K--) {
+    double z = 0.0;
+    if (tid < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) z = fma(wt[j], yv[16 * K + j], z);
+    }
+    double lcur[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) lcur[j] = lc[j];
+    const bool upd = tid < 16 * K;
+    __syncthreads();
+    if (tid < 16) yv[16 * K + tid] = z;
+    fetch(K - 1);
+    __syncthreads();
+    if (upd) {
+      double sacc = yv[tid];
+#pragma unroll
+      for (int j = 0; j < 16; j++) sacc = fma(-lcur[j], yv[16 * K + j], sacc);
+      yv[tid] = sacc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 512) dx[i] = yv[i];
+  // ---- model decrease -(dx.g + 1/2 dx^T A dx): a wave per row, lanes across the columns --------------------------
+  double part = 0.0;
+  for (int a0 = 4 * wave; a0 < n; a0 += 32) {   // four rows per wave in flight
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b2 = lane; b2 < n; b2 += 64) {
+      const double xb = yv[b2];
+#pragma unroll
+      for (int u = 0; u < 4; u++) t[u] = fma((a0 + u < n) ? A[(size_t)(a0 + u) * n + b2] : 0.0, xb, t[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      for (int o = 32; o > 0; o >>= 1) t[u] += __shfl_down(t[u], o, 64);
+      if (lane == 0 && a0 + u < n) part += yv[a0 + u] * (g[a0 + u] + 0.5 * t[u]);
+    }
+  }
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < 8; w++) tot += red[w];
+    const double model = -tot;
+    out[1] = bad ? 0.0 : model;
+    out[0] = (bad || !(model > 0)) ? 0.0 : 1.0;
   }
 }
 
-// xn = x + dx*cs; out[2] = |step|, out[3] = |x|, out[4] = max |g|
-__global__ void swp_step_kernel(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
-                                const double* __restrict__ g, double* __restrict__ xn, double* __restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// xn = x + dx*cs; out[2] = |step|, out[3] = |x|, out[4] = max |g|; one 256-thread workgroup
+__global__ __launch_bounds__(256) void swp_step_kernel(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
+                                                       const double* __restrict__ g, double* __restrict__ xn, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
   double sn = 0, xnrm = 0, gm = 0;
-  for (int j = 0; j < n; j++) {
+  const int ch = (n + 255) / 256;
+  for (int j = t * ch; j < min(n, (t + 1) * ch); j++) {
     const double st = dx[j] * cs[j];
     xn[j] = x[j] + st;
     sn += st * st;
     xnrm += x[j] * x[j];
     gm = fmax(gm, fabs(g[j]));
   }
-  out[2] = sqrt(sn); out[3] = sqrt(xnrm); out[4] = gm;
+  const double snt = swp_block_sum256(sn, red), xt = swp_block_sum256(xnrm, red);
+  red[t] = gm;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = fmax(red[t], red[t + o]);
+    __syncthreads();
+  }
+  if (t == 0) { out[2] = sqrt(snt); out[3] = sqrt(xt); out[4] = red[0]; }
 }
 
 __global__ void swp_colscale_kernel(int n, const double* __restrict__ A, double* __restrict__ cs) {
@@ -617,25 +841,37 @@ extern "C" hipError_t nrsfm_swp_eval(double umin, double umax, int nu, double vm
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_swp_loss(int P2, int m, const double* r, double* scal, hipStream_t st) {
-  hipLaunchKernelGGL(swp_loss_kernel, dim3(1), dim3(64), 0, st, P2, m, r, scal);
+  hipLaunchKernelGGL(swp_loss_kernel, dim3(1), dim3(256), 0, st, P2, m, r, scal);
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_swp_normal(int P2, int m, int n2, double* J, double* r, const double* cs, const double* scal, double* A, double* g, hipStream_t st) {
   hipLaunchKernelGGL(swp_scale_kernel, dim3(256), dim3(256), 0, st, P2, n2, scal, r, J);
-  const int nt = (n2 + 15) / 16;
-  hipLaunchKernelGGL(swp_normal_kernel, dim3(nt, nt), dim3(16, 16), 0, st, m, n2, J, r, cs, A, g);
+  const int nt = (n2 + 15) / 16, tiles = nt * (nt + 1) / 2;
+  hipLaunchKernelGGL(swp_normal_kernel, dim3(tiles), dim3(256), 0, st, m, n2, nt, J, r, cs, A, g);
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_swp_colscale(int n2, const double* A, double* cs, hipStream_t st) {
   hipLaunchKernelGGL(swp_colscale_kernel, dim3((n2 + 127) / 128), dim3(128), 0, st, n2, A, cs);
   return hipGetLastError();
 }
-extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, double radius, double* M, double* dx, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), 0, st, n2, A, g, radius, M, dx, out);
+// M: np*np doubles, Winv: np*16 doubles with np = nrsfm_swp_solve_np(n2)
+extern "C" int nrsfm_swp_solve_np(int n2) { return 16 * ((n2 + 15) / 16); }
+extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, double radius, double* M, double* Winv, double* dx, double* out, hipStream_t st) {
+  const int np = nrsfm_swp_solve_np(n2), NT = np / 16;
+  const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + np + 16);
+  if (lds > 150 * 1024 || np > 512) return hipErrorInvalidValue;   // one thread per unknown in the backward substitution
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swp_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(swp_damp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, n2, np, A, radius, M);
+  hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), lds, st, n2, np, A, g, radius, M, Winv, dx, out);
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_swp_step(int n2, const double* x, const double* dx, const double* cs, const double* g, double* xn, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(swp_step_kernel, dim3(1), dim3(64), 0, st, n2, x, dx, cs, g, xn, out);
+  hipLaunchKernelGGL(swp_step_kernel, dim3(1), dim3(256), 0, st, n2, x, dx, cs, g, xn, out);
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_swp_diffprop(double umin, double umax, int nu, double vmin, double vmax, int nv, int P, const float* kp1, const float* kp2,

@@ -22,6 +22,7 @@
 #include <float.h>
 #define SFT_KERNEL_SOURCE
 #include "sft_problem.h"
+#include "tile_chol.h"
 
 #define NB 32  // panel width of the blocked band Cholesky
 
@@ -60,7 +61,6 @@
 #define BT 8    // sub-diagonal tiles per block column in tile mode (half-bandwidth <= 16*BT)
 #define TILE_LDS (TS * TP)
 
-typedef double v4d __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -726,23 +726,7 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
 //   * the 6 camera rows + the right-hand side ride along as a 7 x 128 ring in LDS (VALU)
 // H is read once (fresh tiles enter the window as it slides), L is written once.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double bcast_lane(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
 
-// 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26 relative) + one coupled Goldschmidt/Newton step
-// (quadratic: ~2^-52) + one residual correction of the square root.
-__device__ __forceinline__ void rsqrt_sqrt(double d, double& inv, double& s) {
-  const double y = __builtin_amdgcn_rsq(d);
-  double g = d * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  const double res = fma(-g, g, d);
-  s = fma(res, h, g);
-  inv = fma(fma(-h, g, 0.5), h + h, h + h);   // one more correction of 1/sqrt without lengthening the sqrt chain
-}
 
 // Barrier that orders LDS traffic only: outstanding global loads/stores stay in flight across it
 // (prefetched H tiles must not be drained at every step; L tiles are first re-read after the loop).
@@ -779,70 +763,6 @@ __device__ __forceinline__ bool chol_inv_mfma(v4d& a, v4d& w) {
     const double wr = w[qj] * m;                       // W[j][c] / L[j][j] (previous W update has landed by now)
     const double u = (g == gj && c == j) ? (nla + 1.0) : nla;   // -(l - e_j)
     w = __builtin_amdgcn_mfma_f64_16x16x4f64(u, wr, w, 0, 0, 0);
-  }
-  return !bad;
-}
-
-// Blocked variant of chol_inv_mfma (4x4 blocks, 13 MFMAs instead of 32 and 4 instead of 16 dependent block steps).
-// Block step J (rows/columns 4J..4J+3 live in register J of lane groups g = 0..3):
-//   1. the 10 entries of the symmetric 4x4 diagonal block are broadcast to every lane; every lane factors it and inverts
-//      the factor redundantly (uniform scalars): D = Ld Ld^T, M = Ld^-1
-//   2. Z  = Mpad * A[4J..4J+3, :]   one MFMA, B operand = register J of `a` as it is; Z[g][c] = L[c][4J+g] comes out
-//      in exactly the lane layout the rank-4 update needs for both of its operands
-//      Zw = Mpad * W[4J..4J+3, :]   the new rows 4J..4J+3 of W = L^-1
-//   3. a -= Z^T Z (rank 4),  W[rows below] -= L[rows below, 4J..4J+3] * Zw,  W[4J..4J+3, :] = Zw
-// Returns false when a pivot is not positive.
-__device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, c = lane & 15;
-  w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
-  bool bad = false;
-  const v4d zero = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int J = 0; J < 4; J++) {
-    const double aJ = a[J];
-    const int b0 = 4 * J;
-    const double d00 = bcast_lane(aJ, b0), d10 = bcast_lane(aJ, 16 + b0), d11 = bcast_lane(aJ, 16 + b0 + 1);
-    const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
-    const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
-    double i0, i1, i2, i3, sq;
-    if (!(d00 > 0.0)) bad = true;
-    rsqrt_sqrt(d00, i0, sq);
-    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-    const double p1 = fma(-l10, l10, d11);
-    if (!(p1 > 0.0)) bad = true;
-    rsqrt_sqrt(p1, i1, sq);
-    const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
-    const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
-    if (!(p2 > 0.0)) bad = true;
-    rsqrt_sqrt(p2, i2, sq);
-    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
-    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-    if (!(p3 > 0.0)) bad = true;
-    rsqrt_sqrt(p3, i3, sq);
-    // M = Ld^-1 (lower triangular)
-    const double m10 = -(l10 * i0) * i1;
-    const double m21 = -(l21 * i1) * i2;
-    const double m32 = -(l32 * i2) * i3;
-    const double m20 = -fma(l21, m10, l20 * i0) * i2;
-    const double m31 = -fma(l32, m21, l31 * i1) * i3;
-    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * i0)) * i3;
-    // A operand of Z = Mpad * rows: lane (i = c, k = g) holds M[i][k] for i < 4, k <= i
-    double sel = 0.0;
-    sel = (c == 0 && g == 0) ? i0 : sel;
-    sel = (c == 1) ? (g == 0 ? m10 : (g == 1 ? i1 : 0.0)) : sel;
-    sel = (c == 2) ? (g == 0 ? m20 : (g == 1 ? m21 : (g == 2 ? i2 : 0.0))) : sel;
-    sel = (c == 3) ? (g == 0 ? m30 : (g == 1 ? m31 : (g == 2 ? m32 : i3))) : sel;
-    const v4d zw = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, w[J], zero, 0, 0, 0);
-    if (J < 3) {
-      const v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, aJ, zero, 0, 0, 0);
-      const double lp = z[0];                       // L[c][4J+g]
-      const double nlp = -lp;
-      a = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, lp, a, 0, 0, 0);
-      const double below = (c >= 4 * J + 4) ? nlp : 0.0;
-      w = __builtin_amdgcn_mfma_f64_16x16x4f64(below, zw[0], w, 0, 0, 0);
-    }
-    w[J] = zw[0];
   }
   return !bad;
 }
