@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="independent problems per GPU per step (2048 = 8 per CU: the launch tail of the slowest problems amortises)")
+    ap.add_argument("--batch", type=int, default=8192, help="independent problems per GPU per step (8192 = 32 per CU, 27 GB of HBM: problems need 7-35 damping trials and a launch ends with its slowest one, so a deep batch amortises the tail)")
     ap.add_argument("--config", default="C2", choices=["smoke", "C2", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -1,0 +1,166 @@
+// Host side of dsh_sfn_estimate / dsh_bbs_bending (include/defslam_hip.h): Shape from Normals,
+// Modules/Mapping/ShapeFromNormals.cc.  The stacked least squares is solved on the device by corrected semi-normal
+// equations: G = A^T A and A^T b on FP64 MFMA (swp_normal_kernel), tile Cholesky (swp_solve_kernel), two steps of
+// iterative refinement with the residual formed from A itself, which restores the accuracy a QR factorisation has.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/defslam_hip.h"
+#include "dsh_ctx.h"
+
+extern "C" hipError_t nrsfm_swp_normal(int, int, int, double*, double*, const double*, const double*, double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_swp_resolve(int, const double*, const double*, const double*, double*, hipStream_t);
+extern "C" int nrsfm_swp_solve_np(int);
+extern "C" hipError_t nrsfm_sfn_rows(double, double, int, double, double, int, int, const double*, const double*, const float*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_sfn_residual(int, int, const double*, const double*, const double*, double, double*, hipStream_t);
+extern "C" hipError_t nrsfm_sfn_axpy(int, const double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_sfn_points(double, double, int, double, double, int, const double*, int, const double*, const double*, float*, hipStream_t);
+
+namespace {
+#define HIPCHK(c, call)                                                                                        \
+  do {                                                                                                         \
+    hipError_t e__ = (call);                                                                                   \
+    if (e__ != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+struct DevBuf {   // a slice of the context's scratch (dsh_ctx.h); nothing to free
+  void* p = nullptr;
+  hipError_t alloc(dsh_ctx_base* c, size_t bytes) { return c->scratch.take(bytes, &p); }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+// int_0^1 b_p^(k) b_q^(k) dt for the four cubic B-spline pieces on a knot interval, k = 0, 1, 2: the three coefficient
+// tables of the reference's bending code are products of these numbers.
+void spline_integrals(double I[3][4][4]) {
+  const double piece[4][4] = {{1.0 / 6, -3.0 / 6, 3.0 / 6, -1.0 / 6}, {4.0 / 6, 0.0, -6.0 / 6, 3.0 / 6}, {1.0 / 6, 3.0 / 6, 3.0 / 6, -3.0 / 6}, {0.0, 0.0, 0.0, 1.0 / 6}};
+  for (int k = 0; k < 3; k++)
+    for (int p = 0; p < 4; p++)
+      for (int q = 0; q < 4; q++) {
+        double a[4], b[4];
+        for (int t = 0; t < 4; t++) { a[t] = piece[p][t]; b[t] = piece[q][t]; }
+        for (int s = 0; s < k; s++) {
+          const double da[4] = {a[1], 2 * a[2], 3 * a[3], 0.0}, db[4] = {b[1], 2 * b[2], 3 * b[3], 0.0};
+          std::memcpy(a, da, sizeof a);
+          std::memcpy(b, db, sizeof b);
+        }
+        double s = 0.0;
+        for (int i = 0; i < 4; i++)
+          for (int j = 0; j < 4; j++) s += a[i] * b[j] / (double)(i + j + 1);
+        I[k][p][q] = s;
+      }
+}
+
+void bending_dense(const dsh_bbs* b, double lambda, double* Bm) {
+  const int nx = b->nptsv, ny = b->nptsu, N = nx * ny;
+  const double sy = (b->umax - b->umin) / (b->nptsu - 3), sx = (b->vmax - b->vmin) / (b->nptsv - 3);
+  double I[3][4][4];
+  spline_integrals(I);
+  double coeff[16][16];
+  for (int d = 0; d < 16; d++)
+    for (int c = 0; c <= d; c++) {
+      const int e1 = c / 4, f1 = c % 4, e2 = d / 4, f2 = d % 4;
+      const double bxx = I[2][f1][f2] * I[0][e1][e2], byy = I[0][f1][f2] * I[2][e1][e2], bxy = 2.0 * I[1][f1][f2] * I[1][e1][e2];
+      coeff[d][c] = sy * bxx / std::pow(sx, 3) + bxy / (sx * sy) + sx * byy / std::pow(sy, 3);
+    }
+  std::fill(Bm, Bm + (size_t)N * N, 0.0);
+  for (int cb = 0; cb < ny - 3; cb++)        // knot cells, u index outer like the reference
+    for (int ca = 0; ca < nx - 3; ca++)
+      for (int c = 0; c < 16; c++)
+        for (int d = c; d < 16; d++) {
+          const int i = (cb + c / 4) * nx + ca + c % 4, j = (cb + d / 4) * nx + ca + d % 4;
+          Bm[(size_t)i * N + j] += lambda * coeff[d][c];
+          if (i != j) Bm[(size_t)j * N + i] = Bm[(size_t)i * N + j];
+        }
+}
+
+bool bbs_ok(const dsh_bbs* b) { return b && b->nptsu >= 4 && b->nptsv >= 4 && b->umax > b->umin && b->vmax > b->vmin; }
+}  // namespace
+
+extern "C" {
+
+int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending) {
+  if (!bbs_ok(bbs) || !bending) return DSH_ERR_ARG;
+  bending_dense(bbs, lambda, bending);
+  return DSH_OK;
+}
+
+int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, double bending_weight,
+                     double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok) {
+  dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
+  if (!c) return DSH_ERR_ARG;
+  if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_sfn_estimate: host-only context, no GPU (there is no CPU fallback)");
+  if (!bbs_ok(bbs) || n < 0 || n_all < 0 || (n > 0 && (!u || !v || !normals)) || (n_all > 0 && (!u_all || !v_all || !pts)) || !ctrl || !ok)
+    return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate: bad argument");
+  const int N = bbs->nptsu * bbs->nptsv;
+  if (N > 512) return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate: more than 512 control points (one-workgroup solve)");
+  *ok = 0;
+  if (hipSetDevice(c->device) != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, "dsh_sfn_estimate: hipSetDevice failed");
+  c->scratch.reset();
+  hipStream_t st = c->stream;
+  const int m = 2 * n + N + 1, np = nrsfm_swp_solve_np(N);
+  DevBuf dA, db, dr, dx, ddx, dG, dg, dM, dW, dones, dscal, du, dv, dn, dua, dva, dctrl, dpts;
+  HIPCHK(c, dA.alloc(c, 8 * (size_t)m * N)); HIPCHK(c, db.alloc(c, 8 * (size_t)m)); HIPCHK(c, dr.alloc(c, 8 * (size_t)m));
+  HIPCHK(c, dx.alloc(c, 8 * (size_t)N)); HIPCHK(c, ddx.alloc(c, 8 * (size_t)N)); HIPCHK(c, dG.alloc(c, 8 * (size_t)N * N)); HIPCHK(c, dg.alloc(c, 8 * (size_t)N));
+  HIPCHK(c, dM.alloc(c, 8 * (size_t)np * np)); HIPCHK(c, dW.alloc(c, 8 * (size_t)np * 16)); HIPCHK(c, dones.alloc(c, 8 * (size_t)N)); HIPCHK(c, dscal.alloc(c, 256));
+  HIPCHK(c, du.alloc(c, 8 * (size_t)n)); HIPCHK(c, dv.alloc(c, 8 * (size_t)n)); HIPCHK(c, dn.alloc(c, 12 * (size_t)n));
+  HIPCHK(c, dua.alloc(c, 8 * (size_t)n_all)); HIPCHK(c, dva.alloc(c, 8 * (size_t)n_all)); HIPCHK(c, dctrl.alloc(c, 8 * (size_t)N)); HIPCHK(c, dpts.alloc(c, 12 * (size_t)n_all));
+  // constant rows: bending block, the row of ones, right-hand side (zero except N * mean_depth in the last row)
+  std::vector<double> tail((size_t)(N + 1) * N), bvec((size_t)m, 0.0), ones((size_t)N, 1.0);
+  bending_dense(bbs, bending_weight, tail.data());
+  std::fill(tail.begin() + (size_t)N * N, tail.end(), 1.0);
+  bvec[m - 1] = (double)N * mean_depth;
+  HIPCHK(c, hipMemsetAsync(dA.p, 0, 8 * (size_t)2 * n * N, st));
+  HIPCHK(c, hipMemcpyAsync(dA.as<double>() + (size_t)2 * n * N, tail.data(), 8 * tail.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(db.p, bvec.data(), 8 * (size_t)m, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dones.p, ones.data(), 8 * (size_t)N, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(dx.p, 0, 8 * (size_t)N, st));
+  HIPCHK(c, hipMemsetAsync(dscal.p, 0, 256, st));
+  if (n > 0) {
+    HIPCHK(c, hipMemcpyAsync(du.p, u, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dv.p, v, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dn.p, normals, 12 * (size_t)n, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, nrsfm_sfn_rows(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, n, du.as<double>(), dv.as<double>(), dn.as<float>(), dA.as<double>(), st));
+  // x0: G x = A^T b  (the solve kernel returns M dx = -g, so it is fed g = A^T (-(b - A x)))
+  double* scal = dscal.as<double>();
+  for (int it = 0; it < 3; it++) {
+    HIPCHK(c, nrsfm_sfn_residual(m, N, dA.as<double>(), dx.as<double>(), db.as<double>(), -1.0, dr.as<double>(), st));
+    HIPCHK(c, nrsfm_swp_normal(0, m, N, dA.as<double>(), dr.as<double>(), dones.as<double>(), scal, dG.as<double>(), dg.as<double>(), st));
+    if (it == 0) HIPCHK(c, nrsfm_swp_solve(N, dG.as<double>(), dg.as<double>(), 1e300, dM.as<double>(), dW.as<double>(), ddx.as<double>(), scal + 2, st));
+    else HIPCHK(c, nrsfm_swp_resolve(N, dg.as<double>(), dM.as<double>(), dW.as<double>(), ddx.as<double>(), st));
+    HIPCHK(c, nrsfm_sfn_axpy(N, ddx.as<double>(), dx.as<double>(), st));
+  }
+  std::vector<double> x((size_t)N);
+  double s8[8];
+  HIPCHK(c, hipMemcpyAsync(x.data(), dx.p, 8 * (size_t)N, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(s8, dscal.p, 64, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (ctrl_raw) std::memcpy(ctrl_raw, x.data(), 8 * (size_t)N);
+  const bool factor_ok = s8[2] != 0.0 || s8[3] != 0.0;   // out[0] also folds in "model > 0"; a positive-definite G always has it
+  bool finite = true;
+  for (double t : x) finite = finite && std::isfinite(t);
+  if (!factor_ok || !finite || n_all == 0) return DSH_OK;
+  // the reference's scale: 1 / median of the float32 control points (ShapeFromNormals.cc:123-135)
+  std::vector<float> dvec((size_t)N);
+  for (int i = 0; i < N; i++) dvec[i] = (float)x[i];
+  std::sort(dvec.begin(), dvec.end());
+  const float corr = 1 / dvec[dvec.size() / 2];
+  for (int i = 0; i < N; i++) ctrl[i] = corr * x[i];
+  HIPCHK(c, hipMemcpyAsync(dctrl.p, ctrl, 8 * (size_t)N, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dua.p, u_all, 8 * (size_t)n_all, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dva.p, v_all, 8 * (size_t)n_all, hipMemcpyHostToDevice, st));
+  HIPCHK(c, nrsfm_sfn_points(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, dctrl.as<double>(), n_all, dua.as<double>(), dva.as<double>(),
+                             dpts.as<float>(), st));
+  HIPCHK(c, hipMemcpyAsync(pts, dpts.p, 12 * (size_t)n_all, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  *ok = 1;
+  return DSH_OK;
+}
+
+}  // extern "C"

@@ -734,6 +734,130 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
   }
 }
 
+// Substitutions only, with the factor left in M / Winv by swp_solve_kernel: M dx = -g (iterative refinement of the
+// Shape-from-Normals least squares).  One workgroup, np <= 512.
+__global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const double* __restrict__ g, const double* __restrict__ M,
+                                                          const double* __restrict__ Winv, double* __restrict__ dx) {
+  __shared__ double yv[512];
+  const int tid = threadIdx.x, NT = np / 16;
+  yv[tid] = (tid < n) ? -g[tid] : 0.0;
+  __syncthreads();
+  for (int K = 0; K < NT; K++) {
+    double z = 0.0;
+    if (tid < 16) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) z = fma(Winv[(size_t)(16 * K + tid) * 16 + k], yv[16 * K + k], z);
+    }
+    double lr[16];
+    const bool upd = tid >= 16 * (K + 1) && tid < np;
+    if (upd) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) lr[j] = M[(size_t)tid * np + 16 * K + j];
+    }
+    __syncthreads();
+    if (tid < 16) yv[16 * K + tid] = z;
+    __syncthreads();
+    if (upd) {
+      double sacc = yv[tid];
+#pragma unroll
+      for (int j = 0; j < 16; j++) sacc = fma(-lr[j], yv[16 * K + j], sacc);
+      yv[tid] = sacc;
+    }
+    __syncthreads();
+  }
+  for (int K = NT - 1; K >= 0; K--) {
+    double z = 0.0;
+    if (tid < 16) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) z = fma(Winv[(size_t)(16 * K + j) * 16 + tid], yv[16 * K + j], z);
+    }
+    double lc[16];
+    const bool upd = tid < 16 * K;
+    if (upd) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) lc[j] = M[(size_t)(16 * K + j) * np + tid];
+    }
+    __syncthreads();
+    if (tid < 16) yv[16 * K + tid] = z;
+    __syncthreads();
+    if (upd) {
+      double sacc = yv[tid];
+#pragma unroll
+      for (int j = 0; j < 16; j++) sacc = fma(-lc[j], yv[16 * K + j], sacc);
+      yv[tid] = sacc;
+    }
+    __syncthreads();
+  }
+  if (tid < n) dx[tid] = yv[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shape from Normals (Modules/Mapping/ShapeFromNormals.cc): stacked least squares [M; Bending; 1^T] x = [0; 0; N mean]
+// ------------------------------------------------------------------------------------------------
+// Rows of obtainM (ShapeFromNormals.cc:178-260) for one site per lane: row k = (n.eta) coloc_du + n_x coloc,
+// row k + n = (n.eta) coloc_dv + n_y coloc; 16 taps each, A is m x N row-major and zeroed beforehand.
+__global__ void sfn_rows_kernel(BbsPar p, int n, const double* __restrict__ u, const double* __restrict__ v, const float* __restrict__ normals, int N,
+                                double* __restrict__ A) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double nu, nv, b0u[4], b1u[4], b0v[4], b1v[4];
+  int Iu, Iv;
+  norm_inter(p.umin, p.umax, p.nptsu, u[k], nu, Iu);
+  norm_inter(p.vmin, p.vmax, p.nptsv, v[k], nv, Iv);
+  if (Iu < 0 || Iu > p.nptsu - 4 || Iv < 0 || Iv > p.nptsv - 4) return;   // outside the definition domain: no constraint
+  cubic_basis(0, nu, b0u); cubic_basis(1, nu, b1u);
+  cubic_basis(0, nv, b0v); cubic_basis(1, nv, b1v);
+  const double fu = deriv_fact(p, 1, 0), fv = deriv_fact(p, 0, 1);
+  double nx = normals[3 * k], ny = normals[3 * k + 1], nz = normals[3 * k + 2];
+  const double nn = sqrt(nx * nx + ny * ny + nz * nz);
+  nx /= nn; ny /= nn; nz /= nn;
+  const double ne = nx * u[k] + ny * v[k] + nz;
+  for (int iu = 0; iu < 4; iu++)
+    for (int iv = 0; iv < 4; iv++) {
+      const int col = (iu + Iu) * p.nptsv + iv + Iv;
+      const double w0 = b0u[iu] * b0v[iv], wu = fu * b1u[iu] * b0v[iv], wv = fv * b0u[iu] * b1v[iv];
+      A[(size_t)k * N + col] = ne * wu + nx * w0;
+      A[(size_t)(k + n) * N + col] = ne * wv + ny * w0;
+    }
+}
+
+// out[i] = sign * (b[i] - A[i,:] x): one wavefront per row
+__global__ __launch_bounds__(256) void sfn_residual_kernel(int m, int N, const double* __restrict__ A, const double* __restrict__ x, const double* __restrict__ b,
+                                                           double sign, double* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  double s = 0.0;
+  for (int j = lane; j < N; j += 64) s = fma(A[(size_t)row * N + j], x[j], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) out[row] = sign * (b[row] - s);
+}
+
+__global__ void sfn_axpy_kernel(int n, const double* __restrict__ dx, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += dx[i];
+}
+
+// Surface points (ShapeFromNormals.cc:150-166): depth d = BBS eval of the scaled control points, float32 (u d, v d, d)
+__global__ void sfn_points_kernel(BbsPar p, const double* __restrict__ ctrl, int n, const double* __restrict__ u, const double* __restrict__ v,
+                                  float* __restrict__ pts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double nu, nv, bu[4], bv[4];
+  int Iu, Iv;
+  norm_inter(p.umin, p.umax, p.nptsu, u[k], nu, Iu);
+  norm_inter(p.vmin, p.vmax, p.nptsv, v[k], nv, Iv);
+  cubic_basis(0, nu, bu);
+  cubic_basis(0, nv, bv);
+  double d = 0.0;
+  if (!(Iu < 0 || Iu > p.nptsu - 4 || Iv < 0 || Iv > p.nptsv - 4)) {
+    for (int iu = 0; iu < 4; iu++)
+      for (int iv = 0; iv < 4; iv++) d += ctrl[(iu + Iu) * p.nptsv + iv + Iv] * (bu[iu] * bv[iv]);
+  }
+  pts[3 * k] = (float)(u[k] * d);
+  pts[3 * k + 1] = (float)(v[k] * d);
+  pts[3 * k + 2] = (float)d;
+}
+
 // xn = x + dx*cs; out[2] = |step|, out[3] = |x|, out[4] = max |g|; one 256-thread workgroup
 __global__ __launch_bounds__(256) void swp_step_kernel(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
                                                        const double* __restrict__ g, double* __restrict__ xn, double* __restrict__ out) {
@@ -878,5 +1002,32 @@ extern "C" hipError_t nrsfm_swp_diffprop(double umin, double umax, int nu, doubl
                                          const double* x, float fx_true, float fy_true, float* diff, uint8_t* drop, hipStream_t st) {
   SwpPar p = {umin, umax, vmin, vmax, 0.0, 0.0, 0.0, nu, nv, nu * nv, P};
   hipLaunchKernelGGL(swp_diffprop_kernel, dim3((P + 127) / 128), dim3(128), 0, st, p, kp1, kp2, x, fx_true, fy_true, diff, drop);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nrsfm_swp_resolve(int n2, const double* g, const double* M, const double* Winv, double* dx, hipStream_t st) {
+  const int np = nrsfm_swp_solve_np(n2);
+  if (np > 512) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(swp_resolve_kernel, dim3(1), dim3(512), 0, st, n2, np, g, M, Winv, dx);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_sfn_rows(double umin, double umax, int nu, double vmin, double vmax, int nv, int n, const double* u, const double* v,
+                                     const float* normals, double* A, hipStream_t st) {
+  BbsPar p = {umin, umax, vmin, vmax, nu, nv, 1, 0};
+  if (n > 0) hipLaunchKernelGGL(sfn_rows_kernel, dim3((n + 127) / 128), dim3(128), 0, st, p, n, u, v, normals, nu * nv, A);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_sfn_residual(int m, int N, const double* A, const double* x, const double* b, double sign, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sfn_residual_kernel, dim3((m + 3) / 4), dim3(256), 0, st, m, N, A, x, b, sign, out);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_sfn_axpy(int n, const double* dx, double* x, hipStream_t st) {
+  hipLaunchKernelGGL(sfn_axpy_kernel, dim3((n + 127) / 128), dim3(128), 0, st, n, dx, x);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_sfn_points(double umin, double umax, int nu, double vmin, double vmax, int nv, const double* ctrl, int n, const double* u,
+                                       const double* v, float* pts, hipStream_t st) {
+  BbsPar p = {umin, umax, vmin, vmax, nu, nv, 1, 0};
+  if (n > 0) hipLaunchKernelGGL(sfn_points_kernel, dim3((n + 127) / 128), dim3(128), 0, st, p, ctrl, n, u, v, pts);
   return hipGetLastError();
 }

@@ -124,3 +124,34 @@ def calculateSchwarps(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot
                                       float(fy_slot), float(lam), float(fx), float(fy), int(max_iters), _ptr(x, C.c_double), _ptr(diff, C.c_float),
                                       _ptr(drop, C.c_uint8), _ptr(info, C.c_int32), _ptr(costs, C.c_double)), "dsh_schwarp_fit")
     return x, diff, drop.astype(bool), info, costs
+
+
+def bbs_bending(bbs: Bbs, lam: float) -> np.ndarray:
+    """BBS::BendingEigen as a dense symmetric N x N matrix (host side of the library)."""
+    L = _lib.load()
+    N = bbs.nptsu * bbs.nptsv
+    out = np.zeros((N, N))
+    b = bbs.c()
+    rc = L.dsh_bbs_bending(C.byref(b), float(lam), _ptr(out, C.c_double))
+    if rc != 0:
+        raise ValueError("dsh_bbs_bending: bad argument")
+    return out
+
+
+def ShapeFromNormals(ctx: Context, bbs: Bbs, u, v, normals, bending_weight: float, mean_depth: float, u_all, v_all):
+    """ShapeFromNormals(refKf, bendingWeight).estimate(): returns (ok, ctrl_raw[N], ctrl[N], pts[n_all, 3] float32)."""
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    ua = np.ascontiguousarray(u_all, np.float64)
+    va = np.ascontiguousarray(v_all, np.float64)
+    N = bbs.nptsu * bbs.nptsv
+    raw = np.zeros(N)
+    ctrl = np.zeros(N)
+    pts = np.zeros((ua.shape[0], 3), np.float32)
+    ok = C.c_int32(0)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_sfn_estimate(ctx._h, C.byref(b), u.shape[0], _ptr(u, C.c_double), _ptr(v, C.c_double), _ptr(nrm, C.c_float), float(bending_weight),
+                                       float(mean_depth), ua.shape[0], _ptr(ua, C.c_double), _ptr(va, C.c_double), _ptr(raw, C.c_double), _ptr(ctrl, C.c_double),
+                                       _ptr(pts, C.c_float), C.byref(ok)), "dsh_sfn_estimate")
+    return bool(ok.value), raw, ctrl, pts

@@ -256,3 +256,33 @@ def make_warp_problem(n_matches: int = 400, seed: int = 3, nu: int = 13, nv: int
     x0 = np.concatenate([cp[:, 0], cp[:, 1]])
     return dict(bbs=(umin, umax, nu, vmin, vmax, nv, 2), kp1=kp1.astype(np.float32), kp2=kp2.astype(np.float32), invsig=invsig, x0=x0,
                 fx=520.0, fy=515.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Shape from Normals: a smooth depth surface z(u, v) over the normalised image plane; key points with the true
+# surface normals (plus noise) as NRSfM would hand them over.  X(u, v) = z (u, v, 1): normal ~ X_u x X_v.
+def make_sfn_scene(n_points: int = 600, seed: int = 4, noise: float = 0.01, with_normal_frac: float = 0.8):
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-0.55, 0.55, n_points)
+    v = rng.uniform(-0.42, 0.42, n_points)
+
+    def z(u, v):
+        return 1.0 + 0.15 * u - 0.1 * v + 0.08 * np.sin(2.5 * u) * np.cos(2.0 * v)
+
+    def zu(u, v):
+        return 0.15 + 0.08 * 2.5 * np.cos(2.5 * u) * np.cos(2.0 * v)
+
+    def zv(u, v):
+        return -0.1 - 0.08 * 2.0 * np.sin(2.5 * u) * np.sin(2.0 * v)
+
+    d = z(u, v)
+    Xu = np.stack([zu(u, v) * u + d, zu(u, v) * v, zu(u, v)], 1)
+    Xv = np.stack([zv(u, v) * u, zv(u, v) * v + d, zv(u, v)], 1)
+    nrm = np.cross(Xu, Xv)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm += rng.normal(scale=noise, size=nrm.shape)
+    has = rng.uniform(size=n_points) < with_normal_frac
+    umin, umax = float(u.min() - 0.10), float(u.max() + 0.10)
+    vmin, vmax = float(v.min() - 0.10), float(v.max() + 0.10)
+    return dict(bbs=(umin, umax, 13, vmin, vmax, 15, 1), u_all=u, v_all=v, depth_true=d, u=u[has], v=v[has], normals=nrm[has].astype(np.float32),
+                mean_depth=float(d.mean()))

@@ -191,6 +191,22 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
                     double fy_slot, double lambda, float fx, float fy, int max_iters, double* x, dsh_diffprop* diff, uint8_t* drop,
                     int32_t* info, double* costs);
 
+/* ---- Shape from Normals -------------------------------------------------------------------------
+ * ShapeFromNormals::ShapeFromNormals + ::estimate (Modules/Mapping/ShapeFromNormals.cc:38-171, obtainM :178-260): the
+ * depth B-spline (valdim 1, bbs->valdim is ignored) of a keyframe from the normals of its map points.
+ *   n sites (u[n], v[n] normalised key point coordinates, normals[3n] float32 as stored by Surface::getNormalSurfacePoint;
+ *   the caller filters bad map points / missing normals exactly like obtainM does); bending_weight = the constructor's
+ *   bendingWeight_; mean_depth = DefKeyFrame::accMean; n_all key points (u_all, v_all) receive a surface point.
+ * Least squares  min |M x|^2 + |Bend x|^2 + (sum x - N mean_depth)^2  over the N = nptsu*nptsv control points, then the
+ * reference's scale: ctrl = x / float(median of float(x)) (Surface::saveArray), pts[3 n_all] = float (u d, v d, d) with
+ * d = BBS eval of ctrl (Surface::set3DSurfacePoint).  ctrl_raw (may be NULL) receives x before the scaling.
+ * *ok = 0 (and DSH_OK) when the reference's estimate() would return false: no key points, rank-deficient system, NaN/Inf. */
+int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, double bending_weight,
+                     double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok);
+/* BBS bending matrix (Thirdparty/BBS/bbs.cc:556-641 bending_ur, bbs_coloc.cc:406-508 BendingEigen) as a dense symmetric
+ * N x N matrix, host side (the constant part of the Shape-from-Normals system). */
+int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending);
+
 #ifdef __cplusplus
 }
 #endif

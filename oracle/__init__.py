@@ -344,3 +344,66 @@ def schwarp_fit(bbs, kp1, kp2, invsig, fxs, fys, lam, fx, fy, x0, max_iters=3):
                          D(fxs), D(fys), D(lam), C.c_float(fx), C.c_float(fy), int(max_iters), _p(x, D), _p(diff, C.c_float), _p(drop, C.c_uint8),
                          _p(info, C.c_int32), _p(costs, D))
     return x, diff, drop.astype(bool), info, costs
+
+
+# ---- Shape-from-Normals oracle (sfn_oracle.c) ----------------------------------------------------------
+def sfn_bending(bbs, lam):
+    """Dense N x N bending matrix (restated BBS bending energy)."""
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    N = nu * nv
+    Bm = np.zeros((N, N))
+    D = C.c_double
+    L.sfn_oracle_bending(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), D(lam), _p(Bm, D))
+    return Bm
+
+
+def ref_bbs_bending(bbs, lam):
+    """The reference's own bending_ur (oracle/_ref/libbbs_ref.so): dense symmetric matrix from its CSC upper-right part."""
+    R = ref_bbs_lib()
+    b = _BbsT(*bbs)
+    nu, nv = bbs[2], bbs[5]
+    N = nu * nv
+    pr = np.zeros(N * 32)
+    ir = np.zeros(N * 32, np.uint64)
+    jc = np.zeros(N + 8, np.uint64)
+    D = C.c_double
+    f = R._ZN3BBS10bending_urEPNS_6_bbs_tEdPdPmS3_
+    f.restype = None
+    f(C.byref(b), D(lam), _p(pr, D), _p(ir, C.c_uint64), _p(jc, C.c_uint64))
+    Bm = np.zeros((N, N))
+    for j in range(N):
+        for q in range(int(jc[j]), int(jc[j + 1])):
+            i = int(ir[q])
+            Bm[i, j] = pr[q]
+            Bm[j, i] = pr[q]
+    return Bm
+
+
+def sfn_rows(bbs, u, v, normals):
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)
+    nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    n = u.shape[0]
+    M = np.zeros((2 * n, nu * nv))
+    D = C.c_double
+    L.sfn_oracle_rows(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), n, _p(u, D), _p(v, D), _p(nrm, C.c_float), _p(M, D))
+    return M
+
+
+def sfn_estimate(bbs, u, v, normals, bending_weight, mean_depth, u_all, v_all):
+    """ShapeFromNormals::estimate: returns (ok, ctrl_raw[N], ctrl[N], pts[n_all, 3] float32)."""
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    u = np.ascontiguousarray(u, np.float64); v = np.ascontiguousarray(v, np.float64)
+    ua = np.ascontiguousarray(u_all, np.float64); va = np.ascontiguousarray(v_all, np.float64)
+    nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    N = nu * nv
+    raw = np.zeros(N); ctrl = np.zeros(N)
+    pts = np.zeros((ua.shape[0], 3), np.float32)
+    D = C.c_double
+    L.sfn_oracle_estimate.restype = C.c_int
+    ok = L.sfn_oracle_estimate(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), u.shape[0], _p(u, D), _p(v, D), _p(nrm, C.c_float), D(bending_weight),
+                               D(mean_depth), ua.shape[0], _p(ua, D), _p(va, D), _p(raw, D), _p(ctrl, D), _p(pts, C.c_float))
+    return bool(ok), raw, ctrl, pts
