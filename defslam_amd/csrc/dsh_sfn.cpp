@@ -20,6 +20,8 @@ extern "C" int nrsfm_swp_solve_np(int);
 extern "C" hipError_t nrsfm_sfn_rows(double, double, int, double, double, int, int, const double*, const double*, const float*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_sfn_residual(int, int, const double*, const double*, const double*, double, double*, hipStream_t);
 extern "C" hipError_t nrsfm_sfn_axpy(int, const double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_warp_coloc(double, double, int, double, double, int, int, const float*, const float*, double*, double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_mat_add(size_t, const double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_sfn_points(double, double, int, double, double, int, const double*, int, const double*, const double*, float*, hipStream_t);
 
 namespace {
@@ -160,6 +162,50 @@ int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, c
   HIPCHK(c, hipMemcpyAsync(pts, dpts.p, 12 * (size_t)n_all, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   *ok = 1;
+  return DSH_OK;
+}
+
+int dsh_warp_initialize(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, double lambda, double* x, int32_t* ok) {
+  dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
+  if (!c) return DSH_ERR_ARG;
+  if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_warp_initialize: host-only context, no GPU (there is no CPU fallback)");
+  if (!bbs_ok(bbs) || P <= 0 || !kp1 || !kp2 || !x || !ok) return dsh_fail(c, DSH_ERR_ARG, "dsh_warp_initialize: bad argument");
+  const int N = bbs->nptsu * bbs->nptsv;
+  if (N > 512) return dsh_fail(c, DSH_ERR_ARG, "dsh_warp_initialize: more than 512 control points (one-workgroup solve)");
+  *ok = 0;
+  if (hipSetDevice(c->device) != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, "dsh_warp_initialize: hipSetDevice failed");
+  c->scratch.reset();
+  hipStream_t st = c->stream;
+  const int np = nrsfm_swp_solve_np(N);
+  DevBuf dC, dr0, dr1, dG, dB, dg0, dg1, dM, dW, dx, dones, dscal, dk1, dk2;
+  HIPCHK(c, dC.alloc(c, 8 * (size_t)P * N)); HIPCHK(c, dr0.alloc(c, 8 * (size_t)P)); HIPCHK(c, dr1.alloc(c, 8 * (size_t)P));
+  HIPCHK(c, dG.alloc(c, 8 * (size_t)N * N)); HIPCHK(c, dB.alloc(c, 8 * (size_t)N * N)); HIPCHK(c, dg0.alloc(c, 8 * (size_t)N)); HIPCHK(c, dg1.alloc(c, 8 * (size_t)N));
+  HIPCHK(c, dM.alloc(c, 8 * (size_t)np * np)); HIPCHK(c, dW.alloc(c, 8 * (size_t)np * 16)); HIPCHK(c, dx.alloc(c, 8 * (size_t)2 * N));
+  HIPCHK(c, dones.alloc(c, 8 * (size_t)N)); HIPCHK(c, dscal.alloc(c, 256)); HIPCHK(c, dk1.alloc(c, 8 * (size_t)P)); HIPCHK(c, dk2.alloc(c, 8 * (size_t)P));
+  std::vector<double> Bm((size_t)N * N), ones((size_t)N, 1.0);
+  bending_dense(bbs, lambda, Bm.data());
+  HIPCHK(c, hipMemcpyAsync(dB.p, Bm.data(), 8 * Bm.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dones.p, ones.data(), 8 * (size_t)N, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dk1.p, kp1, 8 * (size_t)P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dk2.p, kp2, 8 * (size_t)P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(dC.p, 0, 8 * (size_t)P * N, st));
+  HIPCHK(c, hipMemsetAsync(dscal.p, 0, 256, st));
+  HIPCHK(c, nrsfm_warp_coloc(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, P, dk1.as<float>(), dk2.as<float>(), dC.as<double>(), dr0.as<double>(),
+                             dr1.as<double>(), st));
+  double* scal = dscal.as<double>();
+  // g1 = C^T (-q2y) first (G is rebuilt by the second call), then G = C^T C, g0 = C^T (-q2x); G += Bending
+  HIPCHK(c, nrsfm_swp_normal(0, P, N, dC.as<double>(), dr1.as<double>(), dones.as<double>(), scal, dG.as<double>(), dg1.as<double>(), st));
+  HIPCHK(c, nrsfm_swp_normal(0, P, N, dC.as<double>(), dr0.as<double>(), dones.as<double>(), scal, dG.as<double>(), dg0.as<double>(), st));
+  HIPCHK(c, nrsfm_mat_add((size_t)N * N, dB.as<double>(), dG.as<double>(), st));
+  HIPCHK(c, nrsfm_swp_solve(N, dG.as<double>(), dg0.as<double>(), 1e300, dM.as<double>(), dW.as<double>(), dx.as<double>(), scal + 2, st));
+  HIPCHK(c, nrsfm_swp_resolve(N, dg1.as<double>(), dM.as<double>(), dW.as<double>(), dx.as<double>() + N, st));
+  double s8[8];
+  HIPCHK(c, hipMemcpyAsync(x, dx.p, 8 * (size_t)2 * N, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(s8, dscal.p, 64, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  bool finite = true;
+  for (int i = 0; i < 2 * N; i++) finite = finite && std::isfinite(x[i]);
+  *ok = ((s8[2] != 0.0 || s8[3] != 0.0) && finite) ? 1 : 0;
   return DSH_OK;
 }
 

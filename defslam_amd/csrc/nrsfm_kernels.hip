@@ -821,6 +821,30 @@ __global__ void sfn_rows_kernel(BbsPar p, int n, const double* __restrict__ u, c
     }
 }
 
+// Colocation rows of Warps::Warp::initialize (Schwarp.cc:136-139): C[k, :] = 16 B-spline weights of key point k (float32 pair),
+// rhs[k] = -kp2 coordinate `coord` (negated: swp_solve_kernel returns M dx = -g).  C is P x N row-major and zeroed beforehand.
+__global__ void warp_coloc_kernel(BbsPar p, int P, const float* __restrict__ kp1, const float* __restrict__ kp2, int N, double* __restrict__ Cm,
+                                  double* __restrict__ rhs0, double* __restrict__ rhs1) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  rhs0[k] = -(double)kp2[2 * k];
+  rhs1[k] = -(double)kp2[2 * k + 1];
+  double nu, nv, bu[4], bv[4];
+  int Iu, Iv;
+  norm_inter(p.umin, p.umax, p.nptsu, (double)kp1[2 * k], nu, Iu);
+  norm_inter(p.vmin, p.vmax, p.nptsv, (double)kp1[2 * k + 1], nv, Iv);
+  if (Iu < 0 || Iu > p.nptsu - 4 || Iv < 0 || Iv > p.nptsv - 4) return;
+  cubic_basis(0, nu, bu);
+  cubic_basis(0, nv, bv);
+  for (int iu = 0; iu < 4; iu++)
+    for (int iv = 0; iv < 4; iv++) Cm[(size_t)k * N + (iu + Iu) * p.nptsv + iv + Iv] = bu[iu] * bv[iv];
+}
+
+__global__ void mat_add_kernel(size_t n, const double* __restrict__ B, double* __restrict__ A) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) A[i] += B[i];
+}
+
 // out[i] = sign * (b[i] - A[i,:] x): one wavefront per row
 __global__ __launch_bounds__(256) void sfn_residual_kernel(int m, int N, const double* __restrict__ A, const double* __restrict__ x, const double* __restrict__ b,
                                                            double sign, double* __restrict__ out) {
@@ -1029,5 +1053,16 @@ extern "C" hipError_t nrsfm_sfn_points(double umin, double umax, int nu, double 
                                        const double* v, float* pts, hipStream_t st) {
   BbsPar p = {umin, umax, vmin, vmax, nu, nv, 1, 0};
   if (n > 0) hipLaunchKernelGGL(sfn_points_kernel, dim3((n + 127) / 128), dim3(128), 0, st, p, ctrl, n, u, v, pts);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nrsfm_warp_coloc(double umin, double umax, int nu, double vmin, double vmax, int nv, int P, const float* kp1, const float* kp2, double* Cm,
+                                       double* rhs0, double* rhs1, hipStream_t st) {
+  BbsPar p = {umin, umax, vmin, vmax, nu, nv, 1, 0};
+  hipLaunchKernelGGL(warp_coloc_kernel, dim3((P + 127) / 128), dim3(128), 0, st, p, P, kp1, kp2, nu * nv, Cm, rhs0, rhs1);
+  return hipGetLastError();
+}
+extern "C" hipError_t nrsfm_mat_add(size_t n, const double* B, double* A, hipStream_t st) {
+  hipLaunchKernelGGL(mat_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, B, A);
   return hipGetLastError();
 }

@@ -155,3 +155,15 @@ def ShapeFromNormals(ctx: Context, bbs: Bbs, u, v, normals, bending_weight: floa
                                        float(mean_depth), ua.shape[0], _ptr(ua, C.c_double), _ptr(va, C.c_double), _ptr(raw, C.c_double), _ptr(ctrl, C.c_double),
                                        _ptr(pts, C.c_float), C.byref(ok)), "dsh_sfn_estimate")
     return bool(ok.value), raw, ctrl, pts
+
+
+def WarpInitialize(ctx: Context, bbs: Bbs, kp1, kp2, lam: float):
+    """Warps::Warp::initialize: returns (ok, x[2N])."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    x = np.zeros(2 * bbs.nptsu * bbs.nptsv)
+    ok = C.c_int32(0)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_warp_initialize(ctx._h, C.byref(b), kp1.shape[0], _ptr(kp1, C.c_float), _ptr(kp2, C.c_float), float(lam), _ptr(x, C.c_double), C.byref(ok)),
+               "dsh_warp_initialize")
+    return bool(ok.value), x

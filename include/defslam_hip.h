@@ -203,6 +203,11 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
  * *ok = 0 (and DSH_OK) when the reference's estimate() would return false: no key points, rank-deficient system, NaN/Inf. */
 int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, double bending_weight,
                      double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok);
+/* Warps::Warp::initialize (Modules/Mapping/Schwarp.cc:99-160): the control points of the warp kp1 -> kp2 that start the
+ * Schwarzian fit, (C^T C + Bending(lambda)) X = C^T kp2 with C the colocation matrix of the P key points kp1 (float32 x,y
+ * pairs, normalised coordinates).  x[2N]: first coordinate of the N control points, then the second (the layout
+ * dsh_schwarp_fit takes).  *ok = 0 when the matrix is not positive definite (too few matches for this lambda). */
+int dsh_warp_initialize(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, double lambda, double* x, int32_t* ok);
 /* BBS bending matrix (Thirdparty/BBS/bbs.cc:556-641 bending_ur, bbs_coloc.cc:406-508 BendingEigen) as a dense symmetric
  * N x N matrix, host side (the constant part of the Shape-from-Normals system). */
 int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending);

@@ -407,3 +407,16 @@ def sfn_estimate(bbs, u, v, normals, bending_weight, mean_depth, u_all, v_all):
     ok = L.sfn_oracle_estimate(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), u.shape[0], _p(u, D), _p(v, D), _p(nrm, C.c_float), D(bending_weight),
                                D(mean_depth), ua.shape[0], _p(ua, D), _p(va, D), _p(raw, D), _p(ctrl, D), _p(pts, C.c_float))
     return bool(ok), raw, ctrl, pts
+
+
+def warp_initialize(bbs, kp1, kp2, lam):
+    """Warps::Warp::initialize: returns (ok, x[2N])."""
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    x = np.zeros(2 * nu * nv)
+    D = C.c_double
+    L.warp_oracle_initialize.restype = C.c_int
+    ok = L.warp_oracle_initialize(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), kp1.shape[0], _p(kp1, C.c_float), _p(kp2, C.c_float), D(lam), _p(x, D))
+    return bool(ok), x

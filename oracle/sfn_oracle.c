@@ -190,3 +190,50 @@ int sfn_oracle_estimate(double umin, double umax, int nptsu, double vmin, double
   free(depth);
   return 1;
 }
+
+
+/* Warps::Warp::initialize (Modules/Mapping/Schwarp.cc:99-160): control points of the warp kp1 -> kp2 from the regularised
+ * linear least squares  (C^T C + Bending(lambda)) X = C^T q2,  C = colocation matrix of kp1 (P x N), X is N x 2 stored
+ * column-major in x[2N].  The reference solves with Eigen::SimplicialLDLT (sparse LDLT) -> UNPINNED; restated with a dense
+ * Cholesky.  Returns 1 on success, 0 when the matrix is not positive definite. */
+int warp_oracle_initialize(double umin, double umax, int nptsu, double vmin, double vmax, int nptsv, int P, const float* kp1, const float* kp2, double lambda,
+                           double* x) {
+  const int N = nptsu * nptsv;
+  double* u = (double*)malloc(sizeof(double) * (size_t)P);
+  double* v = (double*)malloc(sizeof(double) * (size_t)P);
+  int32_t* cols = (int32_t*)malloc(sizeof(int32_t) * 16 * (size_t)P);
+  double* w = (double*)malloc(sizeof(double) * 16 * (size_t)P);
+  double* G = (double*)malloc(sizeof(double) * (size_t)N * N);
+  for (int i = 0; i < P; i++) { u[i] = kp1[2 * i]; v[i] = kp1[2 * i + 1]; }
+  bbs_oracle_coloc(umin, umax, nptsu, vmin, vmax, nptsv, u, v, P, 0, 0, cols, w);
+  sfn_oracle_bending(umin, umax, nptsu, vmin, vmax, nptsv, lambda, G);
+  for (int j = 0; j < 2 * N; j++) x[j] = 0.0;
+  for (int i = 0; i < P; i++)
+    for (int a = 0; a < 16; a++) {
+      const int ca = cols[16 * i + a];
+      if (ca < 0) continue;
+      for (int b = 0; b < 16; b++) G[(size_t)ca * N + cols[16 * i + b]] += w[16 * i + a] * w[16 * i + b];
+      x[ca] += w[16 * i + a] * (double)kp2[2 * i];
+      x[N + ca] += w[16 * i + a] * (double)kp2[2 * i + 1];
+    }
+  int ok = 1;
+  for (int k = 0; k < N && ok; k++) {          /* in-place Cholesky, lower */
+    double d = G[(size_t)k * N + k];
+    for (int j = 0; j < k; j++) d -= G[(size_t)k * N + j] * G[(size_t)k * N + j];
+    if (!(d > 0)) { ok = 0; break; }
+    const double piv = sqrt(d);
+    G[(size_t)k * N + k] = piv;
+    for (int r = k + 1; r < N; r++) {
+      double t = G[(size_t)r * N + k];
+      for (int j = 0; j < k; j++) t -= G[(size_t)r * N + j] * G[(size_t)k * N + j];
+      G[(size_t)r * N + k] = t / piv;
+    }
+  }
+  for (int c = 0; c < 2 && ok; c++) {
+    double* y = x + (size_t)c * N;
+    for (int i = 0; i < N; i++) { double t = y[i]; for (int j = 0; j < i; j++) t -= G[(size_t)i * N + j] * y[j]; y[i] = t / G[(size_t)i * N + i]; }
+    for (int i = N - 1; i >= 0; i--) { double t = y[i]; for (int j = i + 1; j < N; j++) t -= G[(size_t)j * N + i] * y[j]; y[i] = t / G[(size_t)i * N + i]; }
+  }
+  free(u); free(v); free(cols); free(w); free(G);
+  return ok;
+}

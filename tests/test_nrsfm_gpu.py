@@ -181,3 +181,21 @@ def test_shape_from_normals_edge_cases(gpu_ctx, oracle_mod):
     ok0, raw0, *_ = nrsfm.ShapeFromNormals(gpu_ctx, b, sc["u"], sc["v"], sc["normals"], 1e-3, sc["mean_depth"], sc["u_all"], sc["v_all"])
     assert ok0 and ok1
     np.testing.assert_allclose(raw1, raw0, rtol=0, atol=1e-9 * np.abs(raw0).max())
+
+
+@pytest.mark.parametrize("P,seed,lam", [(400, 3, 1e-2), (60, 8, 1.0), (1500, 1, 1e-4)])
+def test_warp_initialize_matches_oracle(gpu_ctx, oracle_mod, P, seed, lam):
+    """Warps::Warp::initialize (SURVEY 8f rank 2, first half): regularised linear fit of the warp control points."""
+    from defslam_amd import nrsfm, synth
+    pr = synth.make_warp_problem(P, seed)
+    oko, xo = oracle_mod.warp_initialize(pr["bbs"], pr["kp1"], pr["kp2"], lam)
+    okg, xg = nrsfm.WarpInitialize(gpu_ctx, nrsfm.Bbs(*pr["bbs"]), pr["kp1"], pr["kp2"], lam)
+    assert oko and okg
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-9 * np.abs(xo).max())
+    # the fitted warp maps kp1 close to kp2 (smooth synthetic warp, small lambda)
+    if lam <= 1e-2:
+        b = nrsfm.Bbs(*pr["bbs"])
+        N = b.nptsu * b.nptsv
+        val, _ = nrsfm.bbs_eval(gpu_ctx, nrsfm.Bbs(b.umin, b.umax, b.nptsu, b.vmin, b.vmax, b.nptsv, 2), np.stack([xg[:N], xg[N:]]).T.reshape(-1),
+                                pr["kp1"][:, 0].astype(float), pr["kp1"][:, 1].astype(float))
+        assert np.abs(val - pr["kp2"]).max() < 0.02
