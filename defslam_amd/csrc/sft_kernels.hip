@@ -923,81 +923,82 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
     int I[RPW];                                     // tile rows held by this wave inside the window [kc, kc+BT-1]
 #pragma unroll
     for (int t = 0; t < RPW; t++) I[t] = kc + ((wave + NW * t - kc) & (BT - 1));
-    double an[RPW][4], bn[4];
-    if (k >= 0) {
+    double an[RPW][4], bn[4];   // one ring row per wave: kept for the rest of the window; two rows: re-read where needed (registers)
+    if constexpr (RPW == 1) {
+      if (k >= 0) {
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-#pragma unroll
-        for (int t = 0; t < RPW; t++) an[t][kk] = -Xp[(I[t] - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
-        bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];                 // border panel
-      }
-      // block column kc first: it is what the next step needs published
-      if (!(mode & 4)) {
-        double bc[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) bc[kk] = Xp[TILE_LDS + (4 * kk + crow) * TP + ccol];
-#pragma unroll
-        for (int c = 0; c < BT; c++)
-          if (c == kslot) {
-#pragma unroll
-            for (int t = 0; t < RPW; t++)
-              if (I[t] < nT) {   // two accumulation chains halve the dependent-MFMA latency of the critical tile
-                v4d side = {0.0, 0.0, 0.0, 0.0};
-                acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][0], bc[0], acc[t][c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep the two chains interleaved (the scheduler would serialise them)
-                side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][1], bc[1], side, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][2], bc[2], acc[t][c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[t][3], bc[3], side, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[t][c] += side;
-              }
-          }
-#pragma unroll
-        for (int t = 0; t < RPW; t++)
-          if (((wave + NW * t + BOFF) & (BT - 1)) == kslot) {   // holder of the border tile of column kc: update, publish below
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) bacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bc[kk], bacc[t], 0, 0, 0);
-          }
+        for (int kk = 0; kk < 4; kk++) {
+          an[0][kk] = -Xp[(I[0] - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+          bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];                 // border panel
+        }
       }
     }
-    ST_MARK(3);
+    // block column kc first: it is what the next step needs published.  Update, then publish / hand to the factorisation
+    // straight from the accumulator (no copies of the tiles are kept).
+    v4d dtile = {0.0, 0.0, 0.0, 0.0};
     bool owner = false;
-    if (kc < nT) {
-      v4d colt[RPW];
+    {
+      double bc[4] = {0.0, 0.0, 0.0, 0.0};
+      const bool upd = k >= 0 && !(mode & 4);
+      if (upd) {
 #pragma unroll
-      for (int t = 0; t < RPW; t++) colt[t] = acc[t][0];
+        for (int kk = 0; kk < 4; kk++) bc[kk] = Xp[TILE_LDS + (4 * kk + crow) * TP + ccol];
+      }
 #pragma unroll
-      for (int c = 1; c < BT; c++)
+      for (int c = 0; c < BT; c++)
         if (c == kslot) {
 #pragma unroll
-          for (int t = 0; t < RPW; t++) colt[t] = acc[t][c];
-        }
-      v4d dtile = colt[0];
+          for (int t = 0; t < RPW; t++) {
+            if (upd && I[t] < nT) {   // two accumulation chains halve the dependent-MFMA latency of the critical tile
+              double a4[4];
 #pragma unroll
-      for (int t = 0; t < RPW; t++) {
-        if (I[t] == kc) {
-          owner = true;
-          dtile = colt[t];
-        } else {
-          // publish tile (I, kc) of block column kc
-          lds_double* dst = Araw + (I[t] - kc) * TILE_LDS + ccol * TP + crow;
+              for (int kk = 0; kk < 4; kk++) a4[kk] = (RPW == 1) ? an[t][kk] : -Xp[(I[t] - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+              v4d side = {0.0, 0.0, 0.0, 0.0};
+              acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], bc[0], acc[t][c], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);   // keep the two chains interleaved (the scheduler would serialise them)
+              side = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], bc[1], side, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], bc[2], acc[t][c], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              side = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], bc[3], side, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              acc[t][c] += side;
+            }
+            if (kc < nT) {
+              if (I[t] == kc) {
+                owner = true;
+                dtile = acc[t][c];
+              } else {   // publish tile (I, kc) of block column kc
+                lds_double* dst = Araw + (I[t] - kc) * TILE_LDS + ccol * TP + crow;
 #pragma unroll
-          for (int q = 0; q < 4; q++) dst[4 * q] = colt[t][q];
+                for (int q = 0; q < 4; q++) dst[4 * q] = acc[t][c][q];
+              }
+            }
+          }
         }
-      }
+      ST_MARK(3);
+#pragma unroll
+      for (int t = 0; t < RPW; t++)
+        if (((wave + NW * t + BOFF) & (BT - 1)) == kslot) {   // holder of the border tile of column kc: update and publish for the next C phase
+          if (upd) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const double b4 = (RPW == 1) ? bn[kk] : -Xp[(4 * kk + crow) * TP + ccol];
+              bacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b4, bc[kk], bacc[t], 0, 0, 0);
+            }
+          }
+          if (kc < nT) {
+            Abord[crow * TS + ccol] = bacc[t][0];
+            if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[t][1];
+          }
+        }
+    }
+    if (kc < nT) {
       if (memwave) {
         lds_double* dst = Araw + BT * TILE_LDS + ccol * TP + crow;
 #pragma unroll
         for (int q = 0; q < 4; q++) dst[4 * q] = fr8[q];
       }
-#pragma unroll
-      for (int t = 0; t < RPW; t++)
-        if (((wave + NW * t + BOFF) & (BT - 1)) == kslot) {   // border block of column kc for the next C phase
-          Abord[crow * TS + ccol] = bacc[t][0];
-          if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[t][1];
-        }
       if (owner) {
         // owner of tile row kc: factor the diagonal tile (critical path)
         __builtin_amdgcn_s_setprio(3);
