@@ -297,7 +297,9 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
   h.tile_mode = (h.kd <= kTS * kBT) ? 1 : 0;
   h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
-  if (const char* dm = std::getenv("DSH_EXPERIMENT")) h.mode = std::atoi(dm) & ~1;  // timing experiments only (results invalid)
+#ifdef SFT_EXPERIMENTS
+  if (const char* dm = std::getenv("DSH_EXPERIMENT")) h.mode = std::atoi(dm) & ~1;  // tuning builds only: phases switched off, results invalid
+#endif
   h.fx = f.K[0]; h.fy = f.K[1]; h.cx = f.K[2]; h.cy = f.K[3];
   h.w_ref = f.reg_temp / std::pow(t.median_L, 2);              // DefOptimizer.cc:378
   h.w_curv = f.reg_lap / (double)nA;                           // :458  (|OptLap|)

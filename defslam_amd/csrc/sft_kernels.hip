@@ -732,41 +732,6 @@ __device__ void factor_and_solve(const SftDev& P, Ctl* ctl, double* panel, doubl
 // (prefetched H tiles must not be drained at every step; L tiles are first re-read after the loop).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Cholesky A = L L^T of the symmetric 16x16 tile `a` (accumulator layout: lane (g = l>>4, c = l&15),
-// register q holds A[g+4q][c]) and W = L^-1, both by rank-1 MFMA updates executed by ONE wavefront:
-//   step j: l = A[:,j] / sqrt(A[j][j])  (row j of the symmetric tile = lanes 16*(j&3).., register j>>2)
-//           A -= l l^T                   (one v_mfma_f64_16x16x4 with only k = j&3 populated)
-//           W[j,:] /= L[j][j];  W -= (l - e_j) W[j,:]     (second MFMA, same operand lanes)
-// The next pivot is formed ahead of the MFMA result (A[j+1][j+1] - l[j+1]^2) so the rsqrt chain overlaps it.
-// Returns false when a pivot is not positive.
-__device__ __forceinline__ bool chol_inv_mfma(v4d& a, v4d& w) {
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, c = lane & 15;
-  w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
-  bool bad = false;
-  double pd = bcast_lane(a[0], 0);     // A[0][0]: lane 0, register 0
-#pragma unroll
-  for (int j = 0; j < TS; j++) {
-    const int gj = j & 3, qj = j >> 2;
-    if (!(pd > 0.0)) bad = true;
-    double inv, sq;
-    rsqrt_sqrt(pd, inv, sq);
-    const double m = (g == gj) ? inv : 0.0;          // operand lanes of this step
-    const double la = a[qj] * m;                       // l[c] in lanes (gj, c), 0 elsewhere
-    if (j + 1 < TS) {                                  // next pivot ahead of the MFMA: A[j+1][j+1] - l[j+1]^2
-      const double an = bcast_lane(a[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1);
-      const double ln = bcast_lane(la, 16 * gj + j + 1);
-      pd = fma(-ln, ln, an);
-    }
-    const double nla = -la;
-    a = __builtin_amdgcn_mfma_f64_16x16x4f64(nla, la, a, 0, 0, 0);
-    const double wr = w[qj] * m;                       // W[j][c] / L[j][j] (previous W update has landed by now)
-    const double u = (g == gj && c == j) ? (nla + 1.0) : nla;   // -(l - e_j)
-    w = __builtin_amdgcn_mfma_f64_16x16x4f64(u, wr, w, 0, 0, 0);
-  }
-  return !bad;
-}
-
 // The solver workspace lives in LDS.  A non-inlined function only sees a generic pointer; the explicit address space keeps
 // its accesses on ds_* instructions (generic = flat_* instructions, which count on both the LDS and the memory counter).
 using lds_double = __attribute__((address_space(3))) double;
@@ -811,7 +776,12 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   const auto Lg = uni(P.Lb);
   const auto Lbord = uni(P.Lbord);
   const auto Linv_g = uni(P.Linv);
-  const int mode = uni(P.mode);   // every P.* used inside the step loop is hoisted: the struct lives in global memory
+#ifdef SFT_EXPERIMENTS   // tuning builds only (EXTRA=-DSFT_EXPERIMENTS): DSH_EXPERIMENT bits switch phases off, results are then invalid
+  const int mode = uni(P.mode);
+#define SFT_EXP(bit) ((mode & (bit)) != 0)
+#else
+#define SFT_EXP(bit) false
+#endif
   ST_BEGIN();
   v4d acc[RPW][BT];
   v4d bacc[RPW];                        // border tiles of ring columns (wave + NW*t + BOFF) mod BT: never on the wave that factors that column
@@ -876,7 +846,7 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
       for (int t = 0; t < RPW; t++)   // the holder of ring column k mod BT (consumed by now) fetches the border block of column k+BT
         if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
     }
-    if (k >= 0 && !(mode & 16)) {
+    if (k >= 0 && !SFT_EXP(16)) {
       // ---- C(k): X_i = A_i Linv^T (RPW sub-diagonal tiles per wave), border panel on 16 lanes per border row ------
       v4d x[RPW], x2[RPW];
       double bv[4];
@@ -939,7 +909,7 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
     bool owner = false;
     {
       double bc[4] = {0.0, 0.0, 0.0, 0.0};
-      const bool upd = k >= 0 && !(mode & 4);
+      const bool upd = k >= 0 && !SFT_EXP(4);
       if (upd) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) bc[kk] = Xp[TILE_LDS + (4 * kk + crow) * TP + ccol];
@@ -1007,7 +977,7 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
           if (crow + 4 * q == ccol && TS * kc + ccol < Dn) dtile[q] += lambda;
         v4d w = dtile;
         ST_MARK(4);
-        const bool ok = (mode & 8) ? true : ((mode & 64) ? chol_inv_mfma(dtile, w) : chol_inv_blocked(dtile, w));
+        const bool ok = SFT_EXP(8) ? true : chol_inv_blocked(dtile, w);
         ST_MARK(5);
         if (!ok && lane == 0) ctl->fact_ok = 0;
         lds_double* dst = LinvK + ccol * TP + crow;
@@ -1031,7 +1001,7 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
           bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];
         }
       }
-      if (more && !(mode & 4)) {
+      if (more && !SFT_EXP(4)) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
           // one batch of LDS reads per k-chunk (a single wait), then MFMAs on independent accumulators back to back
@@ -1063,7 +1033,7 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
         for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
       }
     }
-    if (memwave && k >= 0 && !(mode & 16) && !(mode & 32)) {
+    if (memwave && k >= 0 && !SFT_EXP(16) && !SFT_EXP(32)) {
       // block column k of L goes to global memory from the LDS panel (native tile layout), border rows included
 #pragma unroll
       for (int i = 1; i <= BT; i++)

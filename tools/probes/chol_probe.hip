@@ -1,4 +1,4 @@
-// Probe: cycles of the rank-1-MFMA 16x16 Cholesky(+inverse) used by factor_tiles, one wavefront.
+// Probe: cycles of the 16x16 Cholesky(+inverse) tile kernels, one wavefront: the first (rank-1 MFMA) variant, kept here for the record, and the blocked one factor_tiles uses (tile_chol.h).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
