@@ -468,6 +468,15 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
       if ((v == 4 && all_tiles) || v == 8) nw = v;
     }
   }
+  // 8-wave shape: barrier-free (dataflow) factor steps unless DSH_SFT_DATAFLOW=0 asks for the barrier version (A/B tests)
+  {
+    bool dataflow = true;
+    if (const char* e = std::getenv("DSH_SFT_DATAFLOW")) dataflow = std::atoi(e) != 0;
+    for (int b = 0; b < B; b++) {
+      SftDev& hh = c->packed[b].h;
+      hh.mode = (hh.mode & ~2) | ((nw == 8 && hh.tile_mode && dataflow) ? 2 : 0);
+    }
+  }
   const size_t jl_cap = (nw == 4 ? 72 : 96) * 1024;
   for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to the solver workspace
     SftDev& hh = c->packed[b].h;
@@ -578,7 +587,7 @@ int dsh_sft_batch_phase_ms(dsh_ctx* c, int b, double* out8) {
     for (int w = 0; w < 8; w++) if (t[16 + 8 * w] > 0 && t[16 + 8 * w] < t0) t0 = t[16 + 8 * w];
     for (int w = 0; w < 8; w++) {
       std::printf("wave %d:", w);
-      for (int e = 0; e < 8; e++) std::printf(" %8.0f", t[16 + 8 * w + e] > 0 ? t[16 + 8 * w + e] - t0 : -1.0);
+      for (int e = 0; e < 8; e++) std::printf(" %8.0f", t[16 + 8 * w + e] > 0 ? t[16 + 8 * w + e] - (std::getenv("DSH_SFT_DATAFLOW") ? 0.0 : t0) : -1.0);
       std::printf("\n");
     }
   }
@@ -683,11 +692,12 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   SftDev h = c->h_probs[b];
   if (D != 6 + h.Dn) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: D mismatch");
   // flip the mode of this one problem, run it alone, restore
+  const int32_t mode_saved = h.mode;
   h.mode = 1;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  h.mode = 0;
+  h.mode = mode_saved;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
   const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;

@@ -153,20 +153,25 @@ def test_batch_equals_single_and_is_reproducible(gpu_ctx):
 @pytest.mark.parametrize("cfg,pid", [("smoke", 3), ("C2", 5)])
 def test_four_wavefront_launch_shape_matches_eight(gpu_ctx, oracle_mod, cfg, pid, monkeypatch):
     """The throughput launch shape (4 wavefronts per problem, two ring rows per wave, chosen by the library once a batch
-    holds >= 2 problems per CU) runs the same factorisation as the latency shape: same LM trajectory as the oracle,
-    vertices equal to the 8-wavefront result to rounding."""
+    holds >= 2 problems per CU) and the barrier version of the 8-wavefront shape run the same factorisation as the default
+    (8 wavefronts, barrier-free dataflow steps): same LM trajectory as the oracle, vertices equal to rounding."""
     from defslam_amd import sft, synth
     tmpl, fr = synth.make_problem(cfg, pid)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
     out = {}
-    for nw in ("8", "4"):
+    for nw, df in (("8", "1"), ("4", "1"), ("8", "0")):
         monkeypatch.setenv("DSH_SFT_WAVES", nw)     # read by dsh_sft_batch_upload
+        monkeypatch.setenv("DSH_SFT_DATAFLOW", df)  # 8 waves: barrier-free steps (default) or the barrier version
         f = sft.frame_from_synth(fr)
         inl = sft.DefPoseOptimization(gpu_ctx, f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
-        out[nw] = (f, inl)
+        out[nw + df] = (f, inl)
     monkeypatch.delenv("DSH_SFT_WAVES")
-    f8, i8 = out["8"]
-    f4, i4 = out["4"]
+    monkeypatch.delenv("DSH_SFT_DATAFLOW")
+    f8, i8 = out["81"]
+    f4, i4 = out["41"]
+    fb, ib = out["80"]
+    assert ib == i8 and fb.iters == f8.iters and fb.trials == f8.trials
+    assert np.abs(fb.nodes_xyz - f8.nodes_xyz).max() < 1e-10 * np.abs(f8.nodes_xyz).max()
     assert i4 == i8 and f4.iters == f8.iters and f4.trials == f8.trials
     np.testing.assert_array_equal(f4.mvbOutlier, f8.mvbOutlier)
     assert np.abs(f4.nodes_xyz - f8.nodes_xyz).max() < 1e-10 * np.abs(f8.nodes_xyz).max()

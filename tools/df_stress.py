@@ -1,0 +1,25 @@
+"""Stress: barrier-free factor steps vs the barrier version on many problems, bit for bit, repeated."""
+import os, sys, numpy as np
+sys.path.insert(0, '.')
+from defslam_amd import synth, sft
+ctx = sft.Context(0)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+rows, cols, m = synth.CONFIGS[cfg]
+tmpl = synth.make_grid_template(rows, cols)
+ctx.template_build(tmpl.xyz0, tmpl.facets)
+def run(df):
+    os.environ["DSH_SFT_WAVES"] = "8"
+    os.environ["DSH_SFT_DATAFLOW"] = df
+    frames = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(B)]
+    inl = sft.DefPoseOptimizationBatch(ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    return np.stack([f.nodes_xyz for f in frames]), np.array([f.trials for f in frames]), np.array(inl)
+ref = run("0")
+bad = 0
+for r in range(reps):
+    cur = run("1")
+    same = np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1]) and np.array_equal(cur[2], ref[2])
+    print(f"rep {r}: dataflow == barrier bit for bit: {same}; max |diff| {np.abs(cur[0] - ref[0]).max():.3e}")
+    bad += not same
+sys.exit(1 if bad else 0)
