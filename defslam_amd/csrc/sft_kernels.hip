@@ -1457,7 +1457,7 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   };
   // Tiles of the next PF blocks are in flight (register ring, the block loop is unrolled PF times): under load the
   // L tiles come from HBM, one block of look-ahead does not cover that latency.
-  constexpr int PF = 3;
+  constexpr int PF = 3;   // measured: 3 and 4 equal, 8 loses to register pressure
   Pre ring[PF];
 #pragma unroll
   for (int j = 0; j < PF; j++) ring[j] = fetch(nT - 1 - j);
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(64 * NW, 2) void sft_lm_kernel(const SftDev* __rest
       double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
       PH_ADD(7);
       if (P.tile_mode) {
-        if (NW == 8 && (P.mode & 2)) factor_tiles_df(P, ctl, panel);
+        if (NW == 8 && (P.mode & 2)) { PH_RESET(); factor_tiles_df(P, ctl, panel); PH_ADD(5); }
         else factor_tiles<NW>(P, ctl, panel);
         PH_RESET();
         backsub_tiles<NW>(P, ctl, panel);
