@@ -468,13 +468,13 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
       if ((v == 4 && all_tiles) || v == 8) nw = v;
     }
   }
-  // 8-wave shape: barrier-free (dataflow) factor steps unless DSH_SFT_DATAFLOW=0 asks for the barrier version (A/B tests)
+  // tile mode: barrier-free (dataflow) factor steps unless DSH_SFT_DATAFLOW=0 asks for the barrier version (A/B tests)
   {
     bool dataflow = true;
     if (const char* e = std::getenv("DSH_SFT_DATAFLOW")) dataflow = std::atoi(e) != 0;
     for (int b = 0; b < B; b++) {
       SftDev& hh = c->packed[b].h;
-      hh.mode = (hh.mode & ~2) | ((nw == 8 && hh.tile_mode && dataflow) ? 2 : 0);
+      hh.mode = (hh.mode & ~2) | ((hh.tile_mode && dataflow) ? 2 : 0);
     }
   }
   const size_t jl_cap = (nw == 4 ? 72 : 96) * 1024;

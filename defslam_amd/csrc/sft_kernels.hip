@@ -16,6 +16,7 @@
 //
 // Every sum is evaluated in a fixed order (no atomics), so a run is bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <math.h>
@@ -1119,7 +1120,9 @@ __device__ __forceinline__ void flags_wait(lds_int* flags, int lo, int hi, int v
   asm volatile("" ::: "memory");
 }
 
-__device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* ws) {
+// 8-wavefront specialisation (one ring row per wave): the same algorithm as factor_tiles_df<NW> below written without the
+// per-row loops -- the compiler allocates registers noticeably better for it (10.8 vs 12.0 ms per C2 problem).
+__device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double* ws) {
   constexpr int NW = 8, NT = 64 * NW, BOFF = 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1132,7 +1135,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   lds_double* AbordB = LinvB + 3 * TILE_LDS;                   // 3 x 7x16 border block
   lds_double* Cn = AbordB + 3 * SFT_BORDER * TS;               // 7x7 corner
   lds_int* F = (lds_int*)(Cn + 64);                            // flags: [0] W ready (column), [1] border block ready, [2..10] X tile j ready (step+1), [16..23] wave done (step+1)
-  lds_int* wflag = F, *bflag = F + 1, *xflag = F + 2, *dflag = F + 16;
+  lds_int* wflag = F, *bflag = F + 1, *dflag = F + 24;
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;
   const auto Hg = uni(P.Hb);
@@ -1170,7 +1173,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
     }
   }
   for (int i = tid; i < 2 * (BT + 1) * TILE_LDS; i += NT) XpB[i] = 0.0;   // rows 7..15 of both border panel tiles stay zero
-  if (tid < 32) F[tid] = (tid == 0 || tid == 1) ? -1 : 0;
+  if (tid < 48) F[tid] = (tid == 0 || tid == 1) ? -1 : 0;
   if (tid == 0) ctl->fact_ok = 1;
   __syncthreads();
 
@@ -1180,6 +1183,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
     const int I = kc + ((wave - kc) & (BT - 1));     // ring row held during this step: window [kc, kc+BT-1]
     const int i = I - k;                             // its tile of block column k is (I, k): X slot i in 1..BT
     lds_double* Xp = XpB + par * (BT + 1) * TILE_LDS;
+    lds_int* xflag = F + 2 + 10 * par;
     const bool memwave = wave == (k & (BT - 1));     // factored column k: its ring row is free, it takes the global-memory duties
     v4d araw = {0.0, 0.0, 0.0, 0.0};
     if (k >= 0) {
@@ -1410,6 +1414,338 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   __syncthreads();
 }
 
+#undef WT_BEGIN
+#undef WT_END
+
+template <int NW>
+__device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* ws) {
+  constexpr int RPW = BT / NW, NT = 64 * NW, BOFF = 2;
+  static_assert(RPW == 1 || RPW == 2, "one or two ring rows per wave");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Dn = uni(P.Dn);
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  const int nT = Dnp / TS;
+  lds_double* AselfB = to_lds(ws);                             // BT private raw tiles (one per ring slot), operand layout
+  lds_double* XpB = to_lds(ws) + BT * TILE_LDS;                // 2 x (BT+1) X tiles, slot 0 = border panel
+  lds_double* LinvB = XpB + 2 * (BT + 1) * TILE_LDS;           // 3 x Linv^T (column mod 3: a lagging wave may still read W of step k-1 while W of k+1 is written)
+  lds_double* AbordB = LinvB + 3 * TILE_LDS;                   // 3 x 7x16 border block
+  lds_double* Cn = AbordB + 3 * SFT_BORDER * TS;               // 7x7 corner
+  // flags: [0] W ready (column), [1] border block ready, [2..10] / [12..20] X tile j of an even / odd step ready (step+1),
+  // [24..31] wave done (step+1).  The X flags are per buffer parity: a wave that runs one step ahead must not satisfy a
+  // reader that still waits for the same tile slot of the previous step.
+  lds_int* F = (lds_int*)(Cn + 64);
+  lds_int* wflag = F, *bflag = F + 1, *dflag = F + 24;
+  const double lambda = ctl->lambda;
+  const int crow = lane >> 4, ccol = lane & 15;
+  const auto Hg = uni(P.Hb);
+  const auto Hbord = uni(P.Hbord);
+  const auto Lg = uni(P.Lb);
+  const auto Lbord = uni(P.Lbord);
+  const auto Linv_g = uni(P.Linv);
+  v4d acc[RPW][BT];
+  v4d bacc[RPW];
+#ifdef SFT_STEP_TRACE
+  long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt0;   // cycles spent waiting: [0] buffers free [1] W [2] X1 [3] X2..i [4] border [5] store flags [6] chol [7] whole loop
+  const long long wloop0 = clock64();
+#define WT_BEGIN() wt0 = clock64()
+#define WT_END(e) wt[e] += clock64() - wt0
+#else
+#define WT_BEGIN() do {} while (0)
+#define WT_END(e) do {} while (0)
+#endif
+  auto fresh_tile = [&](int I, int d) -> v4d { return *reinterpret_cast<const v4d*>(Hg + tile_off(I, d) + 4 * lane); };
+  auto fresh_border = [&](int J) -> v4d {
+    v4d v = {0.0, 0.0, 0.0, 0.0};
+    v[0] = Hbord[(size_t)crow * Dnp + TS * J + ccol];
+    v[1] = Hbord[(size_t)(crow + 4) * Dnp + TS * J + ccol];
+    return v;
+  };
+#pragma unroll
+  for (int t = 0; t < RPW; t++) {
+    const int a = wave + NW * t;
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(a, (a - b) & (BT - 1));
+    bacc[t] = fresh_border((a + BOFF) & (BT - 1));
+  }
+  v4d cacc = {0.0, 0.0, 0.0, 0.0};
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
+    }
+  }
+  for (int i = tid; i < 2 * (BT + 1) * TILE_LDS; i += NT) XpB[i] = 0.0;   // rows 7..15 of both border panel tiles stay zero
+  if (tid < 48) F[tid] = (tid == 0 || tid == 1) ? -1 : 0;
+  if (tid == 0) ctl->fact_ok = 1;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int k = -1; k < nT; k++) {
+    const int kc = k + 1, kslot = kc & (BT - 1), par = k & 1, p3 = (k + 3) % 3, p3c = kc % 3;
+    lds_double* Xp = XpB + par * (BT + 1) * TILE_LDS;
+    lds_int* xflag = F + 2 + 10 * par;
+    int I[RPW];                                       // ring rows held during this step: window [kc, kc+BT-1]
+#pragma unroll
+    for (int t = 0; t < RPW; t++) I[t] = kc + ((wave + NW * t - kc) & (BT - 1));
+    // the row closer to the diagonal goes first everywhere (it is the one other waves -- and the factorisation -- wait for)
+    const bool swap = RPW == 2 && I[RPW - 1] < I[0];
+    bool memwave = false;                             // holds the ring slot of column k: that row is free, it takes the global-memory duties
+    v4d araw = {0.0, 0.0, 0.0, 0.0};
+    if (k >= 0) {
+#pragma unroll
+      for (int t = 0; t < RPW; t++) {
+        if (wave + NW * t == (k & (BT - 1))) {        // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
+          memwave = true;
+#pragma unroll
+          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1));
+          araw = fresh_tile(k + BT, BT);
+        }
+        if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
+      }
+      // nobody may still be reading the buffers of step k-2 (same parity)
+      WT_BEGIN();
+      if (k >= 2) flags_wait(dflag, 0, NW - 1, k - 1);
+      WT_END(0);
+      // ---- C: X_i = A_i W_k^T for the tiles of the own ring rows ----
+      WT_BEGIN();
+      flag_wait(wflag, k);
+      WT_END(1);
+      lds_double* LinvK = LinvB + p3 * TILE_LDS;
+      double bv[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) bv[kk] = LinvK[(4 * kk + crow) * TP + ccol];
+#pragma unroll
+      for (int o = 0; o < RPW; o++)
+#pragma unroll
+      for (int t = 0; t < RPW; t++)
+      if (t == (swap ? RPW - 1 - o : o)) {   // rows in order of their distance to the diagonal, t stays a compile-time index
+        const int i = I[t] - k;
+        lds_double* Aself = AselfB + (wave + NW * t) * TILE_LDS;
+        if (i == BT) {                                // the recycled row: its raw tile arrives from HBM, through the private LDS slot into operand layout
+          lds_double* dst = Aself + ccol * TP + crow;
+#pragma unroll
+          for (int q = 0; q < 4; q++) dst[4 * q] = araw[q];
+        }
+        double av[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) av[kk] = Aself[(4 * kk + crow) * TP + ccol];
+        v4d x = {0.0, 0.0, 0.0, 0.0}, x2 = x;
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], x2, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], x2, 0, 0, 0);
+        x += x2;
+        lds_double* dst = Xp + i * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[4 * q] = (I[t] < nT) ? x[q] : 0.0;
+        flag_set(xflag + i, k + 1);
+      }
+      bool border_trsm = false;
+#pragma unroll
+      for (int t = 0; t < RPW; t++) border_trsm = border_trsm || (I[t] - k == 4);
+      if (border_trsm) {                              // border panel (7 camera/rhs rows): one more MFMA tile, off the critical path
+        WT_BEGIN();
+        flag_wait(bflag, k);
+        WT_END(4);
+        lds_double* Abord = AbordB + p3 * SFT_BORDER * TS;
+        double ab[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) ab[kk] = (ccol < SFT_BORDER) ? Abord[ccol * TS + 4 * kk + crow] : 0.0;
+        v4d xb = {0.0, 0.0, 0.0, 0.0}, xb2 = xb;
+        xb = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[0], bv[0], xb, 0, 0, 0);
+        xb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[1], bv[1], xb2, 0, 0, 0);
+        xb = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[2], bv[2], xb, 0, 0, 0);
+        xb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ab[3], bv[3], xb2, 0, 0, 0);
+        xb += xb2;
+        Xp[ccol * TP + crow] = xb[0];
+        if (crow + 4 < SFT_BORDER) Xp[ccol * TP + crow + 4] = xb[1];
+        flag_set(xflag, k + 1);
+      }
+    }
+    // ---- D1: block column kc of the own rows, then publish (private slot) or factor (owner); D2: rest of the row ----
+#pragma unroll
+    for (int o = 0; o < RPW; o++)
+#pragma unroll
+    for (int t = 0; t < RPW; t++)
+    if (t == (swap ? RPW - 1 - o : o)) {
+      const int i = I[t] - k;
+      double an[4] = {0.0, 0.0, 0.0, 0.0};
+      if (k >= 0) {
+        WT_BEGIN();
+        flag_wait(xflag + 1, k + 1);                  // X of tile (kc, k); the owner produced it itself
+        WT_END(2);
+        double bc[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          an[kk] = -Xp[i * TILE_LDS + (4 * kk + crow) * TP + ccol];
+          bc[kk] = Xp[TILE_LDS + (4 * kk + crow) * TP + ccol];
+        }
+        if (I[t] < nT) {
+#pragma unroll
+          for (int c = 0; c < BT; c++)
+            if (c == kslot) {
+              v4d side = {0.0, 0.0, 0.0, 0.0};
+              acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[0], bc[0], acc[t][c], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[1], bc[1], side, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              acc[t][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[2], bc[2], acc[t][c], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[3], bc[3], side, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              acc[t][c] += side;
+            }
+        }
+      }
+      if (kc < nT) {
+        v4d dtile = acc[t][0];
+#pragma unroll
+        for (int c = 1; c < BT; c++)
+          if (c == kslot) dtile = acc[t][c];
+        if (I[t] == kc) {
+          __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (crow + 4 * q == ccol && TS * kc + ccol < Dn) dtile[q] += lambda;
+          v4d w = dtile;
+          WT_BEGIN();
+          const bool ok = chol_inv_blocked(dtile, w);
+          WT_END(6);
+          if (!ok && lane == 0) ctl->fact_ok = 0;
+          lds_double* dst = LinvB + p3c * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+          for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
+          flag_set(wflag, kc);
+          *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
+          __builtin_amdgcn_s_setprio(0);
+        } else {
+          lds_double* dst = AselfB + (wave + NW * t) * TILE_LDS + ccol * TP + crow;   // raw tile (I, kc) for the next step's TRSM: private slot
+#pragma unroll
+          for (int q = 0; q < 4; q++) dst[4 * q] = dtile[q];
+        }
+      }
+      if (k >= 0 && I[t] < nT && I[t] > kc) {         // tiles (I, J), kc < J <= I: need X tiles 2..i of this step
+        WT_BEGIN();
+        flags_wait(xflag, 2, i, k + 1);
+        WT_END(3);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          double bb[BT];
+#pragma unroll
+          for (int b = 0; b < BT; b++) bb[b] = Xp[(kc + ((b - kc) & (BT - 1)) - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+#pragma unroll
+          for (int b = 0; b < BT; b++) {
+            const int J = kc + ((b - kc) & (BT - 1));
+            if (J <= I[t] && J != kc) acc[t][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[b], acc[t][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (k >= 0) {
+      // ---- border tiles of ring columns (wave + NW t + BOFF), corner ----
+      WT_BEGIN();
+      flag_wait(xflag, k + 1);
+      WT_END(4);
+      double bn[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) bn[kk] = -Xp[(4 * kk + crow) * TP + ccol];
+#pragma unroll
+      for (int t = 0; t < RPW; t++) {
+        const int Jb = kc + ((wave + NW * t + BOFF - kc) & (BT - 1));
+        WT_BEGIN();
+        flag_wait(xflag + (Jb - k), k + 1);
+        WT_END(4);
+        double bbord[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) bbord[kk] = Xp[(Jb - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) bacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bbord[kk], bacc[t], 0, 0, 0);
+        if (Jb == kc && kc < nT) {                    // border block of column kc for the next TRSM
+          lds_double* Abord = AbordB + p3c * SFT_BORDER * TS;
+          Abord[crow * TS + ccol] = bacc[t][0];
+          if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[t][1];
+          flag_set(bflag, kc);
+        }
+      }
+      if (wave == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
+      }
+      // ---- block column k of L goes to global memory from the LDS panel ----
+      if (memwave) {
+        WT_BEGIN();
+        flags_wait(xflag, 0, BT, k + 1);
+        WT_END(5);
+#pragma unroll
+        for (int j = 1; j <= BT; j++)
+          if (k + j < nT) {
+            const lds_double* src = Xp + j * TILE_LDS + ccol * TP + crow;
+            v4d x;
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = src[4 * q];
+            *reinterpret_cast<v4d*>(Lg + tile_off(k, j) + 4 * lane) = x;   // L is stored by block COLUMN: tile (k+j, k) at slot (k, j)
+          }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int e = lane + 64 * h, r = e >> 4, j = e & 15;
+          if (r < SFT_BORDER) Lbord[(size_t)r * Dnp + TS * k + j] = Xp[j * TP + r];
+        }
+      }
+      flag_set(dflag + wave, k + 1);                  // done with the buffers of step k
+    } else {
+      // k == -1: the border block of column 0 comes straight from H
+#pragma unroll
+      for (int t = 0; t < RPW; t++)
+        if (((wave + NW * t + BOFF) & (BT - 1)) == 0) {
+          lds_double* Abord = AbordB + p3c * SFT_BORDER * TS;
+          Abord[crow * TS + ccol] = bacc[t][0];
+          if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[t][1];
+          flag_set(bflag, 0);
+        }
+    }
+  }
+#ifdef SFT_STEP_TRACE
+  wt[7] = clock64() - wloop0;
+  if (lane == 0 && P.dbg[8] < 0.5) { for (int e = 0; e < 8; e++) P.dbg[16 + 8 * wave + e] = (double)wt[e] + 1.0; }
+  __syncthreads();
+  if (tid == 0) P.dbg[8] = 1.0;
+#endif
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = cacc[q];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool bad = false;
+    for (int k = 0; k < 6; k++) {
+      double d = Cn[k * 7 + k];
+      for (int j = 0; j < k; j++) d -= Cn[k * 7 + j] * Cn[k * 7 + j];
+      if (!(d > 0.0)) bad = true;
+      const double piv = sqrt(d);
+      Cn[k * 7 + k] = piv;
+      for (int r = k + 1; r < 7; r++) {
+        double v = Cn[r * 7 + k];
+        for (int j = 0; j < k; j++) v -= Cn[r * 7 + j] * Cn[k * 7 + j];
+        Cn[r * 7 + k] = v / piv;
+      }
+    }
+    if (bad) ctl->fact_ok = 0;
+    if (ctl->fact_ok)
+      for (int k = 5; k >= 0; k--) {
+        double v = Cn[6 * 7 + k];
+        for (int r = k + 1; r < 6; r++) v -= Cn[r * 7 + k] * P.x[Dnp + r];
+        P.x[Dnp + k] = v / Cn[k * 7 + k];
+      }
+  }
+  __syncthreads();
+}
+
 // Back substitution in tile mode: x_J = Linv_J^T (y_J - sum_{I>J} X_{I,J}^T x_I - Lcn_J^T x_cam).
 // Wave w forms the partial products of tiles (J+d, J), d = w+1+NW*t; wave 0 finishes the block.  The tiles of block J-1
 // are prefetched while block J is processed (LDS-only barriers keep the loads in flight).
@@ -1583,7 +1919,12 @@ __global__ __launch_bounds__(64 * NW, 2) void sft_lm_kernel(const SftDev* __rest
       double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
       PH_ADD(7);
       if (P.tile_mode) {
-        if (NW == 8 && (P.mode & 2)) { PH_RESET(); factor_tiles_df(P, ctl, panel); PH_ADD(5); }
+        if (P.mode & 2) {
+          PH_RESET();
+          if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel);
+          else factor_tiles_df<NW>(P, ctl, panel);
+          PH_ADD(5);
+        }
         else factor_tiles<NW>(P, ctl, panel);
         PH_RESET();
         backsub_tiles<NW>(P, ctl, panel);
@@ -1682,7 +2023,7 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
   const size_t backsub = NB + (SFT_NT / NB) * NB + NB * NB;
   if (backsub > panel) panel = backsub;
-  const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 32 + 128;  // dataflow layout (the larger one) + step-trace stamps
+  const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 48 + 128;  // dataflow layout (the larger one) + step-trace stamps
   if (kd <= TS * BT) panel = tiles;
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;

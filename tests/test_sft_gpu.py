@@ -182,6 +182,32 @@ def test_four_wavefront_launch_shape_matches_eight(gpu_ctx, oracle_mod, cfg, pid
     assert np.abs(f4.nodes_xyz - r.xyz).max() < 1e-9 * np.abs(r.xyz).max()
 
 
+@pytest.mark.parametrize("waves", ["8", "4"])
+def test_dataflow_steps_equal_barrier_steps_bit_for_bit_under_load(gpu_ctx, waves, monkeypatch):
+    """The barrier-free factor steps hand tiles over through LDS flags; a missed dependency shows up as a (rare, load
+    dependent) difference.  Many more problems than CUs, both launch shapes, compared bit for bit with the barrier
+    version (same arithmetic order).  Regression test for the per-parity X flags (a wave one step ahead must not
+    satisfy a reader of the previous step)."""
+    from defslam_amd import sft, synth
+    tmpl = synth.make_grid_template(12, 14)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    B = 900
+    monkeypatch.setenv("DSH_SFT_WAVES", waves)
+
+    def run(df):
+        monkeypatch.setenv("DSH_SFT_DATAFLOW", df)
+        frames = [sft.frame_from_synth(synth.make_frame(tmpl, 260 + (p % 7) * 20, p)) for p in range(B)]
+        inl = sft.DefPoseOptimizationBatch(gpu_ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        return np.stack([f.nodes_xyz for f in frames]), np.array([f.trials for f in frames]), np.array(inl)
+
+    ref = run("0")
+    for _ in range(2):
+        cur = run("1")
+        np.testing.assert_array_equal(cur[1], ref[1])
+        np.testing.assert_array_equal(cur[2], ref[2])
+        np.testing.assert_array_equal(cur[0], ref[0])
+
+
 def test_mappoint_writeback_float32(gpu_ctx):
     from defslam_amd import sft, synth
     tmpl, fr = synth.make_problem("smoke", 2)
