@@ -135,6 +135,9 @@ def main():
         achieved_tf = flops_per_launch / (kern_ms * 1e-3) / 1e12
         # assembly: algorithmic bytes per launch (SURVEY 8d per-iteration figure x iterations the launch executes)
         bytes_per_launch = (alg_bytes / args.batch) * iters
+        nTt = ((Dn + 31) // 32) * 2                      # 16-row tile rows of the padded node block
+        stream_trial = nTt * 9 * 2048 + 2 * nTt * 8 * 2048 + 3 * 7 * 16 * nTt * 8 + 2 * nTt * 2048   # H tiles, L write + read, border rows, Linv
+        stream_bytes = stream_trial * trials
         hbm_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "SfT GN iters/sec (500-node mesh, 1k matches)", "value": value, "unit": "iters/s",
@@ -153,6 +156,11 @@ def main():
                          "hbm_assembly": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                                           "algorithmic_bytes_per_launch": bytes_per_launch,
                                           "measured_traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None},
+                         # what THIS algorithm has to stream per launch: assembly bytes + per damping trial the H tiles read once,
+                         # L written once by the factorisation and read once by the back substitution
+                         "hbm_solver_stream": {"achieved": (bytes_per_launch + stream_bytes) / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": (bytes_per_launch + stream_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "bytes_per_trial": stream_trial, "achievable_stream_GBps_this_box": 5400.0},
                          "note": "one persistent kernel = residuals + Jacobian assembly + banded-arrowhead Cholesky (FP64 MFMA) + LM control; "
                                  "frac = algorithmic solve flops / FP64 peak over the WHOLE kernel time; hbm_assembly = SURVEY 8d assembly bytes over the same time"},
         }

@@ -17,6 +17,8 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
+// dense build of the same kernels (sft_kernels_dense.hip): 128 VGPRs per wave, two 8-wavefront problems per CU
+extern "C" hipError_t sft_lm_launch_dense(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 
 namespace {
 
@@ -119,6 +121,7 @@ struct dsh_ctx : dsh_ctx_base {
   int max_kd = 0;
   size_t jl_doubles = 0;
   int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
+  bool dense = false; // 8 wavefronts at 128 VGPRs: two problems share a CU (dense build of the kernels)
   int num_cus = 256;
   bool ran = false;
 };
@@ -477,7 +480,11 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
       hh.mode = (hh.mode & ~2) | ((hh.tile_mode && dataflow) ? 2 : 0);
     }
   }
-  const size_t jl_cap = (nw == 4 ? 72 : 96) * 1024;
+  bool dense = false;
+  if (const char* e = std::getenv("DSH_SFT_DENSE")) dense = std::atoi(e) != 0 && nw == 8;
+  if (dense)
+    for (int b = 0; b < B; b++) dense = dense && c->packed[b].h.tile_mode;
+  const size_t jl_cap = ((nw == 4 || dense) ? 72 : 96) * 1024;
   for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to the solver workspace
     SftDev& hh = c->packed[b].h;
     const size_t need = 4 * ((size_t)hh.S + hh.Es + hh.V);
@@ -538,6 +545,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->max_kd = max_kd;
   c->jl_doubles = jl_doubles;
   c->nw = nw;
+  c->dense = dense;
   c->ran = false;
   return DSH_OK;
 }
@@ -547,7 +555,7 @@ int dsh_sft_batch_run(dsh_ctx* c) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
   (void)hipSetDevice(c->device);
-  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  HIPCHK(c, (c->dense ? sft_lm_launch_dense : sft_lm_launch)(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
   c->ran = true;
   return DSH_OK;
 }
@@ -561,7 +569,7 @@ int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, (c->dense ? sft_lm_launch_dense : sft_lm_launch)(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0.f;

@@ -23,6 +23,13 @@
 #include <float.h>
 #define SFT_KERNEL_SOURCE
 #include "sft_problem.h"
+#ifndef SFT_WAVES_PER_EU
+#define SFT_WAVES_PER_EU 2      // 4: the dense build (sft_kernels_dense.hip), 128 VGPRs per wave, two 8-wave problems per CU
+#endif
+#ifndef SFT_LAUNCH_NAME
+#define SFT_LAUNCH_NAME sft_lm_launch
+#define SFT_LDS_BYTES_NAME sft_lm_kernel_lds_bytes
+#endif
 #include "tile_chol.h"
 
 #define NB 32  // panel width of the blocked band Cholesky
@@ -1172,6 +1179,11 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
       if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
     }
   }
+#if SFT_WAVES_PER_EU >= 4
+  // dense build (four waves per SIMD, 128 VGPRs): the corner accumulator of wave 0 waits in LDS between the steps
+  lds_double* CaccL = (lds_double*)(F + 48);
+  if (wave == 0) { CaccL[2 * lane] = cacc[0]; CaccL[2 * lane + 1] = cacc[1]; }
+#endif
   for (int i = tid; i < 2 * (BT + 1) * TILE_LDS; i += NT) XpB[i] = 0.0;   // rows 7..15 of both border panel tiles stay zero
   if (tid < 48) F[tid] = (tid == 0 || tid == 1) ? -1 : 0;
   if (tid == 0) ctl->fact_ok = 1;
@@ -1292,6 +1304,14 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
         flag_set(wflag, kc);
         *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
         __builtin_amdgcn_s_setprio(0);
+#if SFT_WAVES_PER_EU >= 4
+        // This wave's ring row is recycled at the next step (it becomes the memory wave): nothing of it is read again.
+        // Telling the compiler (the registers are "redefined" here, without an instruction) frees them across the factorisation.
+#pragma unroll
+        for (int b2 = 0; b2 < BT; b2++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) { double z; asm volatile("" : "=v"(z)); acc[b2][q] = z; }
+#endif
       } else {
         lds_double* dst = Aself + ccol * TP + crow;  // raw tile (I, kc) for the next step's TRSM: private slot
 #pragma unroll
@@ -1332,8 +1352,15 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) bacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bbord[kk], bacc, 0, 0, 0);
         if (wave == 0) {
+#if SFT_WAVES_PER_EU >= 4
+          v4d cc = {CaccL[2 * lane], CaccL[2 * lane + 1], 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) cc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cc, 0, 0, 0);
+          CaccL[2 * lane] = cc[0]; CaccL[2 * lane + 1] = cc[1];
+#else
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
+#endif
         }
         if (Jb == kc && kc < nT) {                   // border block of column kc for the next TRSM
           lds_double* Abord = AbordB + p3c * SFT_BORDER * TS;
@@ -1385,7 +1412,11 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int r = crow + 4 * q;
+#if SFT_WAVES_PER_EU >= 4
+      if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = CaccL[2 * lane + q];
+#else
       if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = cacc[q];
+#endif
     }
   }
   __syncthreads();
@@ -1848,7 +1879,7 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 // The persistent per-problem kernel
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void sft_lm_kernel(const SftDev* __restrict__ probs) {
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const SftDev* __restrict__ probs) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const SftDev& P = probs[blockIdx.x];
@@ -2017,20 +2048,20 @@ __global__ __launch_bounds__(64 * NW, 2) void sft_lm_kernel(const SftDev* __rest
 }  // namespace
 
 // LDS bytes the kernel needs for a problem with half-bandwidth kd
-extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
+extern "C" size_t SFT_LDS_BYTES_NAME(int kd, size_t jl_doubles) {
   const size_t rows = NB + kd + SFT_BORDER;
   const size_t LDP = rows | 1;
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
   const size_t backsub = NB + (SFT_NT / NB) * NB + NB * NB;
   if (backsub > panel) panel = backsub;
-  const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 48 + 128;  // dataflow layout (the larger one) + step-trace stamps
+  const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 48 + 128 + 128;  // dataflow layout (the larger one) + step-trace stamps
   if (kd <= TS * BT) panel = tiles;
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
 
-extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
-  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+extern "C" hipError_t SFT_LAUNCH_NAME(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
+  const size_t lds = SFT_LDS_BYTES_NAME(max_kd, jl_doubles);
   static size_t configured[2] = {0, 0};
   const int slot = nw == 4 ? 0 : 1;
   if (lds > configured[slot]) {
