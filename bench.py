@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--config", default="C2", choices=["smoke", "C2", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank); gloo only to exercise the multi-rank path on a single GPU")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing aid: every rank uses this device index instead of LOCAL_RANK")
     args = ap.parse_args()
 
     import torch
@@ -66,6 +68,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.all_ranks_on_device >= 0:
+        local_rank = args.all_ranks_on_device
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -74,7 +78,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -104,8 +111,9 @@ def main():
     alg_bytes = sum(i[0] for i in infos)
     _, counts = infos[0]
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([iters, trials, args.batch], dtype=torch.float64, device="cuda")
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([iters, trials, args.batch], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
