@@ -22,6 +22,8 @@ extern "C" hipError_t nrsfm_sfn_residual(int, int, const double*, const double*,
 extern "C" hipError_t nrsfm_sfn_axpy(int, const double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_warp_coloc(double, double, int, double, double, int, int, const float*, const float*, double*, double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_mat_add(size_t, const double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_match_search(double, double, int, double, double, int, const double*, int, const float*, const uint32_t*, const float*, const float*, int, int,
+                                         int, const float*, const uint32_t*, const uint8_t*, float, int, int32_t*, int32_t*, hipStream_t);
 extern "C" hipError_t nrsfm_sfn_points(double, double, int, double, double, int, const double*, int, const double*, const double*, float*, hipStream_t);
 
 namespace {
@@ -206,6 +208,46 @@ int dsh_warp_initialize(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp
   bool finite = true;
   for (int i = 0; i < 2 * N; i++) finite = finite && std::isfinite(x[i]);
   *ok = ((s8[2] != 0.0 || s8[3] != 0.0) && finite) ? 1 : 0;
+  return DSH_OK;
+}
+
+int dsh_search_by_schwarp(dsh_ctx* ctx, const dsh_bbs* bbs, const double* x, int Q, const float* kp1, const uint8_t* desc1, const float* cam2,
+                          const float* bounds2, int grid_cols, int grid_rows, int N2, const float* kp2, const uint8_t* desc2, const uint8_t* has_mp2,
+                          float radius, int th_low, int32_t* match, int32_t* nmatches) {
+  dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
+  if (!c) return DSH_ERR_ARG;
+  if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_search_by_schwarp: host-only context, no GPU (there is no CPU fallback)");
+  if (!bbs_ok(bbs) || !x || Q < 0 || N2 < 0 || (Q > 0 && (!kp1 || !desc1 || !match)) || (N2 > 0 && (!kp2 || !desc2 || !has_mp2)) || !cam2 || !bounds2 ||
+      grid_cols <= 0 || grid_rows <= 0 || grid_cols * grid_rows > 8192 || !(bounds2[1] > bounds2[0]) || !(bounds2[3] > bounds2[2]) || th_low > 256)
+    return dsh_fail(c, DSH_ERR_ARG, "dsh_search_by_schwarp: bad argument");
+  if (nmatches) *nmatches = 0;
+  if (Q == 0) return DSH_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, "dsh_search_by_schwarp: hipSetDevice failed");
+  c->scratch.reset();
+  hipStream_t st = c->stream;
+  const int N = bbs->nptsu * bbs->nptsv;
+  DevBuf dx, dk1, dd1, dk2, dd2, dmp, dcell, dmatch;
+  HIPCHK(c, dx.alloc(c, 8 * (size_t)2 * N)); HIPCHK(c, dk1.alloc(c, 8 * (size_t)Q)); HIPCHK(c, dd1.alloc(c, 32 * (size_t)Q));
+  HIPCHK(c, dk2.alloc(c, 8 * (size_t)N2)); HIPCHK(c, dd2.alloc(c, 32 * (size_t)N2)); HIPCHK(c, dmp.alloc(c, (size_t)N2));
+  HIPCHK(c, dcell.alloc(c, 4 * (size_t)N2)); HIPCHK(c, dmatch.alloc(c, 4 * (size_t)Q));
+  HIPCHK(c, hipMemcpyAsync(dx.p, x, 8 * (size_t)2 * N, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dk1.p, kp1, 8 * (size_t)Q, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dd1.p, desc1, 32 * (size_t)Q, hipMemcpyHostToDevice, st));
+  if (N2 > 0) {
+    HIPCHK(c, hipMemcpyAsync(dk2.p, kp2, 8 * (size_t)N2, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dd2.p, desc2, 32 * (size_t)N2, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dmp.p, has_mp2, (size_t)N2, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, nrsfm_match_search(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, dx.as<double>(), Q, dk1.as<float>(), dd1.as<uint32_t>(), cam2,
+                               bounds2, grid_cols, grid_rows, N2, dk2.as<float>(), dd2.as<uint32_t>(), dmp.as<uint8_t>(), radius, th_low, dcell.as<int32_t>(),
+                               dmatch.as<int32_t>(), st));
+  HIPCHK(c, hipMemcpyAsync(match, dmatch.p, 4 * (size_t)Q, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (nmatches) {
+    int n = 0;
+    for (int q = 0; q < Q; q++) n += match[q] >= 0;
+    *nmatches = n;
+  }
   return DSH_OK;
 }
 

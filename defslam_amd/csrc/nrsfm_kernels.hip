@@ -845,6 +845,88 @@ __global__ void mat_add_kernel(size_t n, const double* __restrict__ B, double* _
   if (i < n) A[i] += B[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Warp-guided match search (DefORBmatcher::searchBySchwarp, Modules/Matching/DefORBmatcher.cc:189-294)
+// ------------------------------------------------------------------------------------------------
+struct MatchPar { float fx, fy, cx, cy, minX, maxX, minY, maxY, winv, hinv, radius; int cols, rows, th_low; };
+
+// grid cell of every key point of keyframe 2 (Frame::PosInGrid, Frame.cc:484-496): cell = px * rows + py or -1 (not in the grid)
+__global__ void match_cells_kernel(MatchPar p, int N2, const float* __restrict__ kp2, int32_t* __restrict__ cell) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N2) return;
+  const int px = (int)roundf((kp2[2 * j] - p.minX) * p.winv), py = (int)roundf((kp2[2 * j + 1] - p.minY) * p.hinv);
+  cell[j] = (px < 0 || px >= p.cols || py < 0 || py >= p.rows) ? -1 : px * p.rows + py;
+}
+
+// One wavefront per query: prediction through the warp (16 taps, float32 key point like Warp::getEstimates), image and window
+// tests of KeyFrame::GetFeaturesInArea, 256-bit Hamming distance to every candidate.  The reference walks the grid cells
+// column by column and keeps the first strictly better candidate; a brute-force scan reproduces that with the key
+// (distance, cell, index): lanes scan candidates j = lane, lane + 64, ..., then a wave-wide lexicographic minimum.
+__global__ __launch_bounds__(256) void match_search_kernel(BbsPar b, MatchPar p, const double* __restrict__ x, int Q, const float* __restrict__ kp1,
+                                                           const uint32_t* __restrict__ desc1, int N2, const float* __restrict__ kp2,
+                                                           const uint32_t* __restrict__ desc2, const uint8_t* __restrict__ has_mp2,
+                                                           const int32_t* __restrict__ cell, int32_t* __restrict__ match) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const int N = b.nptsu * b.nptsv;
+  double nu, nv, bu[4], bv[4];
+  int Iu, Iv;
+  const double u = kp1[2 * q], v = kp1[2 * q + 1];
+  norm_inter(b.umin, b.umax, b.nptsu, u, nu, Iu);
+  norm_inter(b.vmin, b.vmax, b.nptsv, v, nv, Iv);
+  cubic_basis(0, nu, bu);
+  cubic_basis(0, nv, bv);
+  double ax = 0.0, ay = 0.0;
+  if (!(Iu < 0 || Iu > b.nptsu - 4 || Iv < 0 || Iv > b.nptsv - 4)) {
+    for (int iu = 0; iu < 4; iu++)
+      for (int iv = 0; iv < 4; iv++) {
+        const double bas = bu[iu] * bv[iv];
+        const int c = (iu + Iu) * b.nptsv + iv + Iv;
+        ax += x[c] * bas;
+        ay += x[N + c] * bas;
+      }
+  }
+  const float ex = (float)ax, ey = (float)ay;
+  const float px = ex * p.fx + p.cx, py = ey * p.fy + p.cy;
+  int result = -1;
+  bool live = px >= p.minX && px < p.maxX && py >= p.minY && py < p.maxY;
+  int c0 = 0, c1 = 0, r0 = 0, r1 = 0;
+  if (live) {
+    c0 = max(0, (int)floorf((px - p.minX - p.radius) * p.winv));
+    c1 = min(p.cols - 1, (int)ceilf((px - p.minX + p.radius) * p.winv));
+    r0 = max(0, (int)floorf((py - p.minY - p.radius) * p.hinv));
+    r1 = min(p.rows - 1, (int)ceilf((py - p.minY + p.radius) * p.hinv));
+    live = c0 < p.cols && c1 >= 0 && r0 < p.rows && r1 >= 0;
+  }
+  if (live) {
+    uint32_t d1[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) d1[w] = desc1[8 * (size_t)q + w];
+    // key = distance (9 bits) | cell (13 bits at most 64*48) | index: smaller is better, exactly the reference's visiting order among equal distances
+    unsigned long long best = ~0ull;
+    for (int j = lane; j < N2; j += 64) {
+      const int cj = cell[j];
+      if (cj < 0 || has_mp2[j]) continue;
+      const int cx = cj / p.rows, cy = cj - cx * p.rows;
+      if (cx < c0 || cx > c1 || cy < r0 || cy > r1) continue;
+      const float dx = kp2[2 * j] - px, dy = kp2[2 * j + 1] - py;
+      if (!(fabsf(dx) < p.radius && fabsf(dy) < p.radius)) continue;
+      int dist = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) dist += __popc(d1[w] ^ desc2[8 * (size_t)j + w]);
+      if (dist >= p.th_low) continue;
+      const unsigned long long key = ((unsigned long long)dist << 48) | ((unsigned long long)cj << 32) | (unsigned)j;
+      best = key < best ? key : best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(best, o, 64);
+      best = other < best ? other : best;
+    }
+    if (best != ~0ull) result = (int)(best & 0xFFFFFFFFull);
+  }
+  if (lane == 0) match[q] = result;
+}
+
 // out[i] = sign * (b[i] - A[i,:] x): one wavefront per row
 __global__ __launch_bounds__(256) void sfn_residual_kernel(int m, int N, const double* __restrict__ A, const double* __restrict__ x, const double* __restrict__ b,
                                                            double sign, double* __restrict__ out) {
@@ -1064,5 +1146,19 @@ extern "C" hipError_t nrsfm_warp_coloc(double umin, double umax, int nu, double 
 }
 extern "C" hipError_t nrsfm_mat_add(size_t n, const double* B, double* A, hipStream_t st) {
   hipLaunchKernelGGL(mat_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, B, A);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t nrsfm_match_search(double umin, double umax, int nu, double vmin, double vmax, int nv, const double* x, int Q, const float* kp1,
+                                         const uint32_t* desc1, const float* cam2, const float* bounds2, int cols, int rows, int N2, const float* kp2,
+                                         const uint32_t* desc2, const uint8_t* has_mp2, float radius, int th_low, int32_t* cell, int32_t* match, hipStream_t st) {
+  BbsPar b = {umin, umax, vmin, vmax, nu, nv, 2, 0};
+  MatchPar p;
+  p.fx = cam2[0]; p.fy = cam2[1]; p.cx = cam2[2]; p.cy = cam2[3];
+  p.minX = bounds2[0]; p.maxX = bounds2[1]; p.minY = bounds2[2]; p.maxY = bounds2[3];
+  p.winv = (float)cols / (p.maxX - p.minX); p.hinv = (float)rows / (p.maxY - p.minY);
+  p.radius = radius; p.cols = cols; p.rows = rows; p.th_low = th_low;
+  if (N2 > 0) hipLaunchKernelGGL(match_cells_kernel, dim3((N2 + 255) / 256), dim3(256), 0, st, p, N2, kp2, cell);
+  if (Q > 0) hipLaunchKernelGGL(match_search_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, b, p, x, Q, kp1, desc1, N2, kp2, desc2, has_mp2, cell, match);
   return hipGetLastError();
 }

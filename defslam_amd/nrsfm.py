@@ -167,3 +167,23 @@ def WarpInitialize(ctx: Context, bbs: Bbs, kp1, kp2, lam: float):
     ctx._check(ctx._L.dsh_warp_initialize(ctx._h, C.byref(b), kp1.shape[0], _ptr(kp1, C.c_float), _ptr(kp2, C.c_float), float(lam), _ptr(x, C.c_double), C.byref(ok)),
                "dsh_warp_initialize")
     return bool(ok.value), x
+
+
+def searchBySchwarp(ctx: Context, bbs: Bbs, x, kp1, desc1, cam2, bounds2, kp2, desc2, has_mp2, radius: float = 2.0, th_low: int = 50, grid=(64, 48)):
+    """DefORBmatcher::searchBySchwarp: returns match[Q] (index into keyframe 2 or -1)."""
+    x = np.ascontiguousarray(x, np.float64)
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    cam2 = np.ascontiguousarray(cam2, np.float32)
+    b2 = np.ascontiguousarray(bounds2, np.float32)
+    mp2 = np.ascontiguousarray(has_mp2, np.uint8)
+    match = np.full(kp1.shape[0], -1, np.int32)
+    nm = C.c_int32(0)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_search_by_schwarp(ctx._h, C.byref(b), _ptr(x, C.c_double), kp1.shape[0], _ptr(kp1, C.c_float), _ptr(d1, C.c_uint8), _ptr(cam2, C.c_float),
+                                            _ptr(b2, C.c_float), int(grid[0]), int(grid[1]), kp2.shape[0], _ptr(kp2, C.c_float), _ptr(d2, C.c_uint8), _ptr(mp2, C.c_uint8),
+                                            float(radius), int(th_low), _ptr(match, C.c_int32), C.byref(nm)), "dsh_search_by_schwarp")
+    assert nm.value == int((match >= 0).sum())
+    return match

@@ -286,3 +286,44 @@ def make_sfn_scene(n_points: int = 600, seed: int = 4, noise: float = 0.01, with
     vmin, vmax = float(v.min() - 0.10), float(v.max() + 0.10)
     return dict(bbs=(umin, umax, 13, vmin, vmax, 15, 1), u_all=u, v_all=v, depth_true=d, u=u[has], v=v[has], normals=nrm[has].astype(np.float32),
                 mean_depth=float(d.mean()))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Warp-guided match search: keyframe 1 key points (normalised) with ORB-like 256-bit descriptors, a warp, and keyframe 2
+# key points scattered around the predictions (pixels) with noisy copies of the descriptors, distractors, exact duplicates
+# (distance ties), points that already carry a map point and points outside the image / the grid.
+def make_match_scene(n_query: int = 600, n_extra: int = 900, seed: int = 2):
+    rng = np.random.default_rng(seed)
+    pr = make_warp_problem(400, seed + 1)
+    bbs = pr["bbs"][:6] + (2,)
+    x = pr["x0"]
+    cam2 = np.array([520.0, 515.0, 322.5, 241.25], np.float32)
+    bounds2 = np.array([0.0, 640.0, 0.0, 480.0], np.float32)
+    kp1 = np.stack([rng.uniform(bbs[0] + 0.02, bbs[1] - 0.02, n_query), rng.uniform(bbs[3] + 0.02, bbs[4] - 0.02, n_query)], 1).astype(np.float32)
+    # predictions with numpy (double) only to PLACE key points of keyframe 2; the tests compare device and oracle, not this
+    C = _coloc_dense(bbs[0], bbs[1], bbs[2], bbs[3], bbs[4], bbs[5], kp1[:, 0].astype(float), kp1[:, 1].astype(float))
+    N = bbs[2] * bbs[5]
+    pred = np.stack([C @ x[:N], C @ x[N:]], 1)
+    pix = pred * cam2[:2] + cam2[2:]
+    desc1 = rng.integers(0, 256, (n_query, 32), dtype=np.uint8)
+    kp2, desc2 = [], []
+    for q in range(n_query):
+        k = int(rng.integers(0, 4))                       # 0..3 candidates near the prediction
+        for _ in range(k):
+            kp2.append(pix[q] + rng.uniform(-2.6, 2.6, 2))
+            d = desc1[q].copy()
+            flips = rng.integers(0, 256, int(rng.integers(0, 70)))
+            for f in flips:
+                d[f // 8] ^= np.uint8(1 << (f % 8))
+            desc2.append(d)
+        if k and rng.uniform() < 0.25:                    # exact duplicate of the last candidate close by: a distance tie
+            kp2.append(kp2[-1] + rng.uniform(-0.4, 0.4, 2))
+            desc2.append(desc2[-1].copy())
+    kp2 += list(np.stack([rng.uniform(-20, 660, n_extra), rng.uniform(-20, 500, n_extra)], 1))
+    desc2 += list(rng.integers(0, 256, (n_extra, 32), dtype=np.uint8))
+    kp2 = np.asarray(kp2, np.float32)
+    desc2 = np.asarray(desc2, np.uint8)
+    perm = rng.permutation(kp2.shape[0])
+    kp2, desc2 = kp2[perm], desc2[perm]
+    has_mp2 = (rng.uniform(size=kp2.shape[0]) < 0.2).astype(np.uint8)
+    return dict(bbs=bbs, x=x, kp1=kp1, desc1=desc1, cam2=cam2, bounds2=bounds2, kp2=kp2, desc2=desc2, has_mp2=has_mp2)

@@ -208,6 +208,18 @@ int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, c
  * pairs, normalised coordinates).  x[2N]: first coordinate of the N control points, then the second (the layout
  * dsh_schwarp_fit takes).  *ok = 0 when the matrix is not positive definite (too few matches for this lambda). */
 int dsh_warp_initialize(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, double lambda, double* x, int32_t* ok);
+/* DefORBmatcher::searchBySchwarp (Modules/Matching/DefORBmatcher.cc:189-294): for each of the Q query key points of keyframe
+ * 1 (the caller keeps the reference's filter :200-211: map point present, not bad, not yet in keyframe 2; kp1 = mpKeypointNorm,
+ * desc1 = the 32-byte ORB descriptor rows) predict the position in keyframe 2 through the warp x[2N] (Warp::getEstimates,
+ * float32 key point), convert to pixels with cam2 = {fx, fy, cx, cy}, skip predictions outside bounds2 = {mnMinX, mnMaxX,
+ * mnMinY, mnMaxY} (KeyFrame::IsInImage), and among the key points of keyframe 2 (kp2 = mvKeysUn in pixels, desc2) that lie in
+ * the search window of KeyFrame::GetFeaturesInArea(x, y, radius) (grid_cols x grid_rows = FRAME_GRID_COLS x FRAME_GRID_ROWS)
+ * and have no map point (has_mp2[j] == 0) take the one with the smallest Hamming distance below th_low (TH_LOW = 50); among
+ * equal distances the first one in the reference's visiting order (grid column, grid row, index).
+ * match[q] = index in keyframe 2 or -1; *nmatches (may be NULL) = number of matches.  Bit-exact index parity. */
+int dsh_search_by_schwarp(dsh_ctx* ctx, const dsh_bbs* bbs, const double* x, int Q, const float* kp1, const uint8_t* desc1, const float* cam2,
+                          const float* bounds2, int grid_cols, int grid_rows, int N2, const float* kp2, const uint8_t* desc2, const uint8_t* has_mp2,
+                          float radius, int th_low, int32_t* match, int32_t* nmatches);
 /* BBS bending matrix (Thirdparty/BBS/bbs.cc:556-641 bending_ur, bbs_coloc.cc:406-508 BendingEigen) as a dense symmetric
  * N x N matrix, host side (the constant part of the Shape-from-Normals system). */
 int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending);

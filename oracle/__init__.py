@@ -420,3 +420,26 @@ def warp_initialize(bbs, kp1, kp2, lam):
     L.warp_oracle_initialize.restype = C.c_int
     ok = L.warp_oracle_initialize(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), kp1.shape[0], _p(kp1, C.c_float), _p(kp2, C.c_float), D(lam), _p(x, D))
     return bool(ok), x
+
+
+# ---- warp-guided match search oracle (match_oracle.c) -------------------------------------------------
+def search_by_schwarp(bbs, x, kp1, desc1, cam2, bounds2, kp2, desc2, has_mp2, radius=2.0, th_low=50, grid=(64, 48)):
+    """DefORBmatcher::searchBySchwarp: returns match[Q] (index in keyframe 2 or -1)."""
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    x = np.ascontiguousarray(x, np.float64)
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    cam2 = np.ascontiguousarray(cam2, np.float32)
+    b2 = np.ascontiguousarray(bounds2, np.float32)
+    mp2 = np.ascontiguousarray(has_mp2, np.uint8)
+    match = np.full(kp1.shape[0], -1, np.int32)
+    D = C.c_double
+    L.match_oracle_search_by_schwarp.restype = C.c_int
+    n = L.match_oracle_search_by_schwarp(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), _p(x, D), kp1.shape[0], _p(kp1, C.c_float), _p(d1, C.c_uint8),
+                                         _p(cam2, C.c_float), _p(b2, C.c_float), int(grid[0]), int(grid[1]), kp2.shape[0], _p(kp2, C.c_float), _p(d2, C.c_uint8),
+                                         _p(mp2, C.c_uint8), C.c_float(radius), int(th_low), _p(match, C.c_int32))
+    assert n == int((match >= 0).sum())
+    return match

@@ -199,3 +199,19 @@ def test_warp_initialize_matches_oracle(gpu_ctx, oracle_mod, P, seed, lam):
         val, _ = nrsfm.bbs_eval(gpu_ctx, nrsfm.Bbs(b.umin, b.umax, b.nptsu, b.vmin, b.vmax, b.nptsv, 2), np.stack([xg[:N], xg[N:]]).T.reshape(-1),
                                 pr["kp1"][:, 0].astype(float), pr["kp1"][:, 1].astype(float))
         assert np.abs(val - pr["kp2"]).max() < 0.02
+
+
+@pytest.mark.parametrize("nq,nx,seed", [(600, 900, 2), (50, 0, 7), (1500, 4000, 9)])
+def test_search_by_schwarp_matches_oracle_bit_exact(gpu_ctx, oracle_mod, nq, nx, seed):
+    """DefORBmatcher::searchBySchwarp (SURVEY 8f rank 2, second half): index work, the bar is bit-exact -- including distance
+    ties (first candidate in the reference's grid visiting order), candidates with a map point, points outside image / grid."""
+    from defslam_amd import nrsfm, synth
+    sc = synth.make_match_scene(nq, nx, seed=seed)
+    mo = oracle_mod.search_by_schwarp(sc["bbs"], sc["x"], sc["kp1"], sc["desc1"], sc["cam2"], sc["bounds2"], sc["kp2"], sc["desc2"], sc["has_mp2"])
+    mg = nrsfm.searchBySchwarp(gpu_ctx, nrsfm.Bbs(*sc["bbs"]), sc["x"], sc["kp1"], sc["desc1"], sc["cam2"], sc["bounds2"], sc["kp2"], sc["desc2"], sc["has_mp2"])
+    np.testing.assert_array_equal(mg, mo)
+    assert (mo >= 0).sum() >= nq // 10
+    # no candidates at all / every candidate taken
+    none = nrsfm.searchBySchwarp(gpu_ctx, nrsfm.Bbs(*sc["bbs"]), sc["x"], sc["kp1"], sc["desc1"], sc["cam2"], sc["bounds2"], sc["kp2"], sc["desc2"],
+                                 np.ones_like(sc["has_mp2"]))
+    assert (none == -1).all()

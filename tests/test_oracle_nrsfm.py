@@ -163,3 +163,38 @@ def test_schwarp_fit_never_increases_the_cost(oracle_mod):
         assert info[0] <= 3 and costs[1] <= costs[0]
         if info[1] == 0:
             np.testing.assert_array_equal(x, pr["x0"])
+
+
+def test_match_search_oracle_equals_brute_force(oracle_mod):
+    """The grid-walking oracle of searchBySchwarp against an independent numpy brute force with the explicit tie-break key
+    (distance, grid column, grid row, index)."""
+    from defslam_amd import synth
+    sc = synth.make_match_scene(300, 500, seed=4)
+    m = oracle_mod.search_by_schwarp(sc["bbs"], sc["x"], sc["kp1"], sc["desc1"], sc["cam2"], sc["bounds2"], sc["kp2"], sc["desc2"], sc["has_mp2"])
+    assert (m >= 0).sum() > 50
+    bbs = sc["bbs"]
+    N = bbs[2] * bbs[5]
+    ctrl = np.stack([sc["x"][:N], sc["x"][N:]], 1).reshape(-1)
+    val, _ = oracle_mod.bbs_eval(bbs, ctrl, sc["kp1"][:, 0].astype(float), sc["kp1"][:, 1].astype(float))
+    e = val.astype(np.float32)
+    px = e[:, 0] * sc["cam2"][0] + sc["cam2"][2]
+    py = e[:, 1] * sc["cam2"][1] + sc["cam2"][3]
+    winv, hinv = np.float32(64) / np.float32(640), np.float32(48) / np.float32(480)
+    k2 = sc["kp2"]
+    cx = np.floor(k2[:, 0] * winv + np.float32(0.5)).astype(int)      # roundf for non-negative values; negatives fall outside anyway
+    cy = np.floor(k2[:, 1] * hinv + np.float32(0.5)).astype(int)
+    ingrid = (k2[:, 0] * winv > -0.5) & (cx < 64) & (k2[:, 1] * hinv > -0.5) & (cy < 48)
+    bits = np.unpackbits(sc["desc2"], axis=1)
+    for q in range(sc["kp1"].shape[0]):
+        exp = -1
+        if 0 <= px[q] < 640 and 0 <= py[q] < 480:
+            dx, dy = np.abs(k2[:, 0] - px[q]), np.abs(k2[:, 1] - py[q])
+            c0 = max(0, int(np.floor((px[q] - np.float32(2)) * winv))); c1 = min(63, int(np.ceil((px[q] + np.float32(2)) * winv)))
+            r0 = max(0, int(np.floor((py[q] - np.float32(2)) * hinv))); r1 = min(47, int(np.ceil((py[q] + np.float32(2)) * hinv)))
+            cand = np.where(ingrid & (dx < 2) & (dy < 2) & (sc["has_mp2"] == 0) & (cx >= c0) & (cx <= c1) & (cy >= r0) & (cy <= r1))[0]
+            if cand.size:
+                dist = (bits[cand] != np.unpackbits(sc["desc1"][q])[None, :]).sum(1)
+                keys = [(int(d), int(cx[j]), int(cy[j]), int(j)) for d, j in zip(dist, cand) if d < 50]
+                if keys:
+                    exp = min(keys)[3]
+        assert m[q] == exp, q
