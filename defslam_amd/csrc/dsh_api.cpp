@@ -82,6 +82,8 @@ struct Packed {
   SftDev h{};                   // sizes + scalars (pointers filled at upload)
   std::vector<int32_t> act, obs_nodes, ref_node, star_node, str_nodes, blk_rc, blk_ptr, diag_blk, off_blk;
   std::vector<uint32_t> contrib;
+  std::vector<int32_t> blk_hdr;      // 4 per block in processing order (diagonal blocks of nodes 0..nA-1, then the off-diagonal blocks): start, count, block row, block col
+  std::vector<double> cfac;          // 2 per contribution: constant factors of curvature / stretch contributions (H factor, b factor)
   std::vector<double> obs_bary, obs_uv, obs_w, star_sL, str_L0, xyz_init;
   double pose_init[7];
   int n_curv_ref = 0;           // curvature edges in the reference's (unfused) count
@@ -311,6 +313,31 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   h.hub_delta = (double)deltaMono;
   h.hub_dsqr = h.hub_delta * h.hub_delta;
   P.max_iters = f.max_iters;
+  // ---- constants of the gather pass: one header per block and, per contribution, the factors that do not depend on the
+  // state (curvature: w_curv * sL_e * c_s * c_t and w_curv * sL_e * c_s; stretch: +-w_str), so that the assembly kernel
+  // needs one dependent load level (record -> Jacobian record) instead of four (record -> star node -> neighbour list -> weight)
+  P.blk_hdr.clear();
+  P.blk_hdr.reserve(4 * (size_t)nblk);
+  for (int a = 0; a < nA; a++) {
+    const int q = P.diag_blk[a];
+    P.blk_hdr.insert(P.blk_hdr.end(), {P.blk_ptr[q], P.blk_ptr[q + 1] - P.blk_ptr[q], a, a});
+  }
+  for (int q : P.off_blk) P.blk_hdr.insert(P.blk_hdr.end(), {P.blk_ptr[q], P.blk_ptr[q + 1] - P.blk_ptr[q], P.blk_rc[2 * q], P.blk_rc[2 * q + 1]});
+  P.cfac.assign(2 * total, 0.0);
+  for (size_t p = 0; p < total; p++) {
+    const uint32_t rec = P.contrib[p], kind = rec >> 30, s = (rec >> 26) & 15u, u = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
+    if (kind == SFT_KIND_STAR) {
+      const int base = t.nbr_ptr[P.star_node[e]];
+      const double cs = (s == 0) ? 1.0 : t.nbr_c[base + s - 1];
+      const double ct = (u == 0) ? 1.0 : t.nbr_c[base + u - 1];
+      const double wt = h.w_curv * P.star_sL[e];
+      P.cfac[2 * p] = wt * (cs * ct);
+      P.cfac[2 * p + 1] = wt * cs;
+    } else if (kind == SFT_KIND_STR) {
+      P.cfac[2 * p] = ((s == 0) == (u == 0)) ? h.w_str : -h.w_str;
+      P.cfac[2 * p + 1] = (s == 0) ? h.w_str : -h.w_str;
+    }
+  }
   return DSH_OK;
 }
 
@@ -441,7 +468,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   st.clear();
   const size_t o_tab = a.take(sizeof(SftDev) * B);
   st.resize(a.size);
-  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, xyz_init, pose_init; };
+  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, hdr, cfac, xyz_init, pose_init; };
   std::vector<Offs> ro(B);
   for (int b = 0; b < B; b++) {
     Packed& P = c->packed[b];
@@ -450,7 +477,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     o.obs_w = put(st, a, P.obs_w); o.ref = put(st, a, P.ref_node); o.star = put(st, a, P.star_node); o.sL = put(st, a, P.star_sL);
     o.strn = put(st, a, P.str_nodes); o.strL = put(st, a, P.str_L0); o.rc = put(st, a, P.blk_rc); o.ptr = put(st, a, P.blk_ptr);
     o.dblk = put(st, a, P.diag_blk); o.oblk = put(st, a, P.off_blk);
-    o.contrib = put(st, a, P.contrib); o.xyz_init = put(st, a, P.xyz_init);
+    o.contrib = put(st, a, P.contrib); o.hdr = put(st, a, P.blk_hdr); o.cfac = put(st, a, P.cfac); o.xyz_init = put(st, a, P.xyz_init);
     std::vector<double> pi(P.pose_init, P.pose_init + 7);
     o.pose_init = put(st, a, pi);
   }
@@ -527,7 +554,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.star_node = (const int32_t*)(base + o.star); h.star_sL = (const double*)(base + o.sL); h.str_nodes = (const int32_t*)(base + o.strn);
     h.str_L0 = (const double*)(base + o.strL); h.blk_rc = (const int32_t*)(base + o.rc); h.blk_ptr = (const int32_t*)(base + o.ptr);
     h.diag_blk = (const int32_t*)(base + o.dblk); h.off_blk = (const int32_t*)(base + o.oblk);
-    h.contrib = (const uint32_t*)(base + o.contrib); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
+    h.contrib = (const uint32_t*)(base + o.contrib); h.blk_hdr = (const int32_t*)(base + o.hdr); h.cfac = (const double*)(base + o.cfac); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
     h.xyz = (double*)(base + w.xyz); h.xyz_bak = (double*)(base + w.bak); h.pose = (double*)(base + w.pose);
     h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
     h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);

@@ -382,7 +382,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
     __syncthreads();
   }
   // one contribution into the accumulators of a block (H 3x3; for diagonal blocks also the 6x3 camera block and b)
-  auto contribute = [&](uint32_t rec, bool diag, double* H, double* Hc, double* bn) {
+  auto contribute = [&](uint32_t rec, double cf, double cg, bool diag, double* H, double* Hc, double* bn) {
     const uint32_t kind = rec >> 30, s = (rec >> 26) & 15u, t = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
     if (kind == SFT_KIND_OBS) {
       const double* r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
@@ -405,28 +405,24 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
       }
     } else if (kind == SFT_KIND_STAR) {
       const double* r = jp.star + 4 * e;
-      const int base = P.nbr_ptr[P.star_node[e]];
-      const double cs = (s == 0) ? 1.0 : P.nbr_c[base + s - 1];
-      const double ct = (t == 0) ? 1.0 : P.nbr_c[base + t - 1];
-      const double wt = P.w_curv * P.star_sL[e];
       const double u0 = r[0], u1 = r[1], u2 = r[2];
-      const double f = wt * (cs * ct);
+      const double f = cf;      // w_curv * sL_e * (c_s * c_t), precomputed by the packer (state independent)
       H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
       H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
       H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
       if (diag) {
-        const double g = wt * cs * r[3];
+        const double g = cg * r[3];   // cg = w_curv * sL_e * c_s
         bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
       }
     } else if (kind == SFT_KIND_STR) {
       const double* r = jp.str + 4 * e;
-      const double sg = ((s == 0) == (t == 0)) ? P.w_str : -P.w_str;
+      const double sg = cf;     // +-w_str
       const double g0 = r[0], g1 = r[1], g2 = r[2];
       H[0] += sg * (g0 * g0); H[1] += sg * (g0 * g1); H[2] += sg * (g0 * g2);
       H[3] += sg * (g1 * g0); H[4] += sg * (g1 * g1); H[5] += sg * (g1 * g2);
       H[6] += sg * (g2 * g0); H[7] += sg * (g2 * g1); H[8] += sg * (g2 * g2);
       if (diag) {
-        const double g = (s == 0 ? P.w_str : -P.w_str) * r[3];
+        const double g = cg * r[3];
         bn[0] -= g * g0; bn[1] -= g * g1; bn[2] -= g * g2;
       }
     } else {  // SFT_KIND_REF (diagonal only, J = I)
@@ -460,8 +456,8 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
 #pragma unroll
       for (int i = 0; i < 30; i++) acc[i] = 0.0;
       if (a < P.nA) {
-        const int q = P.diag_blk[a];
-        for (int p = P.blk_ptr[q] + sub; p < P.blk_ptr[q + 1]; p += DG) contribute(P.contrib[p], true, acc, acc + 9, acc + 27);
+        const int p0 = P.blk_hdr[4 * a], p1 = p0 + P.blk_hdr[4 * a + 1];
+        for (int p = p0 + sub; p < p1; p += DG) contribute(P.contrib[p], P.cfac[2 * p], P.cfac[2 * p + 1], true, acc, acc + 9, acc + 27);
       }
 #pragma unroll
       for (int i = 0; i < 30; i++) {
@@ -485,12 +481,47 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
   // ---- off-diagonal blocks: one lane per block, contributions in the reference's edge order
   const int noff = P.nblk - P.nA;
   for (int o = threadIdx.x; o < noff; o += blockDim.x) {
-    const int q = P.off_blk[o];
+    const int4 hd = *reinterpret_cast<const SFT_G int4*>(P.blk_hdr + 4 * (P.nA + o));   // start, count, block row, block col
     double H[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) H[i] = 0.0;
-    for (int p = P.blk_ptr[q]; p < P.blk_ptr[q + 1]; p++) contribute(P.contrib[p], false, H, nullptr, nullptr);
-    store_block(P.blk_rc[2 * q], P.blk_rc[2 * q + 1], H);
+    // Contributions in chunks of CH: all records first, then all Jacobian rows of the chunk (independent loads in flight),
+    // then the sums in list order -- same arithmetic and order as one at a time, a third of the dependent round trips.
+    constexpr int CH = 4;
+    for (int p0 = hd.x; p0 < hd.x + hd.y; p0 += CH) {
+      uint32_t rc[CH];
+      double cf[CH];
+#pragma unroll
+      for (int i = 0; i < CH; i++) {
+        const bool on = p0 + i < hd.x + hd.y;
+        rc[i] = on ? P.contrib[p0 + i] : 0xFFFFFFFFu;
+        cf[i] = on ? P.cfac[2 * (p0 + i)] : 0.0;
+      }
+      double wt[CH], js[CH][6], jt[CH][6];
+#pragma unroll
+      for (int i = 0; i < CH; i++) {
+        if (rc[i] != 0xFFFFFFFFu && (rc[i] >> 30) == SFT_KIND_OBS) {
+          const uint32_t s2 = (rc[i] >> 26) & 15u, t2 = (rc[i] >> 22) & 15u, e = rc[i] & 0x3FFFFFu;
+          const auto r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
+          wt[i] = r[2];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { js[i][k] = r[16 + 6 * s2 + k]; jt[i][k] = r[16 + 6 * t2 + k]; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CH; i++) {
+        if (rc[i] == 0xFFFFFFFFu) continue;
+        if ((rc[i] >> 30) == SFT_KIND_OBS) {
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) H[3 * a + b] += wt[i] * (js[i][a] * jt[i][b] + js[i][3 + a] * jt[i][3 + b]);
+        } else {
+          contribute(rc[i], cf[i], 0.0, false, H, nullptr, nullptr);
+        }
+      }
+    }
+    store_block(hd.z, hd.w, H);
   }
   __syncthreads();
 }

@@ -65,6 +65,8 @@ struct SftDev {
   const SFT_G int32_t* diag_blk;  // nA: block index of every diagonal block
   const SFT_G int32_t* off_blk;   // nblk-nA: block indices of the off-diagonal blocks
   const SFT_G uint32_t* contrib;
+  const SFT_G int32_t* blk_hdr;   // 4 per block in processing order (nA diagonal blocks, then the off-diagonal ones): start, count, block row, block col
+  const SFT_G double* cfac;       // 2 per contribution: state-independent factors (H, b) of curvature / stretch contributions
   // initial state (restored at the start of every run)
   const SFT_G double* xyz_init;   // n*3
   const SFT_G double* pose_init;  // 7: t, q(x,y,z,w)
