@@ -1830,14 +1830,15 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   const auto Lbord = uni(P.Lbord);
   const auto Linv_g = uni(P.Linv);
   const auto xg = uni(P.x);
-  struct Pre { v4d t[RPW], li; double y, b[6]; };
+  // aux is wave specific: wave 0 keeps Linv_J (4 doubles) and y_J, wave 1 the six camera rows of the border; one shared
+  // field keeps a ring entry at 8 RPW + 12 registers
+  struct Pre { v4d t[RPW]; double aux[6]; };
   auto fetch = [&](int J) -> Pre {
     Pre p;
-    p.li = (v4d){0.0, 0.0, 0.0, 0.0}; p.y = 0.0;
 #pragma unroll
-    for (int t = 0; t < RPW; t++) p.t[t] = p.li;
+    for (int t = 0; t < RPW; t++) p.t[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 6; r++) p.b[r] = 0.0;
+    for (int r = 0; r < 6; r++) p.aux[r] = 0.0;
     if (J < 0) return p;
 #pragma unroll
     for (int t = 0; t < RPW; t++) {
@@ -1845,17 +1846,19 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
       if (J + d < nT) p.t[t] = *reinterpret_cast<const v4d*>(Lg + tile_off(J, d) + 4 * lane);   // column-major L: the BT tiles of block column J are contiguous (16 KB)
     }
     if (wave == 0) {
-      p.li = *reinterpret_cast<const v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
-      p.y = Lbord[(size_t)6 * Dnp + TS * J + ccol];
+      const v4d li = *reinterpret_cast<const v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
+#pragma unroll
+      for (int q = 0; q < 4; q++) p.aux[q] = li[q];
+      p.aux[4] = Lbord[(size_t)6 * Dnp + TS * J + ccol];
     } else if (wave == 1) {
 #pragma unroll
-      for (int r = 0; r < 6; r++) p.b[r] = Lbord[(size_t)r * Dnp + TS * J + ccol];
+      for (int r = 0; r < 6; r++) p.aux[r] = Lbord[(size_t)r * Dnp + TS * J + ccol];
     }
     return p;
   };
   // Tiles of the next PF blocks are in flight (register ring, the block loop is unrolled PF times): under load the
   // L tiles come from HBM, one block of look-ahead does not cover that latency.
-  constexpr int PF = 3;   // measured: 3 and 4 equal, 8 loses to register pressure
+  constexpr int PF = 6;
   Pre ring[PF];
 #pragma unroll
   for (int j = 0; j < PF; j++) ring[j] = fetch(nT - 1 - j);
@@ -1884,18 +1887,18 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
       if (wave == 1 && lane < TS) {
         double p = 0.0;
 #pragma unroll
-        for (int r = 0; r < 6; r++) p = fma(cur.b[r], xcr[r], p);
+        for (int r = 0; r < 6; r++) p = fma(cur.aux[r], xcr[r], p);
         part[lane] = p;
       }
       lds_barrier();
       if (wave == 0) {
-        double v = cur.y;
+        double v = cur.aux[4];
 #pragma unroll
         for (int i = 0; i <= BT; i++) v -= part[i * TS + ccol];
         // x[c] = sum_r Linv[r][c] v[r]   (v is replicated in every 16-lane group)
         double p = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) p = fma(cur.li[q], __shfl(v, crow + 4 * q, 64), p);
+        for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
         p += __shfl_xor(p, 16, 64);
         p += __shfl_xor(p, 32, 64);
         if (lane < TS) { xw[(J & (BT - 1)) * TS + lane] = p; xg[TS * J + lane] = p; }
