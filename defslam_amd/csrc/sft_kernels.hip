@@ -350,6 +350,14 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
 // ------------------------------------------------------------------------------------------
 // Normal equations: gather per 3x3 block from the Jacobian records (fixed contribution order).
 // ------------------------------------------------------------------------------------------
+// six consecutive doubles of a Jacobian record as three 16-byte loads (records are 288-byte strided, rows start at
+// 128 + 48 s bytes): the gathers are bound by address-processing cycles per lane, not by bytes
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load6(const SFT_G double* p, double* o) {
+  const SFT_G v2d* q = reinterpret_cast<const SFT_G v2d*>(p);
+  const v2d a = q[0], b = q[1], c = q[2];
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y;
+}
 __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
   // camera corner: H_cc (lower 21) and b_c (6) as a block-wide reduction over the observations
@@ -358,7 +366,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0.0;
     for (int m = threadIdx.x; m < P.M; m += blockDim.x) {
-      const double* rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
+      const auto rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
       const double wt = rec[2], e0 = rec[0], e1 = rec[1];
       double j0[6], j1[6];
 #pragma unroll
@@ -385,11 +393,11 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
   auto contribute = [&](uint32_t rec, double cf, double cg, bool diag, double* H, double* Hc, double* bn) {
     const uint32_t kind = rec >> 30, s = (rec >> 26) & 15u, t = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
     if (kind == SFT_KIND_OBS) {
-      const double* r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
+      const auto r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
       const double wt = r[2];
       double js[6], jt[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) { js[k] = r[16 + 6 * s + k]; jt[k] = r[16 + 6 * t + k]; }
+      load6(r + 16 + 6 * s, js);
+      load6(r + 16 + 6 * t, jt);
 #pragma unroll
       for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -504,8 +512,8 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
           const uint32_t s2 = (rc[i] >> 26) & 15u, t2 = (rc[i] >> 22) & 15u, e = rc[i] & 0x3FFFFFu;
           const auto r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
           wt[i] = r[2];
-#pragma unroll
-          for (int k = 0; k < 6; k++) { js[i][k] = r[16 + 6 * s2 + k]; jt[i][k] = r[16 + 6 * t2 + k]; }
+          load6(r + 16 + 6 * s2, js[i]);
+          load6(r + 16 + 6 * t2, jt[i]);
         }
       }
 #pragma unroll
