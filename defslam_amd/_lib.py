@@ -77,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "dsh_sft_batch_run_timed", "dsh_sft_batch_phase_ms", "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
     "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit",
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
+    "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
 ]
 
 _lib = None
@@ -128,6 +129,12 @@ def load() -> C.CDLL:
     L.dsh_search_by_schwarp.argtypes = [vp, C.POINTER(BbsC), c_double_p, C.c_int, c_float_p, c_u8_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, c_float_p,
                                         c_u8_p, c_u8_p, C.c_float, C.c_int, c_i32_p, c_i32_p]
     L.dsh_warp_initialize.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_float_p, c_float_p, C.c_double, c_double_p, c_i32_p]
+    c_i64_p = C.POINTER(C.c_int64)
+    L.dsh_template_embed_device.argtypes = [vp, C.c_int, c_float_p, c_i32_p, c_i32_p, c_float_p]
+    L.dsh_scale_min_median.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_double_p, C.c_int64, c_float_p, c_i64_p, c_i32_p]
+    L.dsh_optimize_horn.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_double_p, C.c_double, C.c_double, c_i32_p, c_double_p]
+    L.dsh_surface_register.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_double_p, C.c_int64, c_float_p, C.c_double, C.c_int, c_i32_p, c_double_p,
+                                       c_double_p, c_float_p, c_double_p]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("dsh_last_error", "dsh_stream"):

@@ -102,6 +102,8 @@ struct Arena {  // byte layout of a device allocation, 256-byte aligned slices
 
 }  // namespace
 
+extern "C" hipError_t reg_embed(int, const float*, int, const double*, const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, float*, hipStream_t);
+
 struct dsh_ctx : dsh_ctx_base {
   dsh::TemplateHost tmpl;
   // device copy of the template
@@ -442,6 +444,39 @@ int dsh_template_embed(const dsh_ctx* c, int P, const float* pts, int32_t* facet
   if (!c || !c->tmpl.valid || c->tmpl.F <= 0) return DSH_ERR_STATE;
   if (P < 0 || !pts || !facet_id || !nodes || !bary) return DSH_ERR_ARG;
   c->tmpl.embed(P, pts, facet_id, nodes, bary);
+  return DSH_OK;
+}
+
+int dsh_template_embed_device(dsh_ctx* c, int P, const float* pts, int32_t* facet_id, int32_t* nodes, float* bary) {
+  if (!c) return DSH_ERR_ARG;
+  if (!c->tmpl.valid || c->tmpl.F <= 0) return fail(c, DSH_ERR_STATE, "dsh_template_embed_device: needs a template built from facets");
+  if (P < 0 || (P > 0 && (!pts || !facet_id || !nodes || !bary))) return fail(c, DSH_ERR_ARG, "dsh_template_embed_device: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_template_embed_device: host-only context, no GPU (dsh_template_embed is the host routine)");
+  if (P == 0) return DSH_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, DSH_ERR_HIP, "dsh_template_embed_device: hipSetDevice failed");
+  const dsh::TemplateHost& t = c->tmpl;
+  c->scratch.reset();
+  hipStream_t st = c->stream;
+  struct Item { const void* src; size_t bytes; void* dev; };
+  Item in[5] = {{pts, 12 * (size_t)P, nullptr}, {t.xyz0.data(), 24 * (size_t)t.n, nullptr}, {t.facets.data(), 12 * (size_t)t.F, nullptr},
+                {t.nf_ptr.data(), 4 * (size_t)(t.n + 1), nullptr}, {t.nf_idx.data(), 4 * t.nf_idx.size(), nullptr}};
+  for (Item& it : in) {
+    if (c->scratch.take(it.bytes, &it.dev) != hipSuccess) return fail(c, DSH_ERR_HIP, "dsh_template_embed_device: out of device memory");
+    if (it.bytes && hipMemcpyAsync(it.dev, it.src, it.bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+      return fail(c, DSH_ERR_HIP, "dsh_template_embed_device: upload failed");
+  }
+  void *d_fid = nullptr, *d_nodes = nullptr, *d_bary = nullptr;
+  if (c->scratch.take(4 * (size_t)P, &d_fid) != hipSuccess || c->scratch.take(12 * (size_t)P, &d_nodes) != hipSuccess ||
+      c->scratch.take(12 * (size_t)P, &d_bary) != hipSuccess)
+    return fail(c, DSH_ERR_HIP, "dsh_template_embed_device: out of device memory");
+  hipError_t e = reg_embed(P, static_cast<const float*>(in[0].dev), t.n, static_cast<const double*>(in[1].dev), static_cast<const int32_t*>(in[2].dev),
+                           static_cast<const int32_t*>(in[3].dev), static_cast<const int32_t*>(in[4].dev), static_cast<int32_t*>(d_fid),
+                           static_cast<int32_t*>(d_nodes), static_cast<float*>(d_bary), st);
+  if (e == hipSuccess) e = hipMemcpyAsync(facet_id, d_fid, 4 * (size_t)P, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(nodes, d_nodes, 12 * (size_t)P, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(bary, d_bary, 12 * (size_t)P, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return fail(c, DSH_ERR_HIP, std::string("dsh_template_embed_device: ") + hipGetErrorString(e));
   return DSH_OK;
 }
 

@@ -130,6 +130,17 @@ class Context:
                     "dsh_template_embed")
         return fid, nodes, bary
 
+    def template_embed_device(self, pts: np.ndarray):
+        """Same as template_embed, on the GPU (one wavefront per point)."""
+        pts = np.ascontiguousarray(pts, np.float32)
+        P = pts.shape[0]
+        fid = np.zeros(P, np.int32)
+        nodes = np.zeros((P, 3), np.int32)
+        bary = np.zeros((P, 3), np.float32)
+        self._check(self._L.dsh_template_embed_device(self._h, P, _ptr(pts, C.c_float), _ptr(fid, C.c_int32), _ptr(nodes, C.c_int32), _ptr(bary, C.c_float)),
+                    "dsh_template_embed_device")
+        return fid, nodes, bary
+
     # ---- batched SfT ------------------------------------------------------------------------
     def _frame_c(self, f: Frame, reg_lap, reg_inex, reg_temp, layers, max_iters, keep: list) -> _lib.SftFrameC:
         Tcw = np.ascontiguousarray(f.Tcw, np.float32)

@@ -327,3 +327,21 @@ def make_match_scene(n_query: int = 600, n_extra: int = 900, seed: int = 2):
     kp2, desc2 = kp2[perm], desc2[perm]
     has_mp2 = (rng.uniform(size=kp2.shape[0]) < 0.2).astype(np.uint8)
     return dict(bbs=bbs, x=x, kp1=kp1, desc1=desc1, cam2=cam2, bounds2=bounds2, kp2=kp2, desc2=desc2, has_mp2=has_mp2)
+
+
+def make_register_scene(n: int = 600, seed: int = 5, noise: float = 2e-3, outliers: float = 0.05, scale: float = 1.35):
+    """Surface registration (SurfaceRegistration::registerSurfaces): a keyframe surface (up to scale, in world coordinates) and
+    the map points it has to be aligned with, the keyframe's inverse pose and a stream of uniform numbers for scaleMinMedian."""
+    rng = np.random.default_rng(seed)
+    surf = np.stack([rng.uniform(-0.4, 0.4, n), rng.uniform(-0.3, 0.3, n), 1.0 + 0.15 * rng.standard_normal(n)], 1)
+    R = _rodrigues(np.array([0.02, -0.035, 0.015]))
+    t = np.array([0.03, -0.02, 0.05])
+    mp = scale * (surf @ R.T) + t + noise * rng.standard_normal((n, 3))
+    bad = rng.random(n) < outliers
+    mp[bad] += 0.2 * rng.standard_normal((int(bad.sum()), 3))
+    Rwc = _rodrigues(np.array([0.1, 0.05, -0.07]))
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, :3] = Rwc.astype(np.float32)
+    Twc[:3, 3] = np.array([0.2, -0.1, 0.3], np.float32)
+    u = rng.random(n + n * n)
+    return dict(surface=surf.astype(np.float32), map=mp.astype(np.float32), Twc=Twc, u=u, scale=scale, R=R, t=t, outlier=bad)

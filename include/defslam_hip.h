@@ -224,6 +224,39 @@ int dsh_search_by_schwarp(dsh_ctx* ctx, const dsh_bbs* bbs, const double* x, int
  * N x N matrix, host side (the constant part of the Shape-from-Normals system). */
 int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending);
 
+/* ---- surface registration ---------------------------------------------------------------------- */
+/* Barycentric embedding on the device: same contract and results as dsh_template_embed (TriangularMesh.cc:133-236), one
+ * wavefront per point (closest node, then the node's facets in index order).  Needs a template built from facets. */
+int dsh_template_embed_device(dsh_ctx* ctx, int P, const float* pts /* P*3 */, int32_t* facet_id, int32_t* nodes /* P*3 */,
+                              float* bary /* P*3 */);
+/* GroundTruthTools::scaleMinMedian(PosMono, PosStereo) (Modules/GroundTruth/GroundTruthCalculator.cc:54-160).  The reference
+ * draws `(double)rand() / RAND_MAX` while it runs; here the stream of those numbers is an input (u[k] = the k-th draw,
+ * consumed in the reference's order: one per point i, and n-1 more for every i that was selected), so a shim that fills it
+ * from rand() reproduces the reference.  *status: 0 ok, 1 stream too short (DSH_ERR_ARG is returned as well), 2 the
+ * reference's early `return 0.0` (a selected point whose own selection holds fewer than two residuals; the reference reads
+ * past the end of a vector when it holds none -- defined as the same early return).  *consumed (may be NULL) = draws used
+ * when status is 0. */
+int dsh_scale_min_median(dsh_ctx* ctx, int n, const float* pos_mono /* n*3 */, const float* pos_stereo /* n*3 */, const double* u,
+                         int64_t nu, float* scale, int64_t* consumed, int32_t* status);
+/* Optimizer::OptimizeHorn(pts1, pts2, g2oS12, chi, huber) (Modules/Tracking/DefOptimizer.cc:840-922): Levenberg-Marquardt on
+ * one Sim(3) vertex with edges e_i = pts2_i - S.map(pts1_i), Huber(sqrt(huber) as float), numeric Jacobians (g2o's central
+ * differences, delta 1e-9), optimize(50) twice.  sim3[8] = {qx, qy, qz, qw, tx, ty, tz, s}: in the initial estimate, out the
+ * estimate after the FIRST optimize (what the reference reads back, :896).  *acceptable = the function's return value.
+ * info[6] (may be NULL) = {plain chi2 of all edges after the second optimize, count, iterations 1st, iterations 2nd, damping
+ * trials 1st, trials 2nd}. */
+int dsh_optimize_horn(dsh_ctx* ctx, int n, const float* pts1 /* n*3 */, const float* pts2 /* n*3 */, double* sim3 /* 8 */, double chi,
+                      double huber, int32_t* acceptable, double* info /* 6 */);
+/* SurfaceRegistration::registerSurfaces (Modules/Mapping/SurfaceRegistration.cc:48-153), numeric part: cloud_surface = the
+ * keyframe's surface points in world coordinates (cloud2pc), cloud_map = the map points' positions at that keyframe
+ * (cloud1pc), Twc = the keyframe's inverse pose (4x4 row-major float32).  Fewer than 15 pairs -> *registered = 0.  Otherwise
+ * scaleMinMedian(cloud_surface, cloud_map) initialises the scale, OptimizeHorn (chi = chi_limit^2, huber 0.01) aligns, and
+ * unless (!acceptable && check_chi) the Sim(3) is composed with Twc: *s22 = recovered scale (Surface::applyScale takes it),
+ * Tcw_new = the new keyframe pose (float32).  The clouds stay on the device between the two steps.
+ * info[8] (may be NULL) = {initial scale, chi2, count, iterations 1st/2nd, trials 1st/2nd, acceptable}. */
+int dsh_surface_register(dsh_ctx* ctx, int n, const float* cloud_surface /* n*3 */, const float* cloud_map /* n*3 */, const double* u,
+                         int64_t nu, const float* Twc /* 16 */, double chi_limit, int check_chi, int32_t* registered, double* sim3 /* 8 */,
+                         double* s22, float* Tcw_new /* 16 */, double* info /* 8 */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -443,3 +443,64 @@ def search_by_schwarp(bbs, x, kp1, desc1, cam2, bounds2, kp2, desc2, has_mp2, ra
                                          _p(mp2, C.c_uint8), C.c_float(radius), int(th_low), _p(match, C.c_int32))
     assert n == int((match >= 0).sum())
     return match
+
+
+# ---- surface registration oracle (horn_oracle.c) -------------------------------------------------------
+def sim3_exp(u):
+    """g2o Sim3(update): returns [qx qy qz qw tx ty tz s]."""
+    L = lib()
+    u = np.ascontiguousarray(u, np.float64)
+    out = np.zeros(8)
+    L.horn_oracle_sim3_exp(_p(u, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def horn_system(pts1, pts2, sim3, huber=0.01):
+    """Normal equations of one OptimizeHorn linearisation: (H 7x7, b 7, robust chi2)."""
+    L = lib()
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 3)
+    p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 3)
+    s = np.ascontiguousarray(sim3, np.float64)
+    H = np.zeros((7, 7)); b = np.zeros(7); chi = C.c_double()
+    L.horn_oracle_system(p1.shape[0], _p(p1, C.c_float), _p(p2, C.c_float), _p(s, C.c_double), C.c_double(huber), _p(H, C.c_double), _p(b, C.c_double),
+                         C.byref(chi))
+    return H.T.copy(), b, chi.value
+
+
+def scale_min_median(mono, stereo, u):
+    """GroundTruthTools::scaleMinMedian with the rand() stream given as `u`: dict(scale, consumed, status, medians)."""
+    L = lib()
+    m = np.ascontiguousarray(mono, np.float32).reshape(-1, 3)
+    s = np.ascontiguousarray(stereo, np.float32).reshape(-1, 3)
+    u = np.ascontiguousarray(u, np.float64)
+    consumed = C.c_int32(); status = C.c_int32()
+    med = np.zeros(m.shape[0], np.float32)
+    L.horn_oracle_scale_min_median.restype = C.c_float
+    sc = L.horn_oracle_scale_min_median(m.shape[0], _p(m, C.c_float), _p(s, C.c_float), _p(u, C.c_double), u.shape[0], C.byref(consumed), C.byref(status),
+                                        _p(med, C.c_float))
+    return dict(scale=float(sc), consumed=consumed.value, status=status.value, medians=med)
+
+
+def optimize_horn(pts1, pts2, sim3_init, chi, huber=0.01, device_sum_order=False):
+    """Optimizer::OptimizeHorn: dict(ok, sim3, chi2, count, iters[2], trials[2]).  device_sum_order: add the edges' terms
+    in the fixed tree of the device kernel instead of edge order (same numbers to rounding; used to compare trajectories)."""
+    L = lib()
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 3)
+    p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 3)
+    s = np.array(sim3_init, np.float64).copy()
+    chi2 = C.c_double(); count = C.c_int32()
+    iters = np.zeros(2, np.int32); trials = np.zeros(2, np.int32)
+    L.horn_oracle_optimize.restype = C.c_int
+    ok = L.horn_oracle_optimize(p1.shape[0], _p(p1, C.c_float), _p(p2, C.c_float), _p(s, C.c_double), C.c_double(chi), C.c_double(huber), int(bool(device_sum_order)),
+                                C.byref(chi2), C.byref(count), _p(iters, C.c_int32), _p(trials, C.c_int32))
+    return dict(ok=bool(ok), sim3=s, chi2=chi2.value, count=count.value, iters=iters, trials=trials)
+
+
+def horn_compose(sim3, Twc):
+    """Tail of SurfaceRegistration::registerSurfaces: (s22, new Tcw float32 4x4)."""
+    L = lib()
+    s = np.ascontiguousarray(sim3, np.float64)
+    T = np.ascontiguousarray(Twc, np.float32).reshape(16)
+    s22 = C.c_double(); out = np.zeros(16, np.float32)
+    L.horn_oracle_compose(_p(s, C.c_double), _p(T, C.c_float), C.byref(s22), _p(out, C.c_float))
+    return s22.value, out.reshape(4, 4)

@@ -1,0 +1,45 @@
+"""Surface registration timing: device path (scaleMinMedian + OptimizeHorn + composition, template embedding) vs the CPU oracle, 1 core."""
+import sys, time, json
+import numpy as np
+sys.path.insert(0, ".")
+from defslam_amd import sft, register, synth
+import oracle
+ctx = sft.Context(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+sc = synth.make_register_scene(n, seed=21, outliers=0.0)
+
+
+def timeit(f, reps):
+    f()
+    t = time.perf_counter()
+    for _ in range(reps):
+        f()
+    return (time.perf_counter() - t) / reps
+
+
+dt = timeit(lambda: register.registerSurfaces(ctx, sc["surface"], sc["map"], sc["u"], sc["Twc"], 0.05), 20)
+dm = timeit(lambda: register.scaleMinMedian(ctx, sc["surface"], sc["map"], sc["u"]), 20)
+dh = timeit(lambda: register.OptimizeHorn(ctx, sc["surface"], sc["map"], [0, 0, 0, 1, 0, 0, 0, 1.3], 0.0025), 20)
+
+
+def cpu():
+    s0 = oracle.scale_min_median(sc["surface"], sc["map"], sc["u"])
+    o = oracle.optimize_horn(sc["surface"], sc["map"], [0, 0, 0, 1, 0, 0, 0, s0["scale"]], chi=0.0025)
+    return oracle.horn_compose(o["sim3"], sc["Twc"])
+
+
+dc = timeit(cpu, 3)
+dcm = timeit(lambda: oracle.scale_min_median(sc["surface"], sc["map"], sc["u"]), 3)
+tmpl = synth.make_grid_template(25, 20)
+ctx.template_build(tmpl.xyz0, tmpl.facets)
+rng = np.random.default_rng(0)
+fac = rng.integers(0, tmpl.facets.shape[0], size=n)
+bary = rng.dirichlet((1, 1, 1), size=n)
+pts = (bary[:, :, None] * tmpl.xyz0[tmpl.facets[fac]]).sum(1).astype(np.float32)
+de = timeit(lambda: ctx.template_embed_device(pts), 20)
+deh = timeit(lambda: ctx.template_embed(pts), 5)
+print(json.dumps({"metric": "surface registrations/s", "value": 1 / dt, "unit": "registrations/s", "pairs": n, "ms_per_call": 1e3 * dt,
+                  "ms_scale_min_median": 1e3 * dm, "ms_optimize_horn": 1e3 * dh, "ms_embed_device": 1e3 * de, "ms_embed_host_cpp": 1e3 * deh,
+                  "uniform_draws": int(sc["u"].shape[0]),
+                  "cpu_baseline": {"value": 1 / dc, "unit": "registrations/s", "cores": 1, "kind": "port", "ms_scale_min_median": 1e3 * dcm,
+                                   "sample": "same scene, oracle/horn_oracle.c"}}))
