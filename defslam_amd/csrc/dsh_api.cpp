@@ -23,7 +23,7 @@ extern "C" hipError_t sft_lm_launch_dense(const SftDev* d_probs, int B, int max_
 namespace {
 
 constexpr int kNB = 32;  // must match NB in sft_kernels.hip
-constexpr int kTS = 16, kBT = 8;  // must match TS / BT in sft_kernels.hip
+constexpr int kTS = 16, kBT = 8, kWB = 16;  // must match TS / BT in sft_kernels.hip and WB in sft_wide.h
 
 // ---- pose conversions at the float32 boundary (Converter.cc:35-66, se3quat.h:58-64,269-285) -------
 void pose7_from_Tcw(const float* T, double* p) {
@@ -302,7 +302,11 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   pose7_from_Tcw(f.Tcw, P.pose_init);
   SftDev& h = P.h;
   h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
-  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : 0;
+  // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; DSH_SFT_WIDE_OFF=1 keeps the
+  // row-major band solver for A/B runs), row-major band otherwise
+  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : ((h.kd <= kTS * kWB && !std::getenv("DSH_SFT_WIDE_OFF")) ? 2 : 0);
+  h.tpr = h.tile_mode == 1 ? kBT + 1 : (h.tile_mode == 2 ? (h.kd + kTS - 1) / kTS + 1 : 0);
+  h.pad0_ = 0;
   h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
 #ifdef SFT_EXPERIMENTS
   if (const char* dm = std::getenv("DSH_EXPERIMENT")) h.mode = std::atoi(dm) & ~1;  // tuning builds only: phases switched off, results invalid
@@ -517,7 +521,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     o.pose_init = put(st, a, pi);
   }
   c->ro_bytes = a.size;
-  struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, x, chi2, ferr, trace, info, dbg; };
+  struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, chi2, ferr, trace, info, dbg; };
   std::vector<WOffs> wo(B);
   int max_kd = 0;
   size_t jl_doubles = 0;
@@ -526,7 +530,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   int nw = 8;
   {
     bool all_tiles = true;
-    for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode;
+    for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode == 1;
     if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
     if (const char* e = std::getenv("DSH_SFT_WAVES")) {
       const int v = std::atoi(e);
@@ -539,13 +543,13 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     if (const char* e = std::getenv("DSH_SFT_DATAFLOW")) dataflow = std::atoi(e) != 0;
     for (int b = 0; b < B; b++) {
       SftDev& hh = c->packed[b].h;
-      hh.mode = (hh.mode & ~2) | ((hh.tile_mode && dataflow) ? 2 : 0);
+      hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && dataflow) ? 2 : 0);
     }
   }
   bool dense = false;
   if (const char* e = std::getenv("DSH_SFT_DENSE")) dense = std::atoi(e) != 0 && nw == 8;
   if (dense)
-    for (int b = 0; b < B; b++) dense = dense && c->packed[b].h.tile_mode;
+    for (int b = 0; b < B; b++) dense = dense && c->packed[b].h.tile_mode == 1;
   const size_t jl_cap = ((nw == 4 || dense) ? 72 : 96) * 1024;
   for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to the solver workspace
     SftDev& hh = c->packed[b].h;
@@ -561,11 +565,12 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.Jobs = a.take(8 * (size_t)h.M * SFT_JOBS_STRIDE); w.Jstar = a.take(8 * 4 * (size_t)h.S); w.Jstr = a.take(8 * 4 * (size_t)h.Es); w.Jref = a.take(8 * 4 * (size_t)h.V);
     // tile mode: BT+1 zero tile rows below the matrix and an 8th (zero) border row + one window of columns let the
     // factorisation load every tile of its sliding window unconditionally (SFT_H_PAD_* in sft_problem.h)
-    const size_t band_elems = h.tile_mode ? (Dnp / kTS + SFT_H_PAD_TILE_ROWS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
+    const size_t band_elems = h.tile_mode ? (Dnp / kTS + SFT_H_PAD_TILE_ROWS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;
     const size_t bord_elems = (SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER;
     w.Hb = a.take(8 * band_elems); w.Hbord = a.take(8 * bord_elems); w.Hc = a.take(8 * 56);
     w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * bord_elems); w.Lc = a.take(8 * 56);
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
+    w.Lt = a.take(h.tile_mode == 2 ? 8 * band_elems : 0); w.LbT = a.take(h.tile_mode == 2 ? 8 * (Dnp / kTS) * (size_t)kTS * kTS : 0);
     w.x = a.take(8 * (Dnp + 8)); w.chi2 = a.take(8 * (size_t)h.M); w.ferr = a.take(8 * (size_t)h.M);
     w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(1024);
     max_kd = std::max(max_kd, h.kd);
@@ -594,6 +599,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
     h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
     h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc); h.Linv = (double*)(base + w.Linv);
+    h.Lt = (double*)(base + w.Lt); h.LbT = (double*)(base + w.LbT);
     h.x = (double*)(base + w.x); h.chi2_obs = (double*)(base + w.chi2); h.final_err = (double*)(base + w.ferr);
     h.trace = (double*)(base + w.trace); h.info = (int32_t*)(base + w.info); h.dbg = (double*)(base + w.dbg);
     c->h_probs[b] = h;
@@ -770,10 +776,12 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   h.mode = mode_saved;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
-  const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)(kBT + 1) * kTS * kTS : Dnp * (size_t)h.ldh;
+  const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;
   std::vector<double> Hb(band_elems), Hbord(SFT_BORDER * Dnp), Hc(56);
   auto hidx = [&](int r, int cc) -> size_t {
-    if (h.tile_mode) return ((size_t)(r >> 4) * (kBT + 1) + ((r >> 4) - (cc >> 4))) * (kTS * kTS) + ((((r & 15) & 3) << 4) + (cc & 15)) * 4 + ((r & 15) >> 2);
+    const size_t tb = ((size_t)(r >> 4) * h.tpr + ((r >> 4) - (cc >> 4))) * (kTS * kTS);
+    if (h.tile_mode == 1) return tb + ((((r & 15) & 3) << 4) + (cc & 15)) * 4 + ((r & 15) >> 2);
+    if (h.tile_mode == 2) return tb + ((((cc & 15) & 3) << 4) + (r & 15)) * 4 + ((cc & 15) >> 2);   // wide mode keeps the tiles transposed
     return (size_t)r * h.ldh + (cc - r + h.kd);
   };
   HIPCHK(c, hipMemcpy(Hb.data(), h.Hb, 8 * Hb.size(), hipMemcpyDeviceToHost));

@@ -17,6 +17,7 @@
 // Every sum is evaluated in a fixed order (no atomics), so a run is bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <math.h>
@@ -81,7 +82,8 @@ __device__ __forceinline__ size_t tile_off(int I, int d) { return ((size_t)I * (
 __device__ __forceinline__ int tile_elem(int row, int col) { return (((row & 3) << 4) + col) * 4 + (row >> 2); }
 
 __device__ __forceinline__ size_t h_index(const SftDev& P, int r, int c) {
-  if (P.tile_mode) return tile_off(r >> 4, (r >> 4) - (c >> 4)) + tile_elem(r & 15, c & 15);
+  if (P.tile_mode == 1) return tile_off(r >> 4, (r >> 4) - (c >> 4)) + tile_elem(r & 15, c & 15);
+  if (P.tile_mode == 2) return ((size_t)(r >> 4) * P.tpr + ((r >> 4) - (c >> 4))) * (TS * TS) + tile_elem(c & 15, r & 15);   // wide mode: tiles hold H(I,J)^T
   return (size_t)r * P.ldh + (c - r + P.kd);
 }
 
@@ -447,8 +449,12 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
       for (int b = 0; b < 3; b++) {
         const int c = 3 * bj + b;
         if (c <= r) {
-          P.Hb[h_index(P, r, c)] = H[3 * a + b];
-          if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) P.Hb[tile_off(r >> 4, 0) + tile_elem(c & 15, r & 15)] = H[3 * a + b];
+          const size_t idx = h_index(P, r, c);
+          P.Hb[idx] = H[3 * a + b];
+          if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) {   // diagonal tiles are stored symmetric: the mirrored element of the same tile
+            const int e1 = tile_elem(r & 15, c & 15), e2 = tile_elem(c & 15, r & 15);
+            P.Hb[idx + (P.tile_mode == 2 ? e1 - e2 : e2 - e1)] = H[3 * a + b];
+          }
         }
       }
     }
@@ -1917,6 +1923,8 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   __syncthreads();
 }
 
+#include "sft_wide.h"
+
 // ------------------------------------------------------------------------------------------
 // The persistent per-problem kernel
 // ------------------------------------------------------------------------------------------
@@ -1938,9 +1946,10 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
   if (P.tile_mode) {
-    const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * (BT + 1) * TS * TS;   // incl. the zero tile rows below the matrix
+    const int tpr = P.tpr;
+    const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
     for (size_t i = tid; i < nel; i += NT) {
-      const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % (BT + 1)), I = (int)(i / ((size_t)(BT + 1) * TS * TS));
+      const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % tpr), I = (int)(i / ((size_t)tpr * TS * TS));
       const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
       const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn && I < Dnp / TS;
       P.Hb[i] = pad_diag ? 1.0 : 0.0;
@@ -1991,7 +2000,14 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
       for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];
       double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
       PH_ADD(7);
-      if (P.tile_mode) {
+      if (P.tile_mode == 2) {
+        if constexpr (NW == 8) {   // wide band: always the 512-thread kernel
+          factor_wide(P, ctl, panel);
+          PH_ADD(5);
+          backsub_wide(P, ctl, panel);
+          PH_ADD(6);
+        }
+      } else if (P.tile_mode) {
         if (P.mode & 2) {
           PH_RESET();
           if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel);
@@ -2098,6 +2114,7 @@ extern "C" size_t SFT_LDS_BYTES_NAME(int kd, size_t jl_doubles) {
   if (backsub > panel) panel = backsub;
   const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 48 + 128 + 128;  // dataflow layout (the larger one) + step-trace stamps
   if (kd <= TS * BT) panel = tiles;
+  else if (kd <= TS * WB) panel = std::max(panel, (size_t)2 * WB * TS * TS + TILE_LDS + 640);   // wide mode: two staged tile rows, W, corners (or the band panel)
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }

@@ -38,7 +38,9 @@
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
-  int32_t tile_mode, jl_lds;  // 1: 16x16-tile band storage + MFMA factorisation (kd <= 128); 0: row-major band (general)
+  int32_t tile_mode, jl_lds;  // 1: 16x16-tile band storage + register-window MFMA factorisation (kd <= 128); 2: wide tile band, left-looking
+                              // MFMA factorisation (kd <= 256, sft_wide.h); 0: row-major band (general)
+  int32_t tpr, pad0_;         // tile modes: tiles per tile row of the band storage (9 in mode 1, ceil(kd/16) + 1 in mode 2)
   double fx, fy, cx, cy;
   double w_ref, w_curv, w_str, hub_delta, hub_dsqr;
   // template (shared by every problem of a batch)
@@ -79,14 +81,17 @@ struct SftDev {
   SFT_G double* Jstr;             // Es*4 (g, e)
   SFT_G double* Jref;             // V*4  (e)
   SFT_G double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
-                            // tile mode: nT*(BT+1) 16x16 tiles, tile (I,J) at (I*(BT+1) + I-J)*256, element (row,col) at
-                            //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register)
+                            // tile mode: nT*tpr 16x16 tiles, tile (I,J) at (I*tpr + I-J)*256, element (row,col) at
+                            //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register);
+                            //            mode 2 stores the off-diagonal tiles transposed (element (col,row))
   SFT_G double* Hbord;            // 7*Dn     rows 0-5: camera x node, row 6: b_node
   SFT_G double* Hcorner;          // 7*7      camera x camera (lower) + b_cam in row 6
   SFT_G double* Lb;               // Dn*ldh
   SFT_G double* Lbord;            // 7*Dn
   SFT_G double* Lcorner;          // 7*7
   SFT_G double* Linv;             // tile mode: nT inverse diagonal tiles (16x16 row-major)
+  SFT_G double* Lt;               // mode 2: the transposed L tiles (tile (I,K) holds X(I,K)^T at slot (K, I-K)), operands of the left-looking update
+  SFT_G double* LbT;              // mode 2: nT tiles, tile K = transposed 7x16 border block of block column K
   SFT_G double* x;                // Dn+6
   // outputs
   SFT_G double* chi2_obs;         // M

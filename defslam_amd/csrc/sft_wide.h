@@ -1,0 +1,306 @@
+// Wide-band tile solver of the SfT normal equations (included by sft_kernels.hip inside its anonymous namespace):
+// half-bandwidths 128 < kd <= 256 (e.g. the 2000-node stress template, kd = 248), where the trailing window of the
+// right-looking tile factorisation (17 x 17 tiles) no longer fits the register file.
+//
+// LEFT-looking block Cholesky on 16x16 FP64 MFMA tiles, 8 wavefronts, one block column J per iteration:
+//   accT(I,J) = H(I,J)^T - sum_{K = I-wb .. J-1} L(J,K) L(I,K)^T        rows I = J .. J+wb and the 7-row camera/rhs border
+//   W_J = inverse Cholesky factor of acc(J,J)                            (chol_inv_blocked, tile_chol.h)
+//   X(I,J)^T = W_J accT(I,J)                                             (TRSM as a GEMM)
+// Every tile is produced once.  Both MFMA operands of the update are taken as they are stored: a register of a tile in
+// accumulator layout is a 4x16 / 16x4 operand chunk that contracts over the tile's ROW index, so the factor keeps the
+// TRANSPOSE of every L tile (Lt: tile (I,K) holds X(I,K)^T, slot (K, I-K)) and, in this mode, H holds H(I,J)^T in tile
+// (I,J).  The tiles of tile row J (the A operands shared by all rows of the column) are staged in LDS one column ahead;
+// the tile produced last, X(J+1,J)^T, goes there straight from the registers.  The back substitution contracts over the
+// other index, so the TRSM also emits X(I,J) itself (4 more MFMAs per tile) into Lb, block-column layout like tile mode.
+// Work per column: (16 + 15 + ... + 1) + 16 border products of 4 MFMAs each + 18 TRSMs of 8 = 750 MFMAs on 4 SIMDs (12 k
+// cycles); measured 31 k cycles per column on the 2000-node template: the waves wait for operand tiles.
+#pragma once
+
+#define WB 16   // most sub-diagonal tiles per block column in wide mode (half-bandwidth <= 256)
+
+__device__ __forceinline__ size_t wtile_off(int tpr, int I, int d) { return ((size_t)I * tpr + d) * (TS * TS); }
+
+__device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Dn = uni(P.Dn);
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  const int nT = Dnp / TS;
+  const int tpr = uni(P.tpr), wb = tpr - 1;
+  lds_double* Lrow = to_lds(ws);                       // 2 x WB tiles, native layout (lane, 4 doubles): row-J tiles, dist 1..wb
+  lds_double* LinvK = Lrow + 2 * WB * TS * TS;         // W_J, k-major padded: LinvK[k*TP + j] = W[j][k]
+  lds_double* Cn = LinvK + TILE_LDS;                   // 8 partial 7x7 corners, then the corner itself
+  const double lambda = ctl->lambda;
+  const int crow = lane >> 4, ccol = lane & 15;
+  const auto Hg = uni(P.Hb);
+  const auto Hbord = uni(P.Hbord);
+  const auto Lg = uni(P.Lb);
+  const auto Ltg = uni(P.Lt);
+  const auto LbTg = uni(P.LbT);
+  const auto Lbord = uni(P.Lbord);
+  const auto Linv_g = uni(P.Linv);
+  v4d cacc = {0.0, 0.0, 0.0, 0.0};     // this wave's share of the corner updates; wave 0 starts from H_cc + lambda I
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
+    }
+  }
+  if (tid == 0) ctl->fact_ok = 1;
+  __syncthreads();
+
+  // sum_K L(J,K) L(I,K)^T for one row: A operand = row-J tile (LDS), B operand = the stored tile of row I (memory; LDS for
+  // the diagonal row).  The operands of U products are fetched before their MFMAs issue.
+  constexpr int U = 8;
+  using lds_v4d = __attribute__((address_space(3))) v4d;
+  const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
+    // brow: tile of block column K0 for this row; the tile of block column K0 + i sits i * bstride doubles further
+    v4d s0 = zero4, s1 = zero4;
+#pragma unroll 1
+    for (int K = K0; K < J; K += U) {
+      v4d b[U];
+      if (I != J) {
+#pragma unroll
+        for (int u = 0; u < U; u++) b[u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)(min(K + u, J - 1) - K0) * bstride + 4 * lane);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (K + u < J) {
+          const v4d a = *reinterpret_cast<const lds_v4d*>(rowJ + (size_t)(J - K - u - 1) * TS * TS + 4 * lane);
+          const v4d bb = (I == J) ? a : b[u];
+          s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], bb[0], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], bb[1], s1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], bb[2], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], bb[3], s1, 0, 0, 0);
+        }
+    }
+    return s0 + s1;
+  };
+  const long kstride = (long)(tpr - 1) * TS * TS;        // tile (I, K+1) sits (tpr - 1) tiles after tile (I, K)
+
+#pragma unroll 1
+  for (int J = 0; J < nT; J++) {
+    lds_double* rowJ = Lrow + (size_t)(J & 1) * WB * TS * TS;
+    lds_double* rowN = Lrow + (size_t)((J + 1) & 1) * WB * TS * TS;
+    const int d = (wave - J) & 7;                       // this wave's rows: J + d, J + d + 8 (and J + 16 on the diagonal owner)
+    // stage tile row J+1 for the next column: dist 2 + wave and 10 + wave (dist 1 is produced by this column's TRSM)
+    v4d stage[2];
+    bool staged[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int dist = 2 + wave + 8 * h, K = J + 1 - dist;
+      staged[h] = dist <= wb && K >= 0 && J + 1 < nT;
+      if (staged[h]) stage[h] = *reinterpret_cast<const SFT_G v4d*>(Ltg + wtile_off(tpr, K, dist) + 4 * lane);
+    }
+    v4d accT[3];
+    bool have[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int I = J + d + 8 * t;
+      have[t] = I < nT && I - J <= wb && (t < 2 || d == 0);
+      if (have[t]) {
+        const v4d h = *reinterpret_cast<const SFT_G v4d*>(Hg + wtile_off(tpr, I, I - J) + 4 * lane);
+        const int K0 = max(0, I - wb);
+        accT[t] = h - products(J, I, rowJ, Ltg + wtile_off(tpr, K0, I - K0), kstride, K0);
+      }
+      if (t == 0 && d == 0) {
+        // diagonal tile first: it is the critical path of the column
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (crow + 4 * q == ccol && TS * J + ccol < Dn) accT[0][q] += lambda;
+        v4d w = accT[0];
+        const bool ok = chol_inv_blocked(accT[0], w);
+        if (!ok && lane == 0) ctl->fact_ok = 0;
+        lds_double* dst = LinvK + ccol * TP + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
+        *reinterpret_cast<SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane) = w;
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    // border: accTb[j][i] = Hbord[i][16 J + j] - sum_K (L(J,K) Lb(K)^T)[j][i], i < 7
+    v4d accTb = zero4;
+    const bool bwave = d == 7;
+    if (bwave) {
+      v4d h = zero4;
+      if (ccol < SFT_BORDER) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[q] = Hbord[(size_t)ccol * Dnp + TS * J + crow + 4 * q];
+      }
+      const int K0 = max(0, J - wb);
+      accTb = h - products(J, nT, rowJ, LbTg + (size_t)K0 * TS * TS, (long)TS * TS, K0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (staged[h]) *reinterpret_cast<lds_v4d*>(rowN + (size_t)(1 + wave + 8 * h) * TS * TS + 4 * lane) = stage[h];
+    lds_barrier();                                       // W_J is published
+    // ---- TRSM: X^T = W accT (kept for the factor), X = acc W^T (kept for the back substitution) ----
+    double wv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) wv[kk] = LinvK[(4 * kk + crow) * TP + ccol];     // lane (x = ccol, k = crow): W[x][4kk + k]
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int I = J + d + 8 * t;
+      if (!have[t] || I == J) continue;
+      v4d xT = zero4, x = zero4;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        xT = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], accT[t][kk], xT, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(accT[t][kk], wv[kk], x, 0, 0, 0);
+      }
+      *reinterpret_cast<SFT_G v4d*>(Ltg + wtile_off(tpr, J, I - J) + 4 * lane) = xT;
+      *reinterpret_cast<SFT_G v4d*>(Lg + wtile_off(tpr, J, I - J) + 4 * lane) = x;
+      if (I == J + 1) *reinterpret_cast<lds_v4d*>(rowN + 4 * lane) = xT;
+    }
+    if (bwave) {
+      v4d xbT = zero4;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) xbT = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], accTb[kk], xbT, 0, 0, 0);
+      *reinterpret_cast<SFT_G v4d*>(LbTg + (size_t)J * TS * TS + 4 * lane) = xbT;
+      if (ccol < SFT_BORDER) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Lbord[(size_t)ccol * Dnp + TS * J + crow + 4 * q] = xbT[q];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xbT[kk], -xbT[kk], cacc, 0, 0, 0);
+    }
+    __syncthreads();                                     // the column's tiles are in memory (and in rowN) for the next one
+  }
+  // ---- corner: partial sums of the eight waves in a fixed order, then the 6x6 Schur complement of the camera ----
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int r = crow + 4 * q;
+    if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[64 * wave + r * 7 + ccol] = cacc[q];
+  }
+  __syncthreads();
+  if (tid < 49) {
+    double s = 0.0;
+    for (int w = 0; w < 8; w++) s += Cn[64 * w + tid];
+    Cn[512 + tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    lds_double* C = Cn + 512;
+    bool bad = false;
+    for (int k = 0; k < 6; k++) {
+      double dd = C[k * 7 + k];
+      for (int j = 0; j < k; j++) dd -= C[k * 7 + j] * C[k * 7 + j];
+      if (!(dd > 0.0)) bad = true;
+      const double piv = sqrt(dd);
+      C[k * 7 + k] = piv;
+      for (int r = k + 1; r < 7; r++) {
+        double v = C[r * 7 + k];
+        for (int j = 0; j < k; j++) v -= C[r * 7 + j] * C[k * 7 + j];
+        C[r * 7 + k] = v / piv;
+      }
+    }
+    if (bad) ctl->fact_ok = 0;
+    if (ctl->fact_ok)
+      for (int k = 5; k >= 0; k--) {
+        double v = C[6 * 7 + k];
+        for (int r = k + 1; r < 6; r++) v -= C[r * 7 + k] * P.x[Dnp + r];
+        P.x[Dnp + k] = v / C[k * 7 + k];
+      }
+  }
+  __syncthreads();
+}
+
+// Back substitution for the wide band: x_J = W_J^T (y_J - sum_{I > J} X(I,J)^T x_I - L_cJ^T x_cam), block columns from the
+// last to the first; wave w forms the partial products of tiles (J + d, J), d = w + 1 and w + 9; wave 0 finishes the block.
+__device__ __noinline__ void backsub_wide(const SftDev& P, Ctl* ctl, double* ws) {
+  constexpr int NW = 8, RPW = WB / NW, RING = 32;
+  if (!ctl->fact_ok) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Dnp = ((uni(P.Dn) + NB - 1) / NB) * NB;
+  const int nT = Dnp / TS;
+  const int tpr = uni(P.tpr), wb = tpr - 1;
+  lds_double* xw = to_lds(ws);                 // ring of RING x-tiles
+  lds_double* part = xw + TS * RING;           // slot 0: camera rows, slots 1..WB: sub-diagonal tiles
+  const int crow = lane >> 4, ccol = lane & 15;
+  const double xc = (lane < 6) ? P.x[Dnp + lane] : 0.0;
+  double xcr[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) xcr[r] = bcast_lane(xc, r);
+  const auto Lg = uni(P.Lb);
+  const auto Lbord = uni(P.Lbord);
+  const auto Linv_g = uni(P.Linv);
+  const auto xg = uni(P.x);
+  for (int i = tid; i < TS * (WB + 1); i += 64 * NW) part[i] = 0.0;   // slots beyond wb stay zero
+  __syncthreads();
+  struct Pre { v4d t[RPW]; double aux[6]; };
+  auto fetch = [&](int J) -> Pre {
+    Pre p;
+#pragma unroll
+    for (int t = 0; t < RPW; t++) p.t[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 6; r++) p.aux[r] = 0.0;
+    if (J < 0) return p;
+#pragma unroll
+    for (int t = 0; t < RPW; t++) {
+      const int d = wave + 1 + NW * t;
+      if (J + d < nT && d <= wb) p.t[t] = *reinterpret_cast<const SFT_G v4d*>(Lg + wtile_off(tpr, J, d) + 4 * lane);
+    }
+    if (wave == 0) {
+      const v4d li = *reinterpret_cast<const SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
+#pragma unroll
+      for (int q = 0; q < 4; q++) p.aux[q] = li[q];
+      p.aux[4] = Lbord[(size_t)6 * Dnp + TS * J + ccol];
+    } else if (wave == 1) {
+#pragma unroll
+      for (int r = 0; r < 6; r++) p.aux[r] = Lbord[(size_t)r * Dnp + TS * J + ccol];
+    }
+    return p;
+  };
+  constexpr int PF = 4;
+  Pre ring[PF];
+#pragma unroll
+  for (int j = 0; j < PF; j++) ring[j] = fetch(nT - 1 - j);
+#pragma unroll 1
+  for (int base = nT - 1; base >= 0; base -= PF) {
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+      const int J = base - j;
+      if (J < 0) break;
+      const Pre cur = ring[j];
+      ring[j] = fetch(J - PF);
+#pragma unroll
+      for (int t = 0; t < RPW; t++) {
+        const int d = wave + 1 + NW * t;
+        const int I = J + d;
+        double p = 0.0;
+        if (I < nT && d <= wb) {
+          const lds_double* xi = xw + (I & (RING - 1)) * TS + crow;
+#pragma unroll
+          for (int q = 0; q < 4; q++) p = fma(cur.t[t][q], xi[4 * q], p);
+          p += __shfl_xor(p, 16, 64);
+          p += __shfl_xor(p, 32, 64);
+        }
+        if (lane < TS && d <= wb) part[d * TS + lane] = p;
+      }
+      if (wave == 1 && lane < TS) {
+        double p = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) p = fma(cur.aux[r], xcr[r], p);
+        part[lane] = p;
+      }
+      lds_barrier();
+      if (wave == 0) {
+        double v = cur.aux[4];
+#pragma unroll
+        for (int i = 0; i <= WB; i++) v -= part[i * TS + ccol];
+        double p = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        if (lane < TS) { xw[(J & (RING - 1)) * TS + lane] = p; xg[TS * J + lane] = p; }
+      }
+      lds_barrier();
+    }
+  }
+  __syncthreads();
+}

@@ -54,7 +54,7 @@ def test_hip_matches_golden_vectors(gpu_ctx, path):
     np.testing.assert_allclose(f.chi2_obs, g["out_chi2_obs"], rtol=1e-8, atol=1e-12)
 
 
-@pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0)])
+@pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0), ("W12", 1), ("W16", 2)])
 def test_hip_matches_oracle_seeded(gpu_ctx, oracle_mod, cfg, pid):
     from defslam_amd import synth
     tmpl, fr = synth.make_problem(cfg, pid)
@@ -69,7 +69,7 @@ def test_hip_matches_oracle_seeded(gpu_ctx, oracle_mod, cfg, pid):
     assert f.dim == r.dims[0]
 
 
-@pytest.mark.parametrize("shape,m,pid", [((10, 10), 300, 1), ((25, 20), 1000, 2), ((6, 17), 120, 3)])
+@pytest.mark.parametrize("shape,m,pid", [((10, 10), 300, 1), ((25, 20), 1000, 2), ((6, 17), 120, 3), ((8, 30), 400, 4), ((6, 41), 400, 5)])
 def test_normal_equations_match_oracle(gpu_ctx, oracle_mod, shape, m, pid):
     """Residuals + Jacobians + H/b assembly in isolation."""
     from defslam_amd import sft, synth
@@ -253,3 +253,25 @@ def test_full_size_properties(gpu_ctx, cfg):
     assert inl2 == inl
     back = (f2.nodes_xyz - tg) @ Rg
     assert np.abs(back - f.nodes_xyz).max() < 1e-4 * np.abs(f.nodes_xyz).max()
+
+
+@pytest.mark.parametrize("cfg,pid", [("W16", 3), ("W12", 4)])
+def test_wide_tile_solver_agrees_with_the_band_solver(gpu_ctx, monkeypatch, cfg, pid):
+    """Half-bandwidths 128 < kd <= 256 run the left-looking MFMA tile factorisation (sft_wide.h); DSH_SFT_WIDE_OFF=1 selects the
+    row-major band solver for the same problem.  Both are Cholesky factorisations of the same matrix in different summation
+    orders: identical Levenberg-Marquardt trajectories, vertices to 1e-9."""
+    from defslam_amd import sft, synth
+    tmpl, fr = synth.make_problem(cfg, pid)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    fw = sft.frame_from_synth(fr)
+    inl_w = sft.DefPoseOptimization(gpu_ctx, fw, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    _, counts = gpu_ctx.problem_info(0)
+    assert 128 < counts[6] <= 256
+    monkeypatch.setenv("DSH_SFT_WIDE_OFF", "1")
+    fb = sft.frame_from_synth(fr)
+    inl_b = sft.DefPoseOptimization(gpu_ctx, fb, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    assert fw.status == 0 and fb.status == 0
+    assert (fw.iters, fw.trials, inl_w) == (fb.iters, fb.trials, inl_b)
+    np.testing.assert_allclose(fw.trace[:fw.iters, :6], fb.trace[:fb.iters, :6], rtol=1e-7)
+    np.testing.assert_allclose(fw.nodes_xyz, fb.nodes_xyz, rtol=0, atol=1e-9 * np.abs(fb.nodes_xyz).max())
+    np.testing.assert_allclose(fw.pose7, fb.pose7, rtol=0, atol=1e-9)
