@@ -305,8 +305,8 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; DSH_SFT_WIDE_OFF=1 keeps the
   // row-major band solver for A/B runs), row-major band otherwise
   h.tile_mode = (h.kd <= kTS * kBT) ? 1 : ((h.kd <= kTS * kWB && !std::getenv("DSH_SFT_WIDE_OFF")) ? 2 : 0);
-  h.tpr = h.tile_mode == 1 ? kBT + 1 : (h.tile_mode == 2 ? (h.kd + kTS - 1) / kTS + 1 : 0);
-  h.pad0_ = 0;
+  h.wbt = h.tile_mode == 1 ? kBT : (h.tile_mode == 2 ? (h.kd + kTS - 1) / kTS : 0);
+  h.tpr = h.tile_mode ? h.wbt + 1 : 0;
   h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
 #ifdef SFT_EXPERIMENTS
   if (const char* dm = std::getenv("DSH_EXPERIMENT")) h.mode = std::atoi(dm) & ~1;  // tuning builds only: phases switched off, results invalid

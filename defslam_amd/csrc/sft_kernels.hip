@@ -1946,14 +1946,17 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
   if (P.tile_mode) {
-    const int tpr = P.tpr;
-    const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
-    for (size_t i = tid; i < nel; i += NT) {
-      const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % tpr), I = (int)(i / ((size_t)tpr * TS * TS));
-      const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
-      const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn && I < Dnp / TS;
-      P.Hb[i] = pad_diag ? 1.0 : 0.0;
-    }
+    // zero tiles + identity padding; tile mode 1 keeps the compile-time tile-row length (no integer divisions by a runtime value)
+    auto zero_tiles = [&](const int tpr) {
+      const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
+      for (size_t i = tid; i < nel; i += NT) {
+        const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % tpr), I = (int)(i / ((size_t)tpr * TS * TS));
+        const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
+        const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn && I < Dnp / TS;
+        P.Hb[i] = pad_diag ? 1.0 : 0.0;
+      }
+    };
+    if (P.tile_mode == 1) zero_tiles(BT + 1); else zero_tiles(P.tpr);
   } else {
     for (size_t i = tid; i < (size_t)Dnp * ldh; i += NT) {
       const int k = (int)(i % ldh), r = (int)(i / ldh);

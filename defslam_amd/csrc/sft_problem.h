@@ -40,7 +40,9 @@ struct SftDev {
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
   int32_t tile_mode, jl_lds;  // 1: 16x16-tile band storage + register-window MFMA factorisation (kd <= 128); 2: wide tile band, left-looking
                               // MFMA factorisation (kd <= 256, sft_wide.h); 0: row-major band (general)
-  int32_t tpr, pad0_;         // tile modes: tiles per tile row of the band storage (9 in mode 1, ceil(kd/16) + 1 in mode 2)
+  int32_t tpr, wbt;           // tile modes: pitch of a tile row of the band storage in tiles (wbt + 1), sub-diagonal tiles per block
+                              // column (mode 1: 8; mode 2: ceil(kd/16); an even pitch, i.e. an odd tile distance between (I,K) and
+                              // (I,K+1), was tried against L2 channel aliasing: no effect)
   double fx, fy, cx, cy;
   double w_ref, w_curv, w_str, hub_delta, hub_dsqr;
   // template (shared by every problem of a batch)

@@ -26,7 +26,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
   const int Dn = uni(P.Dn);
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
   const int nT = Dnp / TS;
-  const int tpr = uni(P.tpr), wb = tpr - 1;
+  const int tpr = uni(P.tpr), wb = uni(P.wbt);
   lds_double* Lrow = to_lds(ws);                       // 2 x WB tiles, native layout (lane, 4 doubles): row-J tiles, dist 1..wb
   lds_double* LinvK = Lrow + 2 * WB * TS * TS;         // W_J, k-major padded: LinvK[k*TP + j] = W[j][k]
   lds_double* Cn = LinvK + TILE_LDS;                   // 8 partial 7x7 corners, then the corner itself
@@ -217,7 +217,7 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, Ctl* ctl, double* ws)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Dnp = ((uni(P.Dn) + NB - 1) / NB) * NB;
   const int nT = Dnp / TS;
-  const int tpr = uni(P.tpr), wb = tpr - 1;
+  const int tpr = uni(P.tpr), wb = uni(P.wbt);
   lds_double* xw = to_lds(ws);                 // ring of RING x-tiles
   lds_double* part = xw + TS * RING;           // slot 0: camera rows, slots 1..WB: sub-diagonal tiles
   const int crow = lane >> 4, ccol = lane & 15;
