@@ -31,6 +31,27 @@ def test_gpu_entry_points_fail_loudly_without_a_device(host_ctx):
         host_ctx.batch_run()
 
 
+def test_mapping_and_registration_entry_points_fail_loudly_without_a_device(host_ctx):
+    """No CPU fallback anywhere: the one-shot calls refuse a host-only context too (and bad arguments are a status, not a crash)."""
+    from defslam_amd import nrsfm, register, sft, synth
+    sc = synth.make_register_scene(40, seed=1)
+    for call in (lambda: register.scaleMinMedian(host_ctx, sc["surface"], sc["map"], sc["u"]),
+                 lambda: register.OptimizeHorn(host_ctx, sc["surface"], sc["map"], [0, 0, 0, 1, 0, 0, 0, 1.0], 0.01),
+                 lambda: register.registerSurfaces(host_ctx, sc["surface"], sc["map"], sc["u"], sc["Twc"], 0.05),
+                 lambda: nrsfm.bbs_eval(host_ctx, nrsfm.Bbs(0, 1, 5, 0, 1, 5, 1), np.zeros((25, 1)), np.array([0.5]), np.array([0.5]))):
+        with pytest.raises(sft.DshError, match="no GPU|host-only|NO_DEVICE|status"):
+            call()
+    tmpl = synth.make_grid_template(5, 5)
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    with pytest.raises(sft.DshError, match="host-only"):
+        host_ctx.template_embed_device(np.zeros((3, 3), np.float32))
+    # fewer than 15 pairs is the reference's early `return false`, answered without touching a device
+    few = register.registerSurfaces(host_ctx, sc["surface"][:10], sc["map"][:10], sc["u"], sc["Twc"], 0.05)
+    assert not few["registered"]
+    with pytest.raises(sft.DshError):
+        register.scaleMinMedian(host_ctx, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), sc["u"])
+
+
 def test_bad_arguments_return_status_not_abort(host_ctx):
     from defslam_amd import sft, synth
     tmpl, fr = synth.make_problem("smoke")
