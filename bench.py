@@ -107,6 +107,8 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     iters, trials = ctx.batch_counts()              # per step (every step restarts from the uploaded state)
+    # the Jacobian assembly on its own (one linearisation + normal-equation assembly per problem and launch), rank 0's GPU
+    asm_ms = ctx.batch_assemble_timed(5) / 5
     infos = [ctx.problem_info(b) for b in range(args.batch)]
     alg_bytes = sum(i[0] for i in infos)
     _, counts = infos[0]
@@ -123,11 +125,14 @@ def main():
     if rank == 0:
         # HBM traffic per launch measured with rocprofv3 PMC passes for exactly this configuration (profiles/r01/traffic.json)
         traffic = None
+        traffic_asm = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
             key = f"{args.config}_B{args.batch}"
             if key in tj:
                 traffic = tj[key]["bytes_per_launch"]
+            if key + "_assembly" in tj:
+                traffic_asm = tj[key + "_assembly"]["bytes_per_launch"]
         except Exception:
             traffic = None
         ms_per_step = 1e3 * wall / args.steps
@@ -164,6 +169,11 @@ def main():
                          "hbm_assembly": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                                           "algorithmic_bytes_per_launch": bytes_per_launch,
                                           "measured_traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None},
+                         # the same assembly bytes over launches that do nothing but one linearisation + assembly per problem
+                         "hbm_assembly_isolated": {"achieved": alg_bytes / (asm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": alg_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": asm_ms,
+                                                   "algorithmic_bytes_per_pass": alg_bytes, "traffic": traffic_asm,
+                                                   "measured_traffic_GBps": (traffic_asm / (asm_ms * 1e-3) / 1e9) if traffic_asm else None},
                          # what THIS algorithm has to stream per launch: assembly bytes + per damping trial the H tiles read once,
                          # L written once by the factorisation and read once by the back substitution
                          "hbm_solver_stream": {"achieved": (bytes_per_launch + stream_bytes) / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

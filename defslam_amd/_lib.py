@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "dsh_create", "dsh_destroy", "dsh_last_error", "dsh_stream", "dsh_synchronize",
     "dsh_template_build", "dsh_template_set", "dsh_template_dims", "dsh_template_get", "dsh_template_embed",
     "dsh_sft_solve", "dsh_sft_batch_upload", "dsh_sft_batch_run", "dsh_sft_batch_download",
-    "dsh_sft_batch_run_timed", "dsh_sft_batch_phase_ms", "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
+    "dsh_sft_batch_run_timed", "dsh_sft_batch_assemble_timed", "dsh_sft_batch_phase_ms", "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
     "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit",
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
     "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
     L.dsh_sft_batch_upload.argtypes = [vp, C.c_int, C.POINTER(SftFrameC)]
     L.dsh_sft_batch_run.argtypes = [vp]
     L.dsh_sft_batch_run_timed.argtypes = [vp, C.c_int, c_double_p]
+    L.dsh_sft_batch_assemble_timed.argtypes = [vp, C.c_int, c_double_p]
     L.dsh_sft_batch_phase_ms.argtypes = [vp, C.c_int, c_double_p]
     L.dsh_sft_batch_download.argtypes = [vp, C.c_int, C.POINTER(SftResultC)]
     L.dsh_sft_batch_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

@@ -649,6 +649,32 @@ int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
   return DSH_OK;
 }
 
+int dsh_sft_batch_assemble_timed(dsh_ctx* c, int launches, double* total_ms) {
+  if (!c || launches <= 0 || !total_ms) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_assemble_timed: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_assemble_timed: host-only context, no GPU (there is no CPU fallback)");
+  if (c->B <= 0 || !c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_assemble_timed: needs an uploaded batch that has run once");
+  (void)hipSetDevice(c->device);
+  // every problem in "one linearisation + assembly, keep the zero pattern of H" mode for the timed launches, then back
+  std::vector<SftDev> tmp = c->h_probs;
+  for (SftDev& h : tmp) h.mode |= 1 | 4;
+  HIPCHK(c, hipMemcpyAsync(c->d_probs, tmp.data(), sizeof(SftDev) * c->B, hipMemcpyHostToDevice, c->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, (c->dense ? sft_lm_launch_dense : sft_lm_launch)(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_probs, c->h_probs.data(), sizeof(SftDev) * c->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *total_ms = ms;
+  c->ran = false;   // results of the last full run are gone (state reset, H reassembled at the initial state)
+  return DSH_OK;
+}
+
 int dsh_sft_batch_phase_ms(dsh_ctx* c, int b, double* out8) {
   if (!c || !out8 || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_phase_ms: bad argument");
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_phase_ms: host-only context");

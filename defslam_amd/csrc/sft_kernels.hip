@@ -1945,7 +1945,9 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   // ---- initial state, zeroed system with identity padding --------------------------------
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
-  if (P.tile_mode) {
+  const bool keep_system = (P.mode & 4) != 0;   // measurement passes of the assembly alone: H / border keep their zero pattern from the last full run
+  if (keep_system) {
+  } else if (P.tile_mode) {
     // zero tiles + identity padding; tile mode 1 keeps the compile-time tile-row length (no integer divisions by a runtime value)
     auto zero_tiles = [&](const int tpr) {
       const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
@@ -1963,7 +1965,8 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
       P.Hb[i] = (k == kd && r >= Dn) ? 1.0 : 0.0;
     }
   }
-  for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
+  if (!keep_system)
+    for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
   for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
   if (tid == 0) {
     ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
@@ -1973,7 +1976,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   __syncthreads();
   PH_T0();
 
-  if (P.mode == 1) {  // test hook: one assembly at the initial state
+  if (P.mode & 1) {  // test hook / assembly-only measurement pass: one linearisation + assembly at the initial state
     const double chi = eval_edges<true>(P, ctl, red, out, jp);
     assemble(P, red, out, jp);
     if (tid == 0) P.dbg[0] = chi;

@@ -184,6 +184,12 @@ class Context:
         self._check(self._L.dsh_sft_batch_run_timed(self._h, int(launches), C.byref(ms)), "dsh_sft_batch_run_timed")
         return ms.value
 
+    def batch_assemble_timed(self, launches: int = 1) -> float:
+        """`launches` launches of one linearisation + normal-equation assembly per problem (measurement aid); milliseconds."""
+        ms = C.c_double()
+        self._check(self._L.dsh_sft_batch_assemble_timed(self._h, int(launches), C.byref(ms)), "dsh_sft_batch_assemble_timed")
+        return ms.value
+
     def phase_ms(self, b: int = 0):
         out = np.zeros(8)
         self._check(self._L.dsh_sft_batch_phase_ms(self._h, b, _ptr(out, C.c_double)), "dsh_sft_batch_phase_ms")

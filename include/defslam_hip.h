@@ -113,6 +113,11 @@ int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
 /* `launches` back-to-back runs bracketed by HIP events recorded on dsh_stream; returns the elapsed
  * milliseconds between the two events (device time of the launches, no host round trips inside). */
 int dsh_sft_batch_run_timed(dsh_ctx* ctx, int launches, double* total_ms);
+/* Measurement aid for the Jacobian-assembly roofline: `launches` back-to-back launches in which every problem of
+ * the batch does ONE linearisation (residuals + Jacobian records, DefOptimizer.cc:293-507 / g2o linearizeSystem) and one
+ * normal-equation assembly at its uploaded initial state and stops; elapsed device milliseconds between two HIP events.
+ * Needs a batch that has run once (H keeps the zero pattern of that run); invalidates that run's results. */
+int dsh_sft_batch_assemble_timed(dsh_ctx* ctx, int launches, double* total_ms);
 /* Per-phase device time of problem b in the last run, milliseconds (constant 100 MHz counter read by one lane):
  * out8[1] residuals, [2] normal-equation assembly, [3] H->L copy, [4] panel factorisation, [5] trailing update,
  * [6] back substitution, [7] state update + LM control.  out8[0] is reserved. */

@@ -275,3 +275,28 @@ def test_wide_tile_solver_agrees_with_the_band_solver(gpu_ctx, monkeypatch, cfg,
     np.testing.assert_allclose(fw.trace[:fw.iters, :6], fb.trace[:fb.iters, :6], rtol=1e-7)
     np.testing.assert_allclose(fw.nodes_xyz, fb.nodes_xyz, rtol=0, atol=1e-9 * np.abs(fb.nodes_xyz).max())
     np.testing.assert_allclose(fw.pose7, fb.pose7, rtol=0, atol=1e-9)
+
+
+def test_assembly_only_launches_leave_the_batch_intact(gpu_ctx):
+    """dsh_sft_batch_assemble_timed (measurement aid of the assembly roofline) flips every problem into "one linearisation +
+    assembly" mode for its launches and back: a full run afterwards gives the same results bit for bit."""
+    from defslam_amd import sft, synth
+    tmpl, _ = synth.make_problem("smoke", 0)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    frames = [sft.frame_from_synth(synth.make_frame(tmpl, 300, p)) for p in range(6)]
+    gpu_ctx.batch_upload(frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    with pytest.raises(sft.DshError):
+        gpu_ctx.batch_assemble_timed(1)          # nothing has run yet: H has no zero pattern to keep
+    gpu_ctx.batch_run()
+    gpu_ctx.batch_download()
+    ref = [(f.nodes_xyz.copy(), f.pose7.copy(), f.iters, f.trials) for f in frames]
+    ms = gpu_ctx.batch_assemble_timed(3)
+    assert ms > 0
+    with pytest.raises(sft.DshError):
+        gpu_ctx.batch_download()                 # the assembly passes invalidated the run
+    gpu_ctx.batch_run()
+    gpu_ctx.batch_download()
+    for f, (x, q, it, tr) in zip(frames, ref):
+        assert (f.iters, f.trials) == (it, tr)
+        np.testing.assert_array_equal(f.nodes_xyz, x)
+        np.testing.assert_array_equal(f.pose7, q)
