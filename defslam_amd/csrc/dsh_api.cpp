@@ -16,6 +16,7 @@
 #include "sft_problem.h"
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
+extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 // dense build of the same kernels (sft_kernels_dense.hip): 128 VGPRs per wave, two 8-wavefront problems per CU
 extern "C" hipError_t sft_lm_launch_dense(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
@@ -82,6 +83,7 @@ struct Packed {
   SftDev h{};                   // sizes + scalars (pointers filled at upload)
   std::vector<int32_t> act, obs_nodes, ref_node, star_node, str_nodes, blk_rc, blk_ptr, diag_blk, off_blk;
   std::vector<uint32_t> contrib;
+  std::vector<int32_t> tmask;        // tile mode 1: per tile row, bit d = tile (I, I-d) structurally non-zero
   std::vector<int32_t> blk_hdr;      // 4 per block in processing order (diagonal blocks of nodes 0..nA-1, then the off-diagonal blocks): start, count, block row, block col
   std::vector<double> cfac;          // 2 per contribution: constant factors of curvature / stretch contributions (H factor, b factor)
   std::vector<double> obs_bary, obs_uv, obs_w, star_sL, str_L0, xyz_init;
@@ -300,6 +302,21 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
 
   P.xyz_init.assign(f.xyz, f.xyz + 3 * (size_t)n);
   pose7_from_Tcw(f.Tcw, P.pose_init);
+  {  // which 16x16 tiles of the band hold an element of some 3x3 block (30 % of the C2 band is structurally zero)
+    const int Dn_ = 3 * nA, nT_ = ((Dn_ + kNB - 1) / kNB) * kNB / kTS;
+    P.tmask.assign((size_t)nT_ + SFT_H_PAD_TILE_ROWS, 0);
+    for (int I = 0; I < nT_; I++) P.tmask[I] = 1;   // diagonal tiles (incl. the identity padding of the last one)
+    for (int q = 0; q < nblk; q++) {
+      const int bi = P.blk_rc[2 * q], bj = P.blk_rc[2 * q + 1];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          const int r = 3 * bi + a, cc = 3 * bj + b;
+          if (cc > r) continue;
+          const int d = (r >> 4) - (cc >> 4);
+          if (d < 31) P.tmask[r >> 4] |= 1 << d;
+        }
+    }
+  }
   SftDev& h = P.h;
   h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
   // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; DSH_SFT_WIDE_OFF=1 keeps the
@@ -507,7 +524,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   st.clear();
   const size_t o_tab = a.take(sizeof(SftDev) * B);
   st.resize(a.size);
-  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, hdr, cfac, xyz_init, pose_init; };
+  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, hdr, tmask, cfac, xyz_init, pose_init; };
   std::vector<Offs> ro(B);
   for (int b = 0; b < B; b++) {
     Packed& P = c->packed[b];
@@ -516,7 +533,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     o.obs_w = put(st, a, P.obs_w); o.ref = put(st, a, P.ref_node); o.star = put(st, a, P.star_node); o.sL = put(st, a, P.star_sL);
     o.strn = put(st, a, P.str_nodes); o.strL = put(st, a, P.str_L0); o.rc = put(st, a, P.blk_rc); o.ptr = put(st, a, P.blk_ptr);
     o.dblk = put(st, a, P.diag_blk); o.oblk = put(st, a, P.off_blk);
-    o.contrib = put(st, a, P.contrib); o.hdr = put(st, a, P.blk_hdr); o.cfac = put(st, a, P.cfac); o.xyz_init = put(st, a, P.xyz_init);
+    o.contrib = put(st, a, P.contrib); o.hdr = put(st, a, P.blk_hdr); o.tmask = put(st, a, P.tmask); o.cfac = put(st, a, P.cfac); o.xyz_init = put(st, a, P.xyz_init);
     std::vector<double> pi(P.pose_init, P.pose_init + 7);
     o.pose_init = put(st, a, pi);
   }
@@ -594,7 +611,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.star_node = (const int32_t*)(base + o.star); h.star_sL = (const double*)(base + o.sL); h.str_nodes = (const int32_t*)(base + o.strn);
     h.str_L0 = (const double*)(base + o.strL); h.blk_rc = (const int32_t*)(base + o.rc); h.blk_ptr = (const int32_t*)(base + o.ptr);
     h.diag_blk = (const int32_t*)(base + o.dblk); h.off_blk = (const int32_t*)(base + o.oblk);
-    h.contrib = (const uint32_t*)(base + o.contrib); h.blk_hdr = (const int32_t*)(base + o.hdr); h.cfac = (const double*)(base + o.cfac); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
+    h.contrib = (const uint32_t*)(base + o.contrib); h.blk_hdr = (const int32_t*)(base + o.hdr); h.tmask = (const int32_t*)(base + o.tmask); h.cfac = (const double*)(base + o.cfac); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
     h.xyz = (double*)(base + w.xyz); h.xyz_bak = (double*)(base + w.bak); h.pose = (double*)(base + w.pose);
     h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
     h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
@@ -654,18 +671,13 @@ int dsh_sft_batch_assemble_timed(dsh_ctx* c, int launches, double* total_ms) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_assemble_timed: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0 || !c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_assemble_timed: needs an uploaded batch that has run once");
   (void)hipSetDevice(c->device);
-  // every problem in "one linearisation + assembly, keep the zero pattern of H" mode for the timed launches, then back
-  std::vector<SftDev> tmp = c->h_probs;
-  for (SftDev& h : tmp) h.mode |= 1 | 4;
-  HIPCHK(c, hipMemcpyAsync(c->d_probs, tmp.data(), sizeof(SftDev) * c->B, hipMemcpyHostToDevice, c->stream));
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, (c->dense ? sft_lm_launch_dense : sft_lm_launch)(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
   HIPCHK(c, hipEventRecord(e1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_probs, c->h_probs.data(), sizeof(SftDev) * c->B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);

@@ -842,7 +842,14 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
 
   // Raw tile (I, I-d) of H in accumulator layout.  The storage is zero-padded (SFT_H_PAD_*), so every tile the sliding
   // window can ask for exists: loads are unconditional and nothing touches the loaded registers before the MFMAs do.
-  auto fresh_tile = [&](int I, int d) -> v4d { return *reinterpret_cast<const v4d*>(Hg + tile_off(I, d) + 4 * lane); };
+  // Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) are read from the first padding tile row --
+  // one shared 2 KB zero tile that stays in cache -- instead of from their own place in HBM; the load itself stays
+  // unconditional (exact wait counts).  mrow: the mask word of tile row I (P.tmask).
+  const auto tmask = uni(P.tmask);
+  const size_t zero_tile = tile_off(nT, 0);
+  auto fresh_tile = [&](int I, int d, int mrow) -> v4d {
+    return *reinterpret_cast<const v4d*>(Hg + (((mrow >> d) & 1) ? tile_off(I, d) : zero_tile) + 4 * lane);
+  };
   // border block of tile column J: rows crow, crow+4 of the 8-row border (row 7 is zero), accumulator layout
   auto fresh_border = [&](int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
@@ -853,8 +860,9 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
 #pragma unroll
   for (int t = 0; t < RPW; t++) {       // rows 0..BT-1
     const int I = wave + NW * t;
+    const int m0 = uni(tmask[I]);
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1));
+    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1), m0);
     bacc[t] = fresh_border((I + BOFF) & (BT - 1));
   }
   v4d cacc = {0.0, 0.0, 0.0, 0.0};      // wave 0: corner
@@ -889,11 +897,12 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
         memwave = true;
         if (k >= 0) {
           const int I = k + BT;
+          const int mI = uni(tmask[I]);
 #pragma unroll
-          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1));
+          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1), mI);
         }
       }
-    if (memwave) fr8 = fresh_tile(kc + BT, BT);
+    if (memwave) fr8 = fresh_tile(kc + BT, BT, uni(tmask[kc + BT]));
     if (k >= 0) {
 #pragma unroll
       for (int t = 0; t < RPW; t++)   // the holder of ring column k mod BT (consumed by now) fetches the border block of column k+BT
@@ -1206,15 +1215,23 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #define WT_BEGIN() do {} while (0)
 #define WT_END(e) do {} while (0)
 #endif
-  auto fresh_tile = [&](int I, int d) -> v4d { return *reinterpret_cast<const v4d*>(Hg + tile_off(I, d) + 4 * lane); };
+  // Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) are read from the first padding tile row --
+  // one shared 2 KB zero tile that stays in cache -- instead of from their own place in HBM; the load itself stays
+  // unconditional (exact wait counts).  mrow: the mask word of tile row I (P.tmask).
+  const auto tmask = uni(P.tmask);
+  const size_t zero_tile = tile_off(nT, 0);
+  auto fresh_tile = [&](int I, int d, int mrow) -> v4d {
+    return *reinterpret_cast<const v4d*>(Hg + (((mrow >> d) & 1) ? tile_off(I, d) : zero_tile) + 4 * lane);
+  };
   auto fresh_border = [&](int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
     v[0] = Hbord[(size_t)crow * Dnp + TS * J + ccol];
     v[1] = Hbord[(size_t)(crow + 4) * Dnp + TS * J + ccol];
     return v;
   };
+  const int m0 = uni(tmask[wave]);
 #pragma unroll
-  for (int b = 0; b < BT; b++) acc[b] = fresh_tile(wave, (wave - b) & (BT - 1));
+  for (int b = 0; b < BT; b++) acc[b] = fresh_tile(wave, (wave - b) & (BT - 1), m0);
   bacc = fresh_border((wave + BOFF) & (BT - 1));
   v4d cacc = {0.0, 0.0, 0.0, 0.0};
   if (wave == 0) {
@@ -1245,9 +1262,10 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
     v4d araw = {0.0, 0.0, 0.0, 0.0};
     if (k >= 0) {
       if (memwave) {                                 // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
+        const int mk = uni(tmask[k + BT]);
 #pragma unroll
-        for (int b = 0; b < BT; b++) acc[b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1));
-        araw = fresh_tile(k + BT, BT);
+        for (int b = 0; b < BT; b++) acc[b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1), mk);
+        araw = fresh_tile(k + BT, BT, mk);
       }
       if (((wave + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc = fresh_border(k + BT);
       // nobody may still be reading the buffers of step k-2 (same parity)
@@ -1530,7 +1548,14 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
 #define WT_BEGIN() do {} while (0)
 #define WT_END(e) do {} while (0)
 #endif
-  auto fresh_tile = [&](int I, int d) -> v4d { return *reinterpret_cast<const v4d*>(Hg + tile_off(I, d) + 4 * lane); };
+  // Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) are read from the first padding tile row --
+  // one shared 2 KB zero tile that stays in cache -- instead of from their own place in HBM; the load itself stays
+  // unconditional (exact wait counts).  mrow: the mask word of tile row I (P.tmask).
+  const auto tmask = uni(P.tmask);
+  const size_t zero_tile = tile_off(nT, 0);
+  auto fresh_tile = [&](int I, int d, int mrow) -> v4d {
+    return *reinterpret_cast<const v4d*>(Hg + (((mrow >> d) & 1) ? tile_off(I, d) : zero_tile) + 4 * lane);
+  };
   auto fresh_border = [&](int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
     v[0] = Hbord[(size_t)crow * Dnp + TS * J + ccol];
@@ -1541,7 +1566,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   for (int t = 0; t < RPW; t++) {
     const int a = wave + NW * t;
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(a, (a - b) & (BT - 1));
+    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(a, (a - b) & (BT - 1), uni(tmask[a]));
     bacc[t] = fresh_border((a + BOFF) & (BT - 1));
   }
   v4d cacc = {0.0, 0.0, 0.0, 0.0};
@@ -1573,10 +1598,11 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
 #pragma unroll
       for (int t = 0; t < RPW; t++) {
         if (wave + NW * t == (k & (BT - 1))) {        // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
+          const int mk = uni(tmask[k + BT]);
           memwave = true;
 #pragma unroll
-          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1));
-          araw = fresh_tile(k + BT, BT);
+          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1), mk);
+          araw = fresh_tile(k + BT, BT, mk);
         }
         if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
       }
@@ -1945,9 +1971,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   // ---- initial state, zeroed system with identity padding --------------------------------
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
-  const bool keep_system = (P.mode & 4) != 0;   // measurement passes of the assembly alone: H / border keep their zero pattern from the last full run
-  if (keep_system) {
-  } else if (P.tile_mode) {
+  if (P.tile_mode) {
     // zero tiles + identity padding; tile mode 1 keeps the compile-time tile-row length (no integer divisions by a runtime value)
     auto zero_tiles = [&](const int tpr) {
       const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
@@ -1965,8 +1989,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
       P.Hb[i] = (k == kd && r >= Dn) ? 1.0 : 0.0;
     }
   }
-  if (!keep_system)
-    for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
+  for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
   for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
   if (tid == 0) {
     ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
@@ -1976,7 +1999,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   __syncthreads();
   PH_T0();
 
-  if (P.mode & 1) {  // test hook / assembly-only measurement pass: one linearisation + assembly at the initial state
+  if (P.mode == 1) {  // test hook: one assembly at the initial state
     const double chi = eval_edges<true>(P, ctl, red, out, jp);
     assemble(P, red, out, jp);
     if (tid == 0) P.dbg[0] = chi;
@@ -2109,6 +2132,29 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   if (tid == 0) { P.info[0] = iters; P.info[1] = total_trials; }
 }
 
+// Measurement kernel of the Jacobian-assembly roofline: one linearisation (residuals + Jacobian records) and one
+// normal-equation assembly per problem at its uploaded initial state, nothing else.  H and the border keep the zero pattern
+// of the last full run of the batch (the assembly overwrites every structural non-zero).  Same launch shape and LDS layout
+// as sft_lm_kernel; its own name keeps the profiler statistics of the two apart.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_assembly_kernel(const SftDev* __restrict__ probs) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);
+  double* out = red + 16 * 27 + 5;
+  double* panel = out + 32;
+  const JPtr jp = jrecords(P, panel);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
+  if (tid < 7) P.pose[tid] = P.pose_init[tid];
+  __syncthreads();
+  const double chi = eval_edges<true>(P, ctl, red, out, jp);
+  assemble(P, red, out, jp);
+  if (tid == 0) P.dbg[0] = chi;
+}
+
 }  // namespace
 
 // LDS bytes the kernel needs for a problem with half-bandwidth kd
@@ -2124,6 +2170,18 @@ extern "C" size_t SFT_LDS_BYTES_NAME(int kd, size_t jl_doubles) {
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
+
+#ifndef SFT_NO_ASSEMBLY_KERNEL
+extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
+  const size_t lds = SFT_LDS_BYTES_NAME(max_kd, jl_doubles);
+  const void* fn = nw == 4 ? reinterpret_cast<const void*>(sft_assembly_kernel<4>) : reinterpret_cast<const void*>(sft_assembly_kernel<8>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  if (nw == 4) hipLaunchKernelGGL(sft_assembly_kernel<4>, dim3(B), dim3(256), lds, stream, d_probs);
+  else hipLaunchKernelGGL(sft_assembly_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs);
+  return hipGetLastError();
+}
+#endif
 
 extern "C" hipError_t SFT_LAUNCH_NAME(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
   const size_t lds = SFT_LDS_BYTES_NAME(max_kd, jl_doubles);

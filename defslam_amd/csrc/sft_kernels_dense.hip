@@ -4,4 +4,5 @@
 #define SFT_WAVES_PER_EU 4
 #define SFT_LAUNCH_NAME sft_lm_launch_dense
 #define SFT_LDS_BYTES_NAME sft_lm_kernel_lds_bytes_dense
+#define SFT_NO_ASSEMBLY_KERNEL   // one copy of the measurement kernel is enough
 #include "sft_kernels.hip"

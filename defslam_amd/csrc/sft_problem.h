@@ -71,6 +71,8 @@ struct SftDev {
   const SFT_G uint32_t* contrib;
   const SFT_G int32_t* blk_hdr;   // 4 per block in processing order (nA diagonal blocks, then the off-diagonal ones): start, count, block row, block col
   const SFT_G double* cfac;       // 2 per contribution: state-independent factors (H, b) of curvature / stretch contributions
+  const SFT_G int32_t* tmask;     // tile mode 1: per tile row I (nT + SFT_H_PAD_TILE_ROWS entries) bit d set if tile (I, I-d) holds any element of H;
+                                  // the factorisation reads the other (structurally zero) tiles from one shared zero tile instead of HBM
   // initial state (restored at the start of every run)
   const SFT_G double* xyz_init;   // n*3
   const SFT_G double* pose_init;  // 7: t, q(x,y,z,w)

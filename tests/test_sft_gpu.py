@@ -278,8 +278,8 @@ def test_wide_tile_solver_agrees_with_the_band_solver(gpu_ctx, monkeypatch, cfg,
 
 
 def test_assembly_only_launches_leave_the_batch_intact(gpu_ctx):
-    """dsh_sft_batch_assemble_timed (measurement aid of the assembly roofline) flips every problem into "one linearisation +
-    assembly" mode for its launches and back: a full run afterwards gives the same results bit for bit."""
+    """dsh_sft_batch_assemble_timed (measurement aid of the assembly roofline) runs a kernel of its own that does one linearisation +
+    assembly per problem on the batch's buffers: a full run afterwards gives the same results bit for bit."""
     from defslam_amd import sft, synth
     tmpl, _ = synth.make_problem("smoke", 0)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
