@@ -21,6 +21,26 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
 
 
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """The boundary is a C ABI: include/defslam_hip.h compiles as C99 and as C++11, and a C program linked against the
+    shared library creates and destroys a host-only context (what a cgo / JNI / N-API stub would do first)."""
+    import subprocess
+    from defslam_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "client.c"
+    src.write_text('#include "include/defslam_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { dsh_ctx* c = 0; if (dsh_create(&c, -1) != DSH_OK) return 1;\n'
+                   '  if (dsh_synchronize(c) == DSH_OK) return 2;   /* host-only context: GPU entry points refuse */\n'
+                   '  printf("%s\\n", dsh_last_error(c)); return dsh_destroy(c); }\n')
+    lib = _lib.LIB_PATH
+    exe = tmp_path / "client"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", root, str(src), "-o", str(exe), lib,
+                    f"-Wl,-rpath,{os.path.dirname(lib)}"], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", root, str(src)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_gpu_entry_points_fail_loudly_without_a_device(host_ctx):
     from defslam_amd import sft, synth
     tmpl, fr = synth.make_problem("smoke")
