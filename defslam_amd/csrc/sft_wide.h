@@ -51,33 +51,72 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
   if (tid == 0) ctl->fact_ok = 1;
   __syncthreads();
 
-  // sum_K L(J,K) L(I,K)^T for one row: A operand = row-J tile (LDS), B operand = the stored tile of row I (memory; LDS for
-  // the diagonal row).  The operands of U products are fetched before their MFMAs issue.
-  constexpr int U = 8;
-  using lds_v4d = __attribute__((address_space(3))) v4d;
+  // sum_K L(J,K) L(I,K)^T for one row: A operand = row-J tile (LDS), B operand = the stored tile of row I (memory).
+  // The FP64 MFMA pipe bounds the products (two waves per SIMD: 573 cycles per product), so the tile loads must not add
+  // their latency to it: NCH chunks of U products, fully unrolled (straight-line code keeps exact wait counts), the loads of
+  // chunk c+1 issued before the MFMAs of chunk c.  Every chunk issues U loads (the last tile again beyond the row's end).
+  constexpr int U = 4;
   const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-  auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
+  // Staged tiles live in LDS as two 1 KB planes (registers 0,1 of every lane, then registers 2,3): every ds_read_b128 /
+  // ds_write_b128 touches 64 consecutive 16-byte words.
+  typedef double v2d_ __attribute__((ext_vector_type(2)));
+  using lds_v2d = __attribute__((address_space(3))) v2d_;
+  auto lds_tile_read = [&](const lds_double* tile) -> v4d {
+    const v2d_ lo = *reinterpret_cast<const lds_v2d*>(tile + 2 * lane);
+    const v2d_ hi = *reinterpret_cast<const lds_v2d*>(tile + 128 + 2 * lane);
+    return (v4d){lo.x, lo.y, hi.x, hi.y};
+  };
+  auto lds_tile_write = [&](lds_double* tile, const v4d& v) {
+    *reinterpret_cast<lds_v2d*>(tile + 2 * lane) = (v2d_){v[0], v[1]};
+    *reinterpret_cast<lds_v2d*>(tile + 128 + 2 * lane) = (v2d_){v[2], v[3]};
+  };
+  auto mfma4 = [&](const v4d& a, const v4d& b, v4d& s0, v4d& s1) {
+    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], s1, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s1, 0, 0, 0);
+  };
+  auto products_n = [&](auto nch_c, int J, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
     // brow: tile of block column K0 for this row; the tile of block column K0 + i sits i * bstride doubles further
+    constexpr int NCH = decltype(nch_c)::value;
     v4d s0 = zero4, s1 = zero4;
-#pragma unroll 1
-    for (int K = K0; K < J; K += U) {
-      v4d b[U];
-      if (I != J) {
+    v4d buf[2][U];
+    const int last = max(J - 1 - K0, 0);
 #pragma unroll
-        for (int u = 0; u < U; u++) b[u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)(min(K + u, J - 1) - K0) * bstride + 4 * lane);
+    for (int u = 0; u < U; u++) buf[0][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(u, last) * bstride + 4 * lane);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      if (c + 1 < NCH) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          buf[(c + 1) & 1][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
       }
 #pragma unroll
-      for (int u = 0; u < U; u++)
-        if (K + u < J) {
-          const v4d a = *reinterpret_cast<const lds_v4d*>(rowJ + (size_t)(J - K - u - 1) * TS * TS + 4 * lane);
-          const v4d bb = (I == J) ? a : b[u];
-          s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], bb[0], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], bb[1], s1, 0, 0, 0);
-          s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], bb[2], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], bb[3], s1, 0, 0, 0);
-        }
+      for (int u = 0; u < U; u++) {
+        const int K = K0 + U * c + u;
+        if (K < J) mfma4(lds_tile_read(rowJ + (size_t)(J - K - 1) * TS * TS), buf[c & 1][u], s0, s1);
+      }
     }
     return s0 + s1;
+  };
+  auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
+    if (I == J) {   // diagonal row: both operands are the staged tiles of row J
+      v4d s0 = zero4, s1 = zero4;
+#pragma unroll 1
+      for (int K = K0; K < J; K += U) {
+        v4d a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = lds_tile_read(rowJ + (size_t)max(J - K - u - 1, 0) * TS * TS);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (K + u < J) mfma4(a[u], a[u], s0, s1);
+      }
+      return s0 + s1;
+    }
+    const int n = J - K0;
+    if (n <= 0) return zero4;
+    if (n <= 2 * U) return products_n(std::integral_constant<int, 2>{}, J, rowJ, brow, bstride, K0);
+    return products_n(std::integral_constant<int, 4>{}, J, rowJ, brow, bstride, K0);
   };
   const long kstride = (long)(tpr - 1) * TS * TS;        // tile (I, K+1) sits (tpr - 1) tiles after tile (I, K)
 
@@ -85,7 +124,16 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
   for (int J = 0; J < nT; J++) {
     lds_double* rowJ = Lrow + (size_t)(J & 1) * WB * TS * TS;
     lds_double* rowN = Lrow + (size_t)((J + 1) & 1) * WB * TS * TS;
-    const int d = (wave - J) & 7;                       // this wave's rows: J + d, J + d + 8 (and J + 16 on the diagonal owner)
+    // Roles rotate with the column (nothing but the corner sum lives in registers across columns).  The FP64 MFMA pipe is
+    // what the products are bound by (73 cycles per MFMA, two waves per SIMD: tools/probes/lds_mfma_probe.hip), so the rows
+    // are dealt by their number of products: role 0 owns the diagonal tile (16 products, then the Cholesky: the critical
+    // path) and the product-free tile (J+16, J); the other roles take 19 products each (role 7: 22):
+    //   1: border (16), J+14, J+15 | 2: J+1, J+12 | 3: J+2, J+11 | 4: J+3, J+10 | 5: J+4, J+9 | 6: J+5, J+8 | 7: J+6, J+7, J+13
+    const int d = (wave - J) & 7;
+    int Irow[3];
+    Irow[0] = J + (d == 0 ? 0 : d == 1 ? 14 : d - 1);
+    Irow[1] = J + (d == 0 ? 16 : d == 1 ? 15 : 14 - d);
+    Irow[2] = d == 7 ? J + 13 : nT;
     // stage tile row J+1 for the next column: dist 2 + wave and 10 + wave (dist 1 is produced by this column's TRSM)
     v4d stage[2];
     bool staged[2];
@@ -99,8 +147,8 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     bool have[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      const int I = J + d + 8 * t;
-      have[t] = I < nT && I - J <= wb && (t < 2 || d == 0);
+      const int I = Irow[t];
+      have[t] = I < nT && I - J <= wb;
       if (have[t]) {
         const v4d h = *reinterpret_cast<const SFT_G v4d*>(Hg + wtile_off(tpr, I, I - J) + 4 * lane);
         const int K0 = max(0, I - wb);
@@ -124,7 +172,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     }
     // border: accTb[j][i] = Hbord[i][16 J + j] - sum_K (L(J,K) Lb(K)^T)[j][i], i < 7
     v4d accTb = zero4;
-    const bool bwave = d == 7;
+    const bool bwave = d == 1;
     if (bwave) {
       v4d h = zero4;
       if (ccol < SFT_BORDER) {
@@ -136,7 +184,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     }
 #pragma unroll
     for (int h = 0; h < 2; h++)
-      if (staged[h]) *reinterpret_cast<lds_v4d*>(rowN + (size_t)(1 + wave + 8 * h) * TS * TS + 4 * lane) = stage[h];
+      if (staged[h]) lds_tile_write(rowN + (size_t)(1 + wave + 8 * h) * TS * TS, stage[h]);
     lds_barrier();                                       // W_J is published
     // ---- TRSM: X^T = W accT (kept for the factor), X = acc W^T (kept for the back substitution) ----
     double wv[4];
@@ -144,7 +192,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     for (int kk = 0; kk < 4; kk++) wv[kk] = LinvK[(4 * kk + crow) * TP + ccol];     // lane (x = ccol, k = crow): W[x][4kk + k]
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-      const int I = J + d + 8 * t;
+      const int I = Irow[t];
       if (!have[t] || I == J) continue;
       v4d xT = zero4, x = zero4;
 #pragma unroll
@@ -154,7 +202,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
       }
       *reinterpret_cast<SFT_G v4d*>(Ltg + wtile_off(tpr, J, I - J) + 4 * lane) = xT;
       *reinterpret_cast<SFT_G v4d*>(Lg + wtile_off(tpr, J, I - J) + 4 * lane) = x;
-      if (I == J + 1) *reinterpret_cast<lds_v4d*>(rowN + 4 * lane) = xT;
+      if (I == J + 1) lds_tile_write(rowN, xT);
     }
     if (bwave) {
       v4d xbT = zero4;
