@@ -12,9 +12,8 @@
 // (I,J).  The tiles of tile row J (the A operands shared by all rows of the column) are staged in LDS one column ahead;
 // the tile produced last, X(J+1,J)^T, goes there straight from the registers.  The back substitution contracts over the
 // other index, so the TRSM also emits X(I,J) itself (4 more MFMAs per tile) into Lb, block-column layout like tile mode.
-// Work per column: (16 + 15 + ... + 1) + 16 border products of 4 MFMAs each + 18 TRSMs of 8 = 750 MFMAs on 4 SIMDs (12 k
-// cycles); measured 29 k cycles per column on the 2000-node template: the serial chain diagonal products -> Cholesky -> TRSM ->
-// store drain of a column is not overlapped with the next one yet.
+// Work per column: (16 + 15 + ... + 1) + 16 border products of 4 MFMAs each + 18 TRSMs of 8 + 13 = 765 MFMAs on 4 SIMDs (14 k
+// cycles at 73 cycles per FP64 MFMA); measured 26 k cycles per column on the 2000-node template.
 #pragma once
 
 #define WB 16   // most sub-diagonal tiles per block column in wide mode (half-bandwidth <= 256)
