@@ -545,6 +545,11 @@ __global__ __launch_bounds__(256) void swp_normal_kernel(int m, int n2, int nt, 
 #define SWS_TILE (16 * SWS_TP)
 // M = A + diag(clamp(diag A) / radius), padded to np x np with an identity block (whole GPU: one workgroup would be
 // load-latency bound on this 1.2 MB copy)
+// The damped matrix / its factor M is kept as 16x16 tiles in MFMA accumulator order (tile (I,J) at (I*NT + J)*256, element
+// (row, col) at ((row&3)*16 + col)*4 + (row>>2)): the tile Cholesky moves every tile as two 16-byte accesses per lane.
+__device__ __forceinline__ size_t swp_mi(int np, int r, int c) {
+  return ((size_t)(r >> 4) * (np >> 4) + (c >> 4)) * 256 + ((((r & 15) & 3) << 4) + (c & 15)) * 4 + ((r & 15) >> 2);
+}
 __global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, const double* __restrict__ A, double radius, double* __restrict__ M) {
   const int cc = blockIdx.x * 256 + threadIdx.x, rr = blockIdx.y;
   if (cc >= np) return;
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, const doub
     v = A[(size_t)rr * n + cc];
     if (rr == cc) v += fmin(fmax(v, 1e-6), 1e32) / radius;
   }
-  M[(size_t)rr * np + cc] = v;
+  M[swp_mi(np, rr, cc)] = v;
 }
 // sum over the 16 lanes of a row group (lanes sharing l >> 4), result in every lane of the group
 __device__ __forceinline__ double swp_row16_sum(double v) {
@@ -576,9 +581,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
   __syncthreads();
   for (int K = 0; K < NT; K++) {
     if (wave == 0) {
-      v4d a, w;
-#pragma unroll
-      for (int q = 0; q < 4; q++) a[q] = M[(size_t)(16 * K + crow + 4 * q) * np + 16 * K + ccol];
+      v4d a = *reinterpret_cast<const v4d*>(M + ((size_t)K * NT + K) * 256 + 4 * lane), w;
       if (!chol_inv_blocked(a, w) && lane == 0) bad = 1;
       const double yk = yv[16 * K + ccol];
 #pragma unroll
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
       for (int u = 0; u < TU; u++) {
         const int I = min(I0 + 8 * u, NT - 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) av[u][kk] = M[(size_t)(16 * I + ccol) * np + 16 * K + 4 * kk + crow];   // A operand: lane (i = ccol, k = crow)
+        for (int kk = 0; kk < 4; kk++) av[u][kk] = M[swp_mi(np, 16 * I + ccol, 16 * K + 4 * kk + crow)];   // A operand: lane (i = ccol, k = crow)
       }
 #pragma unroll
       for (int u = 0; u < TU; u++) {
@@ -618,10 +621,10 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][2], bv[2], x, 0, 0, 0);
         x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][3], bv[3], x2, 0, 0, 0);
         x += x2;
+        *reinterpret_cast<v4d*>(M + ((size_t)I * NT + K) * 256 + 4 * lane) = x;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           Xp[(size_t)I * SWS_TILE + ccol * SWS_TP + crow + 4 * q] = x[q];
-          M[(size_t)(16 * I + crow + 4 * q) * np + 16 * K + ccol] = x[q];
           const double d = swp_row16_sum(x[q] * zk);
           if (ccol == 0) yv[16 * I + crow + 4 * q] -= d;     // only this wave touches block row I in this step
         }
@@ -647,8 +650,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
 #pragma unroll
           for (int u = 0; u < UNR; u++) {
             const int J = min(J0 + u, I);
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[u][q] = M[(size_t)(16 * I + crow + 4 * q) * np + 16 * J + ccol];
+            acc[u] = *reinterpret_cast<const v4d*>(M + ((size_t)I * NT + J) * 256 + 4 * lane);
           }
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) {
@@ -661,10 +663,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
           }
 #pragma unroll
           for (int u = 0; u < UNR; u++)
-            if (J0 + u <= I) {
-#pragma unroll
-              for (int q = 0; q < 4; q++) M[(size_t)(16 * I + crow + 4 * q) * np + 16 * (J0 + u) + ccol] = acc[u][q];
-            }
+            if (J0 + u <= I) *reinterpret_cast<v4d*>(M + ((size_t)I * NT + J0 + u) * 256 + 4 * lane) = acc[u];
         }
       }
     }
@@ -681,7 +680,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
     }
     if (tid < 16 * K) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) lc[j] = M[(size_t)(16 * K + j) * np + tid];
+      for (int j = 0; j < 16; j++) lc[j] = M[swp_mi(np, 16 * K + j, tid)];
     }
   };
   fetch(NT - 1);
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const d
     const bool upd = tid >= 16 * (K + 1) && tid < np;
     if (upd) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) lr[j] = M[(size_t)tid * np + 16 * K + j];
+      for (int j = 0; j < 16; j++) lr[j] = M[swp_mi(np, tid, 16 * K + j)];
     }
     __syncthreads();
     if (tid < 16) yv[16 * K + tid] = z;
@@ -775,7 +774,7 @@ __global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const d
     const bool upd = tid < 16 * K;
     if (upd) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) lc[j] = M[(size_t)(16 * K + j) * np + tid];
+      for (int j = 0; j < 16; j++) lc[j] = M[swp_mi(np, 16 * K + j, tid)];
     }
     __syncthreads();
     if (tid < 16) yv[16 * K + tid] = z;
