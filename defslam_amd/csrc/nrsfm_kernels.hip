@@ -579,25 +579,27 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
   for (int i = tid; i < np; i += 512) yv[i] = (i < n) ? -g[i] : 0.0;   // M was prepared by swp_damp_kernel
   if (tid == 0) bad = 0;
   __syncthreads();
-  for (int K = 0; K < NT; K++) {
-    if (wave == 0) {
-      v4d a = *reinterpret_cast<const v4d*>(M + ((size_t)K * NT + K) * 256 + 4 * lane), w;
-      if (!chol_inv_blocked(a, w) && lane == 0) bad = 1;
-      const double yk = yv[16 * K + ccol];
+  // Diagonal tile K: Cholesky + inverse (wave 0), W^T into LDS for the TRSM, z_K = W y_K.  `a` = the updated tile.
+  auto factor_diag = [&](int K, v4d a) {
+    v4d w;
+    if (!chol_inv_blocked(a, w) && lane == 0) bad = 1;
+    const double yk = yv[16 * K + ccol];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        Wk[ccol * SWS_TP + crow + 4 * q] = w[q];
-        Winv[(size_t)(16 * K + crow + 4 * q) * 16 + ccol] = w[q];
-      }
-      double z[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) z[q] = swp_row16_sum(w[q] * yk);     // z_K = W y_K, row crow + 4q
-      if (ccol == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) yv[16 * K + crow + 4 * q] = z[q];
-      }
+    for (int q = 0; q < 4; q++) {
+      Wk[ccol * SWS_TP + crow + 4 * q] = w[q];
+      Winv[(size_t)(16 * K + crow + 4 * q) * 16 + ccol] = w[q];
     }
-    __syncthreads();
+    double z[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) z[q] = swp_row16_sum(w[q] * yk);     // z_K = W y_K, row crow + 4q
+    if (ccol == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) yv[16 * K + crow + 4 * q] = z[q];
+    }
+  };
+  if (wave == 0) factor_diag(0, *reinterpret_cast<const v4d*>(M + 4 * lane));
+  __syncthreads();
+  for (int K = 0; K < NT; K++) {
     // TRSM: X_I = A_IK W^T, and the forward substitution of block row I: y_I -= X_I z_K
     const double zk = yv[16 * K + ccol];
     constexpr int TU = 4;   // tiles of this wave in flight (NT <= 32)
@@ -631,39 +633,54 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
       }
     }
     __syncthreads();
-    // trailing update of the lower triangle: tiles (I, J), K < J <= I
-    // Tile rows are dealt to the waves from both ends (row lengths grow linearly: pairing a long with a short row
-    // balances the waves); the A operand of a row is read once, 4 tiles of the row are in flight.
+    // Trailing update of the lower triangle: tiles (I, J), K < J <= I.  Wave 0 looks ahead: it updates the next diagonal
+    // tile and factors it while the other seven waves update the rest, so no step waits for a Cholesky.  The other tile rows
+    // are dealt from both ends (row lengths grow linearly: a long row is paired with a short one); the A operand of a
+    // row is read once, 4 tiles of the row are in flight.
     const int ntr = NT - 1 - K;
-    for (int p = wave; p < (ntr + 1) / 2; p += 8) {
+    if (wave == 0) {
+      if (ntr > 0) {
+        const int I = K + 1;
+        v4d acc = *reinterpret_cast<const v4d*>(M + ((size_t)I * NT + I) * 256 + 4 * lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const double xv = Xp[(size_t)I * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv, xv, acc, 0, 0, 0);
+        }
+        factor_diag(I, acc);
+      }
+    } else {
+      const int R = ntr - 1;                             // tile rows K+2 .. NT-1
+      for (int p = wave - 1; p < (R + 1) / 2; p += 7) {
 #pragma unroll 1
-      for (int side = 0; side < 2; side++) {
-        const int ii = side == 0 ? p : ntr - 1 - p;
-        if (side == 1 && ii == p) break;
-        const int I = K + 1 + ii;
-        double an[4];
+        for (int side = 0; side < 2; side++) {
+          const int rr = side == 0 ? p : R - 1 - p;
+          if (side == 1 && rr == p) break;
+          const int I = K + 2 + rr;
+          double an[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) an[kk] = -Xp[(size_t)I * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
-        constexpr int UNR = 4;
-        for (int J0 = K + 1; J0 <= I; J0 += UNR) {
-          v4d acc[UNR];
-#pragma unroll
-          for (int u = 0; u < UNR; u++) {
-            const int J = min(J0 + u, I);
-            acc[u] = *reinterpret_cast<const v4d*>(M + ((size_t)I * NT + J) * 256 + 4 * lane);
-          }
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) {
+          for (int kk = 0; kk < 4; kk++) an[kk] = -Xp[(size_t)I * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
+          constexpr int UNR = 4;
+          for (int J0 = K + 1; J0 <= I; J0 += UNR) {
+            v4d acc[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
               const int J = min(J0 + u, I);
-              const double bb = Xp[(size_t)J * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
-              acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb, acc[u], 0, 0, 0);
+              acc[u] = *reinterpret_cast<const v4d*>(M + ((size_t)I * NT + J) * 256 + 4 * lane);
             }
-          }
 #pragma unroll
-          for (int u = 0; u < UNR; u++)
-            if (J0 + u <= I) *reinterpret_cast<v4d*>(M + ((size_t)I * NT + J0 + u) * 256 + 4 * lane) = acc[u];
+            for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+              for (int u = 0; u < UNR; u++) {
+                const int J = min(J0 + u, I);
+                const double bb = Xp[(size_t)J * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb, acc[u], 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++)
+              if (J0 + u <= I) *reinterpret_cast<v4d*>(M + ((size_t)I * NT + J0 + u) * 256 + 4 * lane) = acc[u];
+          }
         }
       }
     }
