@@ -98,41 +98,55 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     }
     return s0 + s1;
   };
-  auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
-    if (I == J) {   // diagonal row: both operands are the staged tiles of row J
-      v4d s0 = zero4, s1 = zero4;
-#pragma unroll 1
-      for (int K = K0; K < J; K += U) {
-        v4d a[U];
+  // sum_{K = K0 .. Kend-1} T_K T_K^T with T_K = the stored tile (I, K) from memory as both operands: the diagonal tile of the
+  // NEXT column, formed a column ahead (look-ahead) from the tiles that already exist.
+  auto squares = [&](const SFT_G double* brow, long bstride, int n) -> v4d {
+    v4d s0 = zero4, s1 = zero4;
+    v4d buf[2][U];
+    const int last = max(n - 1, 0);
 #pragma unroll
-        for (int u = 0; u < U; u++) a[u] = lds_tile_read(rowJ + (size_t)max(J - K - u - 1, 0) * TS * TS);
+    for (int u = 0; u < U; u++) buf[0][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(u, last) * bstride + 4 * lane);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c + 1 < 4) {
 #pragma unroll
         for (int u = 0; u < U; u++)
-          if (K + u < J) mfma4(a[u], a[u], s0, s1);
+          buf[(c + 1) & 1][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
       }
-      return s0 + s1;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (U * c + u < n) mfma4(buf[c & 1][u], buf[c & 1][u], s0, s1);
     }
+    return s0 + s1;
+  };
+  auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
     const int n = J - K0;
     if (n <= 0) return zero4;
     if (n <= 2 * U) return products_n(std::integral_constant<int, 2>{}, J, rowJ, brow, bstride, K0);
     return products_n(std::integral_constant<int, 4>{}, J, rowJ, brow, bstride, K0);
   };
   const long kstride = (long)(tpr - 1) * TS * TS;        // tile (I, K+1) sits (tpr - 1) tiles after tile (I, K)
+  // Look-ahead: the diagonal tile of column J+1 minus its products with block columns <= J-1 is formed during column J by the
+  // wave that owns column J+1 next (roles rotate by one wave per column) and waits in its registers.
+  v4d dlook = *reinterpret_cast<const SFT_G v4d*>(Hg + 4 * lane);     // column 0: H(0,0), no products
 
 #pragma unroll 1
   for (int J = 0; J < nT; J++) {
     lds_double* rowJ = Lrow + (size_t)(J & 1) * WB * TS * TS;
     lds_double* rowN = Lrow + (size_t)((J + 1) & 1) * WB * TS * TS;
-    // Roles rotate with the column (nothing but the corner sum lives in registers across columns).  The FP64 MFMA pipe is
-    // what the products are bound by (73 cycles per MFMA, two waves per SIMD: tools/probes/lds_mfma_probe.hip), so the rows
-    // are dealt by their number of products: role 0 owns the diagonal tile (16 products, then the Cholesky: the critical
-    // path) and the product-free tile (J+16, J); the other roles take 19 products each (role 7: 22):
-    //   1: border (16), J+14, J+15 | 2: J+1, J+12 | 3: J+2, J+11 | 4: J+3, J+10 | 5: J+4, J+9 | 6: J+5, J+8 | 7: J+6, J+7, J+13
+    // Roles rotate with the column.  The FP64 MFMA pipe is what the products are bound by (73 cycles per MFMA, two waves per
+    // SIMD: tools/probes/lds_mfma_probe.hip), so the rows are dealt by their number of products, and the Cholesky is taken
+    // off the path every wave waits for: role 0 (owner of column J) starts from the look-ahead tile, adds the one product
+    // with block column J-1, factors, and then does two short rows; role 1 (owner of column J+1) forms the look-ahead tile of
+    // the next column (15 products, tiles from memory) and two short rows; the others take about 20 products each:
+    //   0: diag, J+10, J+12 (+ product-free J+16) | 1: look-ahead, J+13, J+14 | 2: J+1, J+11 | 3: J+2, J+9 | 4: J+3, J+8
+    //   5: J+4, J+7 | 6: J+5, J+6 | 7: border, J+15
     const int d = (wave - J) & 7;
     int Irow[3];
-    Irow[0] = J + (d == 0 ? 0 : d == 1 ? 14 : d - 1);
-    Irow[1] = J + (d == 0 ? 16 : d == 1 ? 15 : 14 - d);
-    Irow[2] = d == 7 ? J + 13 : nT;
+    Irow[0] = J + (d == 0 ? 10 : d == 1 ? 13 : d == 7 ? 15 : d - 1);
+    Irow[1] = J + (d == 0 ? 12 : d == 1 ? 14 : d == 2 ? 11 : d == 3 ? 9 : d == 4 ? 8 : d == 5 ? 7 : d == 6 ? 6 : 99);
+    Irow[2] = d == 0 ? J + 16 : nT;
+    if (d == 7) Irow[1] = nT;
     // stage tile row J+1 for the next column: dist 2 + wave and 10 + wave (dist 1 is produced by this column's TRSM)
     v4d stage[2];
     bool staged[2];
@@ -141,6 +155,28 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
       const int dist = 2 + wave + 8 * h, K = J + 1 - dist;
       staged[h] = dist <= wb && K >= 0 && J + 1 < nT;
       if (staged[h]) stage[h] = *reinterpret_cast<const SFT_G v4d*>(Ltg + wtile_off(tpr, K, dist) + 4 * lane);
+    }
+    if (d == 0) {
+      // the diagonal tile: look-ahead tile minus the product with block column J-1 (the staged tile (J, J-1) twice), Cholesky
+      __builtin_amdgcn_s_setprio(3);
+      v4d dt = dlook;
+      if (J >= 1) {
+        const v4d a = lds_tile_read(rowJ);
+        v4d s0 = zero4, s1 = zero4;
+        mfma4(a, a, s0, s1);
+        dt -= s0 + s1;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (crow + 4 * q == ccol && TS * J + ccol < Dn) dt[q] += lambda;
+      v4d w = dt;
+      const bool ok = chol_inv_blocked(dt, w);
+      if (!ok && lane == 0) ctl->fact_ok = 0;
+      lds_double* dst = LinvK + ccol * TP + crow;
+#pragma unroll
+      for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
+      *reinterpret_cast<SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane) = w;
+      __builtin_amdgcn_s_setprio(0);
     }
     v4d accT[3];
     bool have[3];
@@ -153,25 +189,17 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
         const int K0 = max(0, I - wb);
         accT[t] = h - products(J, I, rowJ, Ltg + wtile_off(tpr, K0, I - K0), kstride, K0);
       }
-      if (t == 0 && d == 0) {
-        // diagonal tile first: it is the critical path of the column
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (crow + 4 * q == ccol && TS * J + ccol < Dn) accT[0][q] += lambda;
-        v4d w = accT[0];
-        const bool ok = chol_inv_blocked(accT[0], w);
-        if (!ok && lane == 0) ctl->fact_ok = 0;
-        lds_double* dst = LinvK + ccol * TP + crow;
-#pragma unroll
-        for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
-        *reinterpret_cast<SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane) = w;
-        __builtin_amdgcn_s_setprio(0);
-      }
+    }
+    if (d == 1 && J + 1 < nT) {
+      // look-ahead for column J+1: H(J+1,J+1) - sum_{K <= J-1} L(J+1,K) L(J+1,K)^T  (the product with block column J follows
+      // in the next column, when tile (J+1, J) exists)
+      const int I = J + 1, K0 = max(0, I - wb);
+      const v4d h = *reinterpret_cast<const SFT_G v4d*>(Hg + wtile_off(tpr, I, 0) + 4 * lane);
+      dlook = h - squares(Ltg + wtile_off(tpr, K0, I - K0), kstride, J - K0);
     }
     // border: accTb[j][i] = Hbord[i][16 J + j] - sum_K (L(J,K) Lb(K)^T)[j][i], i < 7
     v4d accTb = zero4;
-    const bool bwave = d == 1;
+    const bool bwave = d == 7;
     if (bwave) {
       v4d h = zero4;
       if (ccol < SFT_BORDER) {
