@@ -109,6 +109,27 @@ def test_partial_view_keeps_unseen_nodes_fixed(gpu_ctx, oracle_mod):
     assert not moved[far].any()                      # fixed vertices are returned bit-identical
 
 
+@pytest.mark.parametrize("shape,cols_kept", [((6, 41), 30), ((8, 30), 24)])
+def test_partial_view_on_a_wide_band_template(gpu_ctx, oracle_mod, shape, cols_kept):
+    """The wide tile solver (half-bandwidth > 128) with a partially observed template: fewer active nodes than the template has,
+    an active block whose size is not a multiple of the tile size, tile rows near the end of the matrix with short bands."""
+    from defslam_amd import synth
+    rows, cols = shape
+    tmpl = synth.make_grid_template(rows, cols)
+    fr = synth.make_frame(tmpl, 700, 11)
+    keep = [c + cols * r for r in range(rows) for c in range(cols_kept)]
+    sel = np.all(np.isin(fr.obs_nodes, keep), axis=1)
+    for k in ["obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+        setattr(fr, k, getattr(fr, k)[sel])
+    tc, args = oracle_args(oracle_mod, tmpl, fr)
+    r = oracle_mod.sft_solve(*args, ldlt_mode=1)
+    f, inl = _solve_gpu(gpu_ctx, tmpl.xyz0, tmpl.facets, dict(Tcw=fr.Tcw, K=fr.K, n_frame=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary,
+                                                              obs_uv=fr.obs_uv, obs_invsig2=fr.obs_invsig2, xyz=fr.xyz),
+                    (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP))
+    assert f.half_bandwidth > 128 and f.dim == r.dims[0] < 6 + 3 * tmpl.n
+    _compare(f, inl, r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+
+
 def test_warm_started_sequence(gpu_ctx, oracle_mod):
     """Frame-to-frame tracking: every frame starts from the previous result (float32 pose round trip)."""
     from defslam_amd import sft, synth
