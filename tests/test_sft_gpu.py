@@ -150,10 +150,12 @@ def test_warm_started_sequence(gpu_ctx, oracle_mod):
         Tg, xg, To, xo = f.Tcw, f.nodes_xyz, r.Tcw, r.xyz
 
 
-def test_batch_equals_single_and_is_reproducible(gpu_ctx):
-    """Independent problems in one launch give bit-identical results to one-at-a-time solves, run after run."""
+@pytest.mark.parametrize("shape", [(10, 10), (6, 41)], ids=["narrow", "wide-band"])
+def test_batch_equals_single_and_is_reproducible(gpu_ctx, shape):
+    """Independent problems in one launch give bit-identical results to one-at-a-time solves, run after run (register-window
+    tile solver and, for the 6x41 template with half-bandwidth 248, the left-looking wide tile solver; mixed match counts)."""
     from defslam_amd import sft, synth
-    tmpl = synth.make_grid_template(10, 10)
+    tmpl = synth.make_grid_template(*shape)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
     frames = [sft.frame_from_synth(synth.make_frame(tmpl, 200 + 10 * p, p)) for p in range(9)]
     inl = sft.DefPoseOptimizationBatch(gpu_ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
