@@ -173,6 +173,33 @@ def test_batch_equals_single_and_is_reproducible(gpu_ctx, shape):
         np.testing.assert_array_equal(f1.pose7, frames[p].pose7)
 
 
+def test_one_batch_may_mix_solvers(gpu_ctx):
+    """Problems of one batch choose their solver by their own half-bandwidth: a partially observed frame of the 8x30 template falls
+    below 128 (register-window tiles), a fuller view stays above (wide tiles).  Both in one launch = each alone, bit for bit."""
+    from defslam_amd import sft, synth
+    tmpl = synth.make_grid_template(8, 30)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+
+    def frame(cols_kept, pid):
+        fr = synth.make_frame(tmpl, 700, pid)
+        keep = [c + 30 * r for r in range(8) for c in range(cols_kept)]
+        sel = np.all(np.isin(fr.obs_nodes, keep), axis=1)
+        for k in ["obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+            setattr(fr, k, getattr(fr, k)[sel])
+        return sft.frame_from_synth(fr)
+
+    batch = [frame(17, 1), frame(24, 2), frame(30, 3), frame(12, 4)]
+    sft.DefPoseOptimizationBatch(gpu_ctx, batch, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    kinds = [f.half_bandwidth > 128 for f in batch]
+    assert any(kinds) and not all(kinds)
+    for f, (cols_kept, pid) in zip(batch, [(17, 1), (24, 2), (30, 3), (12, 4)]):
+        one = frame(cols_kept, pid)
+        sft.DefPoseOptimization(gpu_ctx, one, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        assert (one.iters, one.trials, one.half_bandwidth) == (f.iters, f.trials, f.half_bandwidth)
+        np.testing.assert_array_equal(one.nodes_xyz, f.nodes_xyz)
+        np.testing.assert_array_equal(one.pose7, f.pose7)
+
+
 @pytest.mark.parametrize("cfg,pid", [("smoke", 3), ("C2", 5)])
 def test_four_wavefront_launch_shape_matches_eight(gpu_ctx, oracle_mod, cfg, pid, monkeypatch):
     """The throughput launch shape (4 wavefronts per problem, two ring rows per wave, chosen by the library once a batch
