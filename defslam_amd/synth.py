@@ -29,6 +29,7 @@ CONFIGS = {
     "C5": (50, 40, 4000),   # 2000-node template, 4000 matches (configs[4], per problem)
     "W12": (8, 30, 500),    # small wide-band cases for oracle-sized parity runs: half-bandwidth 182 (12 sub-diagonal tiles) ...
     "W16": (6, 41, 500),    # ... and 248 (16 tiles, the C5 band) with 246 nodes
+    "B272": (5, 45, 400),   # half-bandwidth 272 > 256: the row-major band solver (general fallback)
 }
 
 

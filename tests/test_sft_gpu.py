@@ -54,7 +54,7 @@ def test_hip_matches_golden_vectors(gpu_ctx, path):
     np.testing.assert_allclose(f.chi2_obs, g["out_chi2_obs"], rtol=1e-8, atol=1e-12)
 
 
-@pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0), ("W12", 1), ("W16", 2)])
+@pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0), ("W12", 1), ("W16", 2), ("B272", 3)])
 def test_hip_matches_oracle_seeded(gpu_ctx, oracle_mod, cfg, pid):
     from defslam_amd import synth
     tmpl, fr = synth.make_problem(cfg, pid)
