@@ -132,19 +132,24 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
   const double ftol = 1e-6, gtol = 1e-10, ptol = 1e-8, min_rel_dec = 1e-3;
   double radius = 1e4, nu = 2.0;
   int it = 0, good = 0, invalid = 0;
+  // One host round trip per iteration: the trial point is evaluated speculatively right behind the solve (a failed solve or a
+  // vanishing step only wastes that evaluation), and the gradient test of an accepted step -- `max |g| <= gtol` after the new
+  // linearisation -- is read with the scalars of the next iteration (whose speculative work is dropped if it fires).
+  bool pending_gtol = false;     // an accepted step was linearised; its max |g| has not been looked at yet
   if (s[6] > gtol)
     while (it < max_iters) {
       it++;
       HIPCHK(c, nrsfm_swp_solve(f.n2, f.A.as<double>(), f.g.as<double>(), radius, f.M.as<double>(), f.W.as<double>(), f.dx.as<double>(), scal + 2, f.st));
       HIPCHK(c, nrsfm_swp_step(f.n2, f.x.as<double>(), f.dx.as<double>(), f.cs.as<double>(), f.g.as<double>(), f.xn.as<double>(), scal + 2, f.st));
+      if ((rc = f.eval(f.xn.as<double>(), false)) != DSH_OK) return rc;   // residuals only: J, A, g still belong to x
       if ((rc = f.scalars(s)) != DSH_OK) return rc;
+      if (pending_gtol && s[6] <= gtol) { it--; break; }                  // the previous iteration had already converged
+      pending_gtol = false;
       const bool ok = s[2] != 0.0;
       const double model = s[3];
       if (!ok) { if (++invalid >= 5) break; radius *= 0.5; continue; }
       invalid = 0;
       if (s[4] <= ptol * (s[5] + ptol)) break;
-      if ((rc = f.eval(f.xn.as<double>(), false)) != DSH_OK) return rc;   // residuals only: J, A, g still belong to x
-      if ((rc = f.scalars(s)) != DSH_OK) return rc;
       const double cost_new = s[0];
       const double rel = (cost - cost_new) / model;
       if (rel > min_rel_dec) {
@@ -153,11 +158,9 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
         radius = std::fmin(1e16, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
         nu = 2.0;
         good++;
-        if ((rc = f.eval(f.x.as<double>(), true)) != DSH_OK) return rc;
-        HIPCHK(c, nrsfm_swp_step(f.n2, f.x.as<double>(), f.dx.as<double>(), f.cs.as<double>(), f.g.as<double>(), f.xn.as<double>(), scal + 2, f.st));
-        if ((rc = f.scalars(s)) != DSH_OK) return rc;
-        cost = s[0];
-        if (s[6] <= gtol) break;
+        if ((rc = f.eval(f.x.as<double>(), true)) != DSH_OK) return rc;   // same residuals as the trial evaluation: cost == cost_new
+        cost = cost_new;
+        pending_gtol = true;
         if (std::fabs(change) <= ftol * old) break;
       } else {
         radius /= nu; nu *= 2.0;
