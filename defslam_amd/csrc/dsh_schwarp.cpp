@@ -16,7 +16,7 @@ extern "C" hipError_t nrsfm_swp_eval(double, double, int, double, double, int, i
 extern "C" hipError_t nrsfm_swp_loss(int, int, const double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_normal(int, int, int, double*, double*, const double*, const double*, double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_colscale(int, const double*, double*, hipStream_t);
-extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, int, int, hipStream_t);
 extern "C" int nrsfm_swp_solve_np(int);
 extern "C" hipError_t nrsfm_swp_step(int, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_diffprop(double, double, int, double, double, int, int, const float*, const float*, const double*, float, float, float*,
@@ -139,7 +139,7 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
   if (s[6] > gtol)
     while (it < max_iters) {
       it++;
-      HIPCHK(c, nrsfm_swp_solve(f.n2, f.A.as<double>(), f.g.as<double>(), radius, f.M.as<double>(), f.W.as<double>(), f.dx.as<double>(), scal + 2, f.st));
+      HIPCHK(c, nrsfm_swp_solve(f.n2, f.A.as<double>(), f.g.as<double>(), radius, f.M.as<double>(), f.W.as<double>(), f.dx.as<double>(), scal + 2, 1, 2 * (3 * bbs->nptsv + 3) + 1, f.st));
       HIPCHK(c, nrsfm_swp_step(f.n2, f.x.as<double>(), f.dx.as<double>(), f.cs.as<double>(), f.g.as<double>(), f.xn.as<double>(), scal + 2, f.st));
       if ((rc = f.eval(f.xn.as<double>(), false)) != DSH_OK) return rc;   // residuals only: J, A, g still belong to x
       if ((rc = f.scalars(s)) != DSH_OK) return rc;

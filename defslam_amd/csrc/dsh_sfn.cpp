@@ -14,8 +14,8 @@
 #include "dsh_ctx.h"
 
 extern "C" hipError_t nrsfm_swp_normal(int, int, int, double*, double*, const double*, const double*, double*, double*, hipStream_t);
-extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, hipStream_t);
-extern "C" hipError_t nrsfm_swp_resolve(int, const double*, const double*, const double*, double*, hipStream_t);
+extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, int, int, hipStream_t);
+extern "C" hipError_t nrsfm_swp_resolve(int, const double*, const double*, const double*, double*, int, int, hipStream_t);
 extern "C" int nrsfm_swp_solve_np(int);
 extern "C" hipError_t nrsfm_sfn_rows(double, double, int, double, double, int, int, const double*, const double*, const float*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_sfn_residual(int, int, const double*, const double*, const double*, double, double*, hipStream_t);
@@ -136,8 +136,8 @@ int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, c
   for (int it = 0; it < 3; it++) {
     HIPCHK(c, nrsfm_sfn_residual(m, N, dA.as<double>(), dx.as<double>(), db.as<double>(), -1.0, dr.as<double>(), st));
     HIPCHK(c, nrsfm_swp_normal(0, m, N, dA.as<double>(), dr.as<double>(), dones.as<double>(), scal, dG.as<double>(), dg.as<double>(), st));
-    if (it == 0) HIPCHK(c, nrsfm_swp_solve(N, dG.as<double>(), dg.as<double>(), 1e300, dM.as<double>(), dW.as<double>(), ddx.as<double>(), scal + 2, st));
-    else HIPCHK(c, nrsfm_swp_resolve(N, dg.as<double>(), dM.as<double>(), dW.as<double>(), ddx.as<double>(), st));
+    if (it == 0) HIPCHK(c, nrsfm_swp_solve(N, dG.as<double>(), dg.as<double>(), 1e300, dM.as<double>(), dW.as<double>(), ddx.as<double>(), scal + 2, 0, N, st));   // dense: the mean-depth row couples every pair of control points
+    else HIPCHK(c, nrsfm_swp_resolve(N, dg.as<double>(), dM.as<double>(), dW.as<double>(), ddx.as<double>(), 0, N, st));
     HIPCHK(c, nrsfm_sfn_axpy(N, ddx.as<double>(), dx.as<double>(), st));
   }
   std::vector<double> x((size_t)N);
@@ -199,8 +199,8 @@ int dsh_warp_initialize(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp
   HIPCHK(c, nrsfm_swp_normal(0, P, N, dC.as<double>(), dr1.as<double>(), dones.as<double>(), scal, dG.as<double>(), dg1.as<double>(), st));
   HIPCHK(c, nrsfm_swp_normal(0, P, N, dC.as<double>(), dr0.as<double>(), dones.as<double>(), scal, dG.as<double>(), dg0.as<double>(), st));
   HIPCHK(c, nrsfm_mat_add((size_t)N * N, dB.as<double>(), dG.as<double>(), st));
-  HIPCHK(c, nrsfm_swp_solve(N, dG.as<double>(), dg0.as<double>(), 1e300, dM.as<double>(), dW.as<double>(), dx.as<double>(), scal + 2, st));
-  HIPCHK(c, nrsfm_swp_resolve(N, dg1.as<double>(), dM.as<double>(), dW.as<double>(), dx.as<double>() + N, st));
+  HIPCHK(c, nrsfm_swp_solve(N, dG.as<double>(), dg0.as<double>(), 1e300, dM.as<double>(), dW.as<double>(), dx.as<double>(), scal + 2, 0, 3 * bbs->nptsv + 3, st));   // colocation and bending couple a 4 x 4 patch: banded
+  HIPCHK(c, nrsfm_swp_resolve(N, dg1.as<double>(), dM.as<double>(), dW.as<double>(), dx.as<double>() + N, 0, 3 * bbs->nptsv + 3, st));
   double s8[8];
   HIPCHK(c, hipMemcpyAsync(x, dx.p, 8 * (size_t)2 * N, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(s8, dscal.p, 64, hipMemcpyDeviceToHost, st));

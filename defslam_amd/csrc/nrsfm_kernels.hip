@@ -550,7 +550,11 @@ __global__ __launch_bounds__(256) void swp_normal_kernel(int m, int n2, int nt, 
 __device__ __forceinline__ size_t swp_mi(int np, int r, int c) {
   return ((size_t)(r >> 4) * (np >> 4) + (c >> 4)) * 256 + ((((r & 15) & 3) << 4) + (c & 15)) * 4 + ((r & 15) >> 2);
 }
-__global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, const double* __restrict__ A, double radius, double* __restrict__ M) {
+// Unknown ordering inside the solver.  A two-coordinate problem (Schwarp: n = 2N, first coordinates then second ones) is
+// interleaved (x0, y0, x1, y1, ...): control points couple within a 4 x 4 patch of the grid, so the interleaved normal matrix is
+// banded (half-bandwidth 2 (3 nptsv + 3) + 1) and the factorisation only visits the tiles of the band.
+__device__ __forceinline__ int swp_perm(int n, int il, int i) { return (il && i < n) ? ((i < n / 2) ? 2 * i : 2 * (i - n / 2) + 1) : i; }
+__global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, int il, const double* __restrict__ A, double radius, double* __restrict__ M) {
   const int cc = blockIdx.x * 256 + threadIdx.x, rr = blockIdx.y;
   if (cc >= np) return;
   double v = (rr == cc) ? 1.0 : 0.0;
@@ -558,15 +562,16 @@ __global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, const doub
     v = A[(size_t)rr * n + cc];
     if (rr == cc) v += fmin(fmax(v, 1e-6), 1e32) / radius;
   }
-  M[swp_mi(np, rr, cc)] = v;
+  M[swp_mi(np, swp_perm(n, il, rr), swp_perm(n, il, cc))] = v;
 }
 // sum over the 16 lanes of a row group (lanes sharing l >> 4), result in every lane of the group
 __device__ __forceinline__ double swp_row16_sum(double v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
 }
-__global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const double* __restrict__ A, const double* __restrict__ g, double radius,
+__global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, int il, int bwt, const double* __restrict__ A, const double* __restrict__ g, double radius,
                                                         double* __restrict__ M, double* __restrict__ Winv, double* __restrict__ dx, double* __restrict__ out) {
+  // il: interleaved unknown ordering (swp_perm); bwt: sub-diagonal tiles of the band (NT - 1: dense)
   extern __shared__ double sws[];
   const int NT = np / 16;
   double* Xp = sws;                       // NT panel tiles, k-major padded: Xp[T*SWS_TILE + k*SWS_TP + i] = X_T[i][k]
@@ -576,7 +581,9 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
   __shared__ int bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int crow = lane >> 4, ccol = lane & 15;
-  for (int i = tid; i < np; i += 512) yv[i] = (i < n) ? -g[i] : 0.0;   // M was prepared by swp_damp_kernel
+  for (int i = tid; i < np; i += 512) yv[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 512) yv[swp_perm(n, il, i)] = -g[i];     // M was prepared by swp_damp_kernel
   if (tid == 0) bad = 0;
   __syncthreads();
   // Diagonal tile K: Cholesky + inverse (wave 0), W^T into LDS for the TRSM, z_K = W y_K.  `a` = the updated tile.
@@ -603,20 +610,21 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
     // TRSM: X_I = A_IK W^T, and the forward substitution of block row I: y_I -= X_I z_K
     const double zk = yv[16 * K + ccol];
     constexpr int TU = 4;   // tiles of this wave in flight (NT <= 32)
-    for (int I0 = K + 1 + wave; I0 < NT; I0 += 8 * TU) {
+    const int Iend = min(NT, K + 1 + bwt);          // tile rows below the band hold zeros: not visited
+    for (int I0 = K + 1 + wave; I0 < Iend; I0 += 8 * TU) {
       double av[TU][4], bv[4];
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) bv[kk] = Wk[(4 * kk + crow) * SWS_TP + ccol];                        // B[k][j] = W[j][k]
 #pragma unroll
       for (int u = 0; u < TU; u++) {
-        const int I = min(I0 + 8 * u, NT - 1);
+        const int I = min(I0 + 8 * u, Iend - 1);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) av[u][kk] = M[swp_mi(np, 16 * I + ccol, 16 * K + 4 * kk + crow)];   // A operand: lane (i = ccol, k = crow)
       }
 #pragma unroll
       for (int u = 0; u < TU; u++) {
         const int I = I0 + 8 * u;
-        if (I >= NT) break;
+        if (I >= Iend) break;
         v4d x = {0.0, 0.0, 0.0, 0.0}, x2 = x;
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[0], x, 0, 0, 0);
         x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[1], x2, 0, 0, 0);
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
     // tile and factors it while the other seven waves update the rest, so no step waits for a Cholesky.  The other tile rows
     // are dealt from both ends (row lengths grow linearly: a long row is paired with a short one); the A operand of a
     // row is read once, 4 tiles of the row are in flight.
-    const int ntr = NT - 1 - K;
+    const int ntr = Iend - 1 - K;
     if (wave == 0) {
       if (ntr > 0) {
         const int I = K + 1;
@@ -695,7 +703,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
 #pragma unroll
       for (int j = 0; j < 16; j++) wt[j] = Winv[(size_t)(16 * K + j) * 16 + tid];     // column tid of W_K = row of W_K^T
     }
-    if (tid < 16 * K) {
+    if (tid < 16 * K && tid >= 16 * (K - bwt)) {
 #pragma unroll
       for (int j = 0; j < 16; j++) lc[j] = M[swp_mi(np, 16 * K + j, tid)];
     }
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
     double lcur[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) lcur[j] = lc[j];
-    const bool upd = tid < 16 * K;
+    const bool upd = tid < 16 * K && tid >= 16 * (K - bwt);
     __syncthreads();
     if (tid < 16) yv[16 * K + tid] = z;
     fetch(K - 1);
@@ -723,20 +731,20 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
     }
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 512) dx[i] = yv[i];
+  for (int i = tid; i < n; i += 512) dx[i] = yv[swp_perm(n, il, i)];
   // ---- model decrease -(dx.g + 1/2 dx^T A dx): a wave per row, lanes across the columns --------------------------
   double part = 0.0;
   for (int a0 = 4 * wave; a0 < n; a0 += 32) {   // four rows per wave in flight
     double t[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b2 = lane; b2 < n; b2 += 64) {
-      const double xb = yv[b2];
+      const double xb = yv[swp_perm(n, il, b2)];
 #pragma unroll
       for (int u = 0; u < 4; u++) t[u] = fma((a0 + u < n) ? A[(size_t)(a0 + u) * n + b2] : 0.0, xb, t[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       for (int o = 32; o > 0; o >>= 1) t[u] += __shfl_down(t[u], o, 64);
-      if (lane == 0 && a0 + u < n) part += yv[a0 + u] * (g[a0 + u] + 0.5 * t[u]);
+      if (lane == 0 && a0 + u < n) part += yv[swp_perm(n, il, a0 + u)] * (g[a0 + u] + 0.5 * t[u]);
     }
   }
   if (lane == 0) red[wave] = part;
@@ -752,11 +760,13 @@ __global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, const dou
 
 // Substitutions only, with the factor left in M / Winv by swp_solve_kernel: M dx = -g (iterative refinement of the
 // Shape-from-Normals least squares).  One workgroup, np <= 512.
-__global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const double* __restrict__ g, const double* __restrict__ M,
+__global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, int il, int bwt, const double* __restrict__ g, const double* __restrict__ M,
                                                           const double* __restrict__ Winv, double* __restrict__ dx) {
   __shared__ double yv[512];
   const int tid = threadIdx.x, NT = np / 16;
-  yv[tid] = (tid < n) ? -g[tid] : 0.0;
+  yv[tid] = 0.0;
+  __syncthreads();
+  if (tid < n) yv[swp_perm(n, il, tid)] = -g[tid];
   __syncthreads();
   for (int K = 0; K < NT; K++) {
     double z = 0.0;
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const d
       for (int k = 0; k < 16; k++) z = fma(Winv[(size_t)(16 * K + tid) * 16 + k], yv[16 * K + k], z);
     }
     double lr[16];
-    const bool upd = tid >= 16 * (K + 1) && tid < np;
+    const bool upd = tid >= 16 * (K + 1) && tid < min(np, 16 * (K + 1 + bwt));
     if (upd) {
 #pragma unroll
       for (int j = 0; j < 16; j++) lr[j] = M[swp_mi(np, tid, 16 * K + j)];
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const d
       for (int j = 0; j < 16; j++) z = fma(Winv[(size_t)(16 * K + j) * 16 + tid], yv[16 * K + j], z);
     }
     double lc[16];
-    const bool upd = tid < 16 * K;
+    const bool upd = tid < 16 * K && tid >= 16 * (K - bwt);
     if (upd) {
 #pragma unroll
       for (int j = 0; j < 16; j++) lc[j] = M[swp_mi(np, 16 * K + j, tid)];
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, const d
     }
     __syncthreads();
   }
-  if (tid < n) dx[tid] = yv[tid];
+  if (tid < n) dx[tid] = yv[swp_perm(n, il, tid)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1102,8 +1112,12 @@ extern "C" hipError_t nrsfm_swp_colscale(int n2, const double* A, double* cs, hi
 }
 // M: np*np doubles, Winv: np*16 doubles with np = nrsfm_swp_solve_np(n2)
 extern "C" int nrsfm_swp_solve_np(int n2) { return 16 * ((n2 + 15) / 16); }
-extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, double radius, double* M, double* Winv, double* dx, double* out, hipStream_t st) {
+// interleave: two-coordinate unknown vector (first coordinates, then second ones) reordered inside the solver; kd: scalar
+// half-bandwidth of the (reordered) matrix, >= n for a dense one.
+extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, double radius, double* M, double* Winv, double* dx, double* out, int interleave,
+                                      int kd, hipStream_t st) {
   const int np = nrsfm_swp_solve_np(n2), NT = np / 16;
+  const int bwt = min(NT - 1, (max(kd, 0) + 15) / 16);
   const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + np + 16);
   if (lds > 150 * 1024 || np > 512) return hipErrorInvalidValue;   // one thread per unknown in the backward substitution
   static size_t configured = 0;
@@ -1112,8 +1126,8 @@ extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, 
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL(swp_damp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, n2, np, A, radius, M);
-  hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), lds, st, n2, np, A, g, radius, M, Winv, dx, out);
+  hipLaunchKernelGGL(swp_damp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, n2, np, interleave, A, radius, M);
+  hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), lds, st, n2, np, interleave, bwt, A, g, radius, M, Winv, dx, out);
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_swp_step(int n2, const double* x, const double* dx, const double* cs, const double* g, double* xn, double* out, hipStream_t st) {
@@ -1127,10 +1141,11 @@ extern "C" hipError_t nrsfm_swp_diffprop(double umin, double umax, int nu, doubl
   return hipGetLastError();
 }
 
-extern "C" hipError_t nrsfm_swp_resolve(int n2, const double* g, const double* M, const double* Winv, double* dx, hipStream_t st) {
-  const int np = nrsfm_swp_solve_np(n2);
+extern "C" hipError_t nrsfm_swp_resolve(int n2, const double* g, const double* M, const double* Winv, double* dx, int interleave, int kd, hipStream_t st) {
+  const int np = nrsfm_swp_solve_np(n2), NT = np / 16;
   if (np > 512) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(swp_resolve_kernel, dim3(1), dim3(512), 0, st, n2, np, g, M, Winv, dx);
+  const int bwt = min(NT - 1, (max(kd, 0) + 15) / 16);
+  hipLaunchKernelGGL(swp_resolve_kernel, dim3(1), dim3(512), 0, st, n2, np, interleave, bwt, g, M, Winv, dx);
   return hipGetLastError();
 }
 extern "C" hipError_t nrsfm_sfn_rows(double umin, double umax, int nu, double vmin, double vmax, int nv, int n, const double* u, const double* v,
