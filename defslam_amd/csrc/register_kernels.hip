@@ -215,7 +215,16 @@ __global__ __launch_bounds__(256) void smm_finish_kernel(int n, int ncand, const
   __syncthreads();
   if (threadIdx.x == 0) {   // float sums in index order, like the reference
     float num = 0.0f, den = 0.0f;
-    for (int i = 0; i < n; i++) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {            // eight pairs per LDS round trip, the additions stay in index order
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a[u] = prod[2 * (i + u)]; b[u] = prod[2 * (i + u) + 1]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (a[u] == a[u]) { num += a[u]; den += b[u]; }
+    }
+    for (; i < n; i++) {
       const float a = prod[2 * i];
       if (a != a) continue;
       num += a;
