@@ -1,18 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- SfT Gauss-Newton/LM iterations per second on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run,
-one rank per GPU).  One *step* = one pass of the hot path over one batch: every rank solves
-`--batch` independent single-frame SfT problems of BASELINE.json configs[1] (500-node template
-20x25, 1000 synthetic ORB matches, 640x480 camera) from their uploaded initial state to LM
-termination, device-resident (inputs are in HBM before the timed region starts).
-The path shards over independent problems with no data-path collective -> weak scaling.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment the script
+spawns its N ranks itself (torch.distributed.run, one rank per GPU, RCCL) and refuses to run when the node has fewer
+than N devices; the driver's own `python -m torch.distributed.run ... bench.py --gpus N` launch works the same way.
+
+One *step* = one pass of the hot path over one batch: every rank solves `--batch` independent single-frame SfT problems
+of BASELINE.json configs[1] (500-node template 20x25, 1000 synthetic ORB matches, 640x480 camera) from their uploaded
+initial state to LM termination, device-resident (inputs are in HBM before the timed region starts).  The path shards
+over independent problems with no data-path collective -> weak scaling.
+
+Everything that is timed runs in the PRODUCT library (libdefslam_hip.so); the kernel duration comes from two HIP events
+this script records on the library's launch stream (dsh_stream).  Only the isolated-assembly leg uses the lab build.
 
 Rank 0 prints ONE JSON line; `value` = LM iterations of all ranks / max-over-ranks wall time.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +31,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector == matrix peak
+PROFILE_ROUND = "r02"
+
+
+def kernel_source_hash() -> str:
+    """Identifies the device code a PMC traffic figure was measured on (profiles/<round>/traffic.json stores it)."""
+    h = hashlib.sha256()
+    for name in ("sft_kernels.hip", "sft_wide.h", "tile_chol.h", "sft_problem.h"):
+        with open(os.path.join(ROOT, "defslam_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(tmpl, m, budget_s):
@@ -43,10 +61,75 @@ def cpu_baseline(tmpl, m, budget_s):
         probs += 1
         D = int(r.dims[0])
     dt = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"{probs} whole problems of the same workload (ids 0..{probs - 1}): {iters} LM iterations, {trials} dense LDLT trials, "
+    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port", "runs": 1,
+            "sample": f"{probs} whole problems of the same workload (ids 0..{probs - 1}), each solved ONCE (BASELINE.md asks for a median of >= 20 runs; "
+                      f"one 3.4 s dense-LDLT solve per problem is what the few-minute budget allows): {iters} LM iterations, {trials} dense LDLT trials, "
                       f"D={D}, {dt:.1f} s; oracle/sft_oracle.c ldlt_mode=0, 1 thread (reference binary not buildable: Eigen/OpenCV absent)",
             "lm_trials_per_s": trials / dt, "frames_per_s": probs / dt}
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here.  Fails loudly when the node has fewer devices."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to report an {n}-GPU number from fewer devices", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def e2e_legs(ctx, tmpl, m, frames, regs):
+    """End-to-end frame timing through the one-shot ABI call dsh_sft_solve: pack + upload + run + download + classification
+    (SURVEY 8d "frame"), host wall clock around the C call with the C structs prepared beforehand."""
+    from defslam_amd import sft, synth
+    out = {}
+    # (1) one C2 frame, repeated
+    call = ctx.prepare_solve(frames[0], *regs, 1, 50)
+    call()
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e3
+    f0 = call.frame
+    out["single_frame"] = {"ms_per_frame_median": float(np.median(ts)), "ms_per_frame_min": float(ts.min()), "frames_e2e_per_s": float(1e3 / np.median(ts)),
+                           "iters": int(f0.iters), "trials": int(f0.trials), "runs": 20,
+                           "what": "dsh_sft_solve wall clock: host packing, one H2D copy, the persistent kernel, one D2H copy of the result slab, device-side classification"}
+    # (2) SEQ100: a 100-frame sequence with smooth deformation, every frame warm-started from the previous result
+    n_frames = synth.SEQ100["n_frames"]
+    T, x = np.eye(4, dtype=np.float32), tmpl.xyz0.copy()
+    tot = 0.0
+    iters = trials = 0
+    errs = []
+    for k in range(n_frames):
+        fr = synth.make_sequence_frame(tmpl, m, k, n_frames, synth.SEQ100["seq_id"], init_xyz=x, init_Tcw=T)
+        call = ctx.prepare_solve(sft.frame_from_synth(fr), *regs, 1, 50)
+        t0 = time.perf_counter()
+        call()
+        tot += time.perf_counter() - t0
+        f = call.frame
+        iters += f.iters
+        trials += f.trials
+        errs.append(float(np.abs(f.nodes_xyz - fr.gt_xyz).max()))
+        T, x = f.Tcw, f.nodes_xyz
+    out["seq100"] = {"frames": n_frames, "frames_e2e_per_s": n_frames / tot, "ms_per_frame_mean": 1e3 * tot / n_frames, "iters_per_frame": iters / n_frames,
+                     "trials_per_frame": trials / n_frames, "iters_per_s": iters / tot, "max_vertex_error_vs_gt_last_frame": errs[-1],
+                     "what": "synthetic 100-frame sequence (smooth bend + camera loop), warm start frame to frame with the float32 pose round trip; "
+                             "sum of dsh_sft_solve wall clocks (frame synthesis excluded)"}
+    return out
 
 
 def main():
@@ -54,13 +137,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8192, help="independent problems per GPU per step (8192 = 32 per CU, 27 GB of HBM: problems need 7-35 damping trials and a launch ends with its slowest one, so a deep batch amortises the tail)")
+    ap.add_argument("--batch", type=int, default=0, help="independent problems per GPU per step (default: 8192 for C2 = 32 per CU, 27 GB of HBM: problems need 7-35 damping "
+                                                         "trials and a launch ends with its slowest one, so a deep batch amortises the tail; 16 for C5 = BASELINE configs[4])")
     ap.add_argument("--config", default="C2", choices=["smoke", "C2", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip latency / end-to-end / isolated-assembly legs (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank); gloo only to exercise the multi-rank path on a single GPU")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing aid: every rank uses this device index instead of LOCAL_RANK")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = {"C2": 8192, "C5": 16, "smoke": 512}[args.config]
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     from defslam_amd import sft, synth
@@ -68,11 +161,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to mislabel the run", file=sys.stderr)
+        sys.exit(2)
     if args.all_ranks_on_device >= 0:
         local_rank = args.all_ranks_on_device
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    elif torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs GPU {local_rank} but the node exposes {torch.cuda.device_count()}", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -86,12 +182,13 @@ def main():
         torch.cuda.set_device(local_rank)
 
     rows, cols, m = synth.CONFIGS[args.config]
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     tmpl = synth.make_grid_template(rows, cols)
     ctx = sft.Context(local_rank)
     ctx.template_build(tmpl.xyz0, tmpl.facets)
     # problems are sharded over ranks by id: rank r owns ids r*B .. r*B+B-1 (no data-path collective)
     frames = [sft.frame_from_synth(synth.make_frame(tmpl, m, rank * args.batch + p)) for p in range(args.batch)]
-    ctx.batch_upload(frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
+    ctx.batch_upload(frames, *regs, 1, 50)
 
     def barrier():
         if dist is not None:
@@ -103,12 +200,10 @@ def main():
         ctx.batch_run()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = ctx.batch_run_timed(args.steps)     # K launches bracketed by HIP events on the launch stream
+    kernel_ms = ctx.batch_run_timed(args.steps)     # K launches bracketed by this script's HIP events on the library's launch stream
     barrier()
     wall = time.perf_counter() - t0
     iters, trials = ctx.batch_counts()              # per step (every step restarts from the uploaded state)
-    # the Jacobian assembly on its own (one linearisation + normal-equation assembly per problem and launch), rank 0's GPU
-    asm_ms = ctx.batch_assemble_timed(5) / 5
     infos = [ctx.problem_info(b) for b in range(args.batch)]
     alg_bytes = sum(i[0] for i in infos)
     _, counts = infos[0]
@@ -116,25 +211,35 @@ def main():
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     wall_t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([iters, trials, args.batch], dtype=torch.float64, device=red_dev)
+    devs = torch.zeros(max(world, 1), dtype=torch.float64, device=red_dev)
+    devs[rank] = 1.0 + local_rank                   # which device every rank computed on
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(devs, op=dist.ReduceOp.SUM)
     wall = float(wall_t.item())
     g_iters, g_trials, g_problems = (float(v) for v in tot.tolist())
+    n_gpus = len(set(int(v) for v in devs.tolist()))   # distinct devices behind the ranks the collective saw
 
     if rank == 0:
-        # HBM traffic per launch measured with rocprofv3 PMC passes for exactly this configuration (profiles/r01/traffic.json)
-        traffic = None
-        traffic_asm = None
+        # HBM traffic per launch: rocprofv3 PMC passes of exactly this configuration, carried with their provenance and dropped when the
+        # device code has changed since (profiles/<round>/traffic.json; tools/profile_bench.sh regenerates it)
+        traffic = traffic_asm = None
+        traffic_source = "none: no PMC pass recorded for this configuration"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))
             key = f"{args.config}_B{args.batch}"
-            if key in tj:
-                traffic = tj[key]["bytes_per_launch"]
-            if key + "_assembly" in tj:
-                traffic_asm = tj[key + "_assembly"]["bytes_per_launch"]
-        except Exception:
-            traffic = None
+            src_hash = kernel_source_hash()
+            if tj.get("kernel_source_hash") != src_hash:
+                traffic_source = (f"stale: profiles/{PROFILE_ROUND}/traffic.json was measured on device code {tj.get('kernel_source_hash')}, this build is {src_hash}")
+            else:
+                if key in tj:
+                    traffic = tj[key]["bytes_per_launch"]
+                if key + "_assembly" in tj:
+                    traffic_asm = tj[key + "_assembly"]["bytes_per_launch"]
+                traffic_source = f"profiles/{PROFILE_ROUND}/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes; device code {src_hash}, commit {tj.get('commit')})"
+        except Exception as e:  # noqa: BLE001
+            traffic_source = f"none: {type(e).__name__}"
         ms_per_step = 1e3 * wall / args.steps
         value = g_iters * args.steps / wall
         kern_ms = kernel_ms / args.steps            # avg duration of the persistent kernel (rank 0)
@@ -154,26 +259,21 @@ def main():
         hbm_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "SfT GN iters/sec (500-node mesh, 1k matches)", "value": value, "unit": "iters/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: single-frame SfT, {rows * cols}-node template ({rows}x{cols}), {m} matches, 640x480",
                        "problems_per_gpu": args.batch, "parallelism": f"{world} x independent problems (no collective)",
-                       "max_lm_iters": 50, "regularisers": [synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP],
-                       "wavefronts_per_problem": int(counts[7])},
+                       "max_lm_iters": 50, "regularisers": list(regs), "wavefronts_per_problem": int(counts[7]), "ranks": world},
             "frames_per_s": g_problems * args.steps / wall,
             "lm_trials_per_s": g_trials * args.steps / wall,
             "iters_per_frame": g_iters / g_problems,
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                         "traffic": traffic, "kernel": "sft_lm_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "sft_lm_kernel", "kernel_ms": kern_ms,
+                         "timing": "HIP events recorded by bench.py on dsh_stream() around the K launches of the product library",
                          "algorithmic_flops_per_launch": flops_per_launch, "flops_per_lm_trial": flops_trial, "dim": Dn + 6, "half_bandwidth": kd,
                          "hbm_assembly": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                                           "algorithmic_bytes_per_launch": bytes_per_launch,
                                           "measured_traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None},
-                         # the same assembly bytes over launches that do nothing but one linearisation + assembly per problem
-                         "hbm_assembly_isolated": {"achieved": alg_bytes / (asm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": alg_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_pass": asm_ms,
-                                                   "algorithmic_bytes_per_pass": alg_bytes, "traffic": traffic_asm,
-                                                   "measured_traffic_GBps": (traffic_asm / (asm_ms * 1e-3) / 1e9) if traffic_asm else None},
                          # what THIS algorithm has to stream per launch: assembly bytes + per damping trial the H tiles read once,
                          # L written once by the factorisation and read once by the back substitution
                          "hbm_solver_stream": {"achieved": (bytes_per_launch + stream_bytes) / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -182,13 +282,32 @@ def main():
                          "note": "one persistent kernel = residuals + Jacobian assembly + banded-arrowhead Cholesky (FP64 MFMA) + LM control; "
                                  "frac = algorithmic solve flops / FP64 peak over the WHOLE kernel time; hbm_assembly = SURVEY 8d assembly bytes over the same time"},
         }
-        # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
-        ctx.batch_upload(frames[:1], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
-        ctx.batch_run()
-        ctx.synchronize()
-        ms1 = ctx.batch_run_timed(5) / 5
-        it1, tr1 = ctx.batch_counts()
-        out["latency"] = {"single_problem_iters_per_s": it1 / (ms1 * 1e-3), "ms_per_frame": ms1, "iters": it1, "trials": tr1}
+        if not args.no_extra_legs:
+            # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
+            ctx.batch_upload(frames[:1], *regs, 1, 50)
+            ctx.batch_run()
+            ctx.synchronize()
+            ms1 = ctx.batch_run_timed(5) / 5
+            it1, tr1 = ctx.batch_counts()
+            out["latency"] = {"single_problem_iters_per_s": it1 / (ms1 * 1e-3), "ms_per_frame": ms1, "iters": it1, "trials": tr1,
+                              "what": "kernel only, inputs resident (HIP events); the end-to-end frame is in `e2e`"}
+            if args.config == "C2":
+                out["e2e"] = e2e_legs(ctx, tmpl, m, frames, regs)
+            # the Jacobian assembly on its own: launches that do one linearisation + normal-equation assembly per problem (measurement
+            # kernel of the LAB build, same device functions as the product kernel), rank 0's GPU
+            ctx.close()
+            lab = sft.Context(local_rank, lab=True)
+            lab.template_build(tmpl.xyz0, tmpl.facets)
+            lab.batch_upload(frames, *regs, 1, 50)
+            lab.batch_run()
+            lab.synchronize()
+            asm_ms = lab.batch_assemble_timed(5) / 5
+            lab.close()
+            out["roofline"]["hbm_assembly_isolated"] = {
+                "achieved": alg_bytes / (asm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms_per_pass": asm_ms, "algorithmic_bytes_per_pass": alg_bytes, "traffic": traffic_asm, "traffic_source": traffic_source,
+                "measured_traffic_GBps": (traffic_asm / (asm_ms * 1e-3) / 1e9) if traffic_asm else None,
+                "library": "libdefslam_hip_lab.so (dsh_lab_sft_assemble_timed -> sft_assembly_kernel)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tmpl, m, args.cpu_seconds)
         print(json.dumps(out))

@@ -1,6 +1,7 @@
-"""ctypes binding of libdefslam_hip.so (the C ABI in include/defslam_hip.h).
+"""ctypes binding of libdefslam_hip.so (the C ABI in include/defslam_hip.h) and of the lab build
+libdefslam_hip_lab.so (the same ABI + include/defslam_hip_debug.h: test hooks, timers, A/B solver switches).
 
-The library is built in-tree by `__graft_entry__.build()` / `make -C defslam_amd/csrc`.
+Both are built in-tree by `__graft_entry__.build()` / `make -C defslam_amd/csrc`.
 There is no CPU fallback: if the shared object is missing, importing a symbol raises.
 """
 from __future__ import annotations
@@ -11,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSH_LIB_PATH: development override to A/B two builds of the same library on one GPU box
 LIB_PATH = os.environ.get("DSH_LIB_PATH") or os.path.join(_HERE, "lib", "libdefslam_hip.so")
+LAB_LIB_PATH = os.environ.get("DSH_LAB_LIB_PATH") or os.path.join(_HERE, "lib", "libdefslam_hip_lab.so")
 
 DSH_OK = 0
 DSH_TRACE_STRIDE = 8
@@ -74,24 +76,41 @@ EXPORTED_SYMBOLS = [
     "dsh_create", "dsh_destroy", "dsh_last_error", "dsh_stream", "dsh_synchronize",
     "dsh_template_build", "dsh_template_set", "dsh_template_dims", "dsh_template_get", "dsh_template_embed",
     "dsh_sft_solve", "dsh_sft_batch_upload", "dsh_sft_batch_run", "dsh_sft_batch_download",
-    "dsh_sft_batch_run_timed", "dsh_sft_batch_assemble_timed", "dsh_sft_batch_phase_ms", "dsh_sft_batch_counts", "dsh_sft_batch_problem_info", "dsh_sft_debug_system",
+    "dsh_sft_batch_counts", "dsh_sft_batch_problem_info",
     "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit",
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
     "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
 ]
 
+# include/defslam_hip_debug.h: only libdefslam_hip_lab.so exports these
+LAB_SYMBOLS = ["dsh_lab_set_option", "dsh_lab_sft_run_timed", "dsh_lab_sft_assemble_timed", "dsh_lab_sft_phase_ms", "dsh_lab_sft_step_trace",
+               "dsh_lab_sft_system"]
+
 _lib = None
+_lab = None
 
 
 def load() -> C.CDLL:
-    """Load the HIP library; raises OSError when it has not been built (no fallback)."""
+    """Load the product library; raises OSError when it has not been built (no fallback)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    if _lib is None:
+        _lib = _bind(LIB_PATH, lab=False)
+    return _lib
+
+
+def load_lab() -> C.CDLL:
+    """Load the lab build (product ABI + the measurement / debugging entry points)."""
+    global _lab
+    if _lab is None:
+        _lab = _bind(LAB_LIB_PATH, lab=True)
+    return _lab
+
+
+def _bind(path: str, lab: bool) -> C.CDLL:
+    if not os.path.exists(path):
+        raise OSError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"(or `make -C defslam_amd/csrc`). There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.dsh_create.argtypes = [C.POINTER(vp), C.c_int]
     L.dsh_destroy.argtypes = [vp]
@@ -109,13 +128,9 @@ def load() -> C.CDLL:
     L.dsh_sft_solve.argtypes = [vp, C.POINTER(SftFrameC), C.POINTER(SftResultC)]
     L.dsh_sft_batch_upload.argtypes = [vp, C.c_int, C.POINTER(SftFrameC)]
     L.dsh_sft_batch_run.argtypes = [vp]
-    L.dsh_sft_batch_run_timed.argtypes = [vp, C.c_int, c_double_p]
-    L.dsh_sft_batch_assemble_timed.argtypes = [vp, C.c_int, c_double_p]
-    L.dsh_sft_batch_phase_ms.argtypes = [vp, C.c_int, c_double_p]
     L.dsh_sft_batch_download.argtypes = [vp, C.c_int, C.POINTER(SftResultC)]
     L.dsh_sft_batch_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.dsh_sft_batch_problem_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), c_i32_p]
-    L.dsh_sft_debug_system.argtypes = [vp, C.c_int, C.c_int32, c_double_p, c_double_p, c_double_p]
     L.dsh_bbs_eval.argtypes = [vp, C.POINTER(BbsC), c_double_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, c_double_p, c_u8_p]
     L.dsh_bbs_coloc.argtypes = [vp, C.POINTER(BbsC), c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, c_i32_p, c_double_p, c_i32_p]
     L.dsh_normals_estimate.argtypes = [vp, C.c_int, c_i32_p, c_float_p, c_u8_p, c_float_p, c_u8_p, c_float_p, c_u8_p, c_float_p,
@@ -140,5 +155,47 @@ def load() -> C.CDLL:
         fn = getattr(L, name)
         if name not in ("dsh_last_error", "dsh_stream"):
             fn.restype = C.c_int
-    _lib = L
+    if lab:
+        L.dsh_lab_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        L.dsh_lab_sft_run_timed.argtypes = [vp, C.c_int, c_double_p]
+        L.dsh_lab_sft_assemble_timed.argtypes = [vp, C.c_int, c_double_p]
+        L.dsh_lab_sft_phase_ms.argtypes = [vp, C.c_int, c_double_p]
+        L.dsh_lab_sft_step_trace.argtypes = [vp, C.c_int, c_double_p]
+        L.dsh_lab_sft_system.argtypes = [vp, C.c_int, C.c_int32, c_double_p, c_double_p, c_double_p]
+        for name in LAB_SYMBOLS:
+            getattr(L, name).restype = C.c_int
     return L
+
+
+class HipEvents:
+    """Two HIP events on a caller-chosen stream (libamdhip64 through ctypes): how bench.py times the launches of the
+    PRODUCT library on the stream it launches on (dsh_stream) without any timing entry point in the ABI."""
+
+    def __init__(self):
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self._hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self._hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self._hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self._hip.hipEventDestroy.argtypes = [C.c_void_p]
+        self.e0, self.e1 = C.c_void_p(), C.c_void_p()
+        for e in (self.e0, self.e1):
+            if self._hip.hipEventCreate(C.byref(e)) != 0:
+                raise OSError("hipEventCreate failed")
+
+    def start(self, stream: int):
+        if self._hip.hipEventRecord(self.e0, C.c_void_p(stream)) != 0:
+            raise OSError("hipEventRecord failed")
+
+    def stop_ms(self, stream: int) -> float:
+        ms = C.c_float()
+        if (self._hip.hipEventRecord(self.e1, C.c_void_p(stream)) != 0 or self._hip.hipEventSynchronize(self.e1) != 0
+                or self._hip.hipEventElapsedTime(C.byref(ms), self.e0, self.e1) != 0):
+            raise OSError("HIP event timing failed")
+        return float(ms.value)
+
+    def close(self):
+        for e in (self.e0, self.e1):
+            if e:
+                self._hip.hipEventDestroy(e)
+        self.e0 = self.e1 = None

@@ -15,11 +15,15 @@
 #include "dsh_template.h"
 #include "sft_problem.h"
 
-extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
-extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
+#ifdef DSH_LAB
+#include "../../include/defslam_hip_debug.h"
+#endif
+
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
-// dense build of the same kernels (sft_kernels_dense.hip): 128 VGPRs per wave, two 8-wavefront problems per CU
-extern "C" hipError_t sft_lm_launch_dense(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
+#ifdef DSH_LAB
+extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
+#endif
 
 namespace {
 
@@ -93,6 +97,34 @@ struct Packed {
   std::vector<int32_t> actnode; // compact index -> node
 };
 
+// Host buffer of a context that the copy engine reads / writes directly: page-locked for a GPU context (hipMemcpyAsync
+// from pageable memory is staged and synchronous), plain memory for a host-only one.  Grow-only.
+struct HostBuf {
+  char* p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  hipError_t ensure(size_t bytes, bool want_pinned) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (want_pinned) {
+      const hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+      if (e != hipSuccess) { p = nullptr; return e; }
+      pinned = true;
+    } else {
+      p = static_cast<char*>(std::malloc(want));
+      if (!p) return hipErrorOutOfMemory;
+      pinned = false;
+    }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+    p = nullptr; cap = 0;
+  }
+};
+
 struct Arena {  // byte layout of a device allocation, 256-byte aligned slices
   size_t size = 0;
   size_t take(size_t bytes) {
@@ -122,14 +154,23 @@ struct dsh_ctx : dsh_ctx_base {
   size_t d_batch_cap = 0;
   SftDev* d_probs = nullptr;       // inside d_batch
   std::vector<SftDev> h_probs;     // host mirror with device pointers
-  std::vector<char> stage;         // host staging of the read-only part
+  HostBuf stage;                   // page-locked staging of the read-only part (one hipMemcpyAsync per upload)
+  hipEvent_t stage_free = nullptr; // recorded behind the upload copy: the staging buffer may be refilled once it has fired
+  bool stage_busy = false;
+  HostBuf results;                 // page-locked landing zone of the result region (one hipMemcpyAsync per download)
   size_t ro_bytes = 0;             // leading read-only bytes of d_batch (uploaded)
+  size_t res_off = 0, res_bytes = 0;            // result region of d_batch: B headers (SftResHdr), then the bodies
+  struct ResOffs { size_t xyz, chi2, trace, mp, outl; };   // offsets inside the result region
+  std::vector<ResOffs> res_offs;
   int max_kd = 0;
   size_t jl_doubles = 0;
   int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
-  bool dense = false; // 8 wavefronts at 128 VGPRs: two problems share a CU (dense build of the kernels)
+  size_t lds_configured[2] = {0, 0};   // dynamic LDS size the two launch shapes were last enabled for on THIS device
   int num_cus = 256;
   bool ran = false;
+  // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
+  // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; } opt;
 };
 
 namespace {
@@ -182,7 +223,7 @@ int upload_template(dsh_ctx* c) {
 }
 
 // Build the graph of DefOptimizer.cc:293-507 as flat arrays + per-block gather lists.
-int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, std::string& err) {
+int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, bool wide_off, Packed& P, std::string& err) {
   const int n = t.n, M = f.M;
   if (M <= 0 || !f.obs_nodes || !f.obs_bary || !f.obs_uv || !f.obs_invsig2 || !f.xyz || !f.Tcw) { err = "empty or null frame"; return DSH_ERR_ARG; }
   if (f.n_frame <= 0 || f.max_iters < 0 || f.max_iters > DSH_MAX_ITERS) { err = "bad n_frame/max_iters"; return DSH_ERR_ARG; }
@@ -319,15 +360,12 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
   }
   SftDev& h = P.h;
   h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
-  // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; DSH_SFT_WIDE_OFF=1 keeps the
-  // row-major band solver for A/B runs), row-major band otherwise
-  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : ((h.kd <= kTS * kWB && !std::getenv("DSH_SFT_WIDE_OFF")) ? 2 : 0);
+  // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; the lab option "wide_off"
+  // keeps the row-major band solver for A/B runs), row-major band otherwise
+  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : ((h.kd <= kTS * kWB && !wide_off) ? 2 : 0);
   h.wbt = h.tile_mode == 1 ? kBT : (h.tile_mode == 2 ? (h.kd + kTS - 1) / kTS : 0);
   h.tpr = h.tile_mode ? h.wbt + 1 : 0;
   h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
-#ifdef SFT_EXPERIMENTS
-  if (const char* dm = std::getenv("DSH_EXPERIMENT")) h.mode = std::atoi(dm) & ~1;  // tuning builds only: phases switched off, results invalid
-#endif
   h.fx = f.K[0]; h.fy = f.K[1]; h.cx = f.K[2]; h.cy = f.K[3];
   h.w_ref = f.reg_temp / std::pow(t.median_L, 2);              // DefOptimizer.cc:378
   h.w_curv = f.reg_lap / (double)nA;                           // :458  (|OptLap|)
@@ -365,11 +403,10 @@ int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, Packed& P, 
 }
 
 template <class T>
-size_t put(std::vector<char>& st, Arena& a, const std::vector<T>& v) {
-  const size_t off = a.take(sizeof(T) * v.size());
-  if (st.size() < a.size) st.resize(a.size);
-  if (!v.empty()) std::memcpy(&st[off], v.data(), sizeof(T) * v.size());
-  return off;
+size_t reserve(Arena& a, const std::vector<T>& v) { return a.take(sizeof(T) * v.size()); }
+template <class T>
+void put(char* st, size_t off, const std::vector<T>& v) {
+  if (!v.empty()) std::memcpy(st + off, v.data(), sizeof(T) * v.size());
 }
 
 }  // namespace
@@ -395,6 +432,11 @@ int dsh_create(dsh_ctx** out, int device) {
     delete c;
     return DSH_ERR_HIP;
   }
+  if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DSH_ERR_HIP;
+  }
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
   *out = c;
@@ -403,9 +445,12 @@ int dsh_create(dsh_ctx** out, int device) {
 
 int dsh_destroy(dsh_ctx* c) {
   if (!c) return DSH_ERR_ARG;
-  if (c->host_only) { delete c; return DSH_OK; }
+  if (c->host_only) { c->stage.release(); c->results.release(); delete c; return DSH_OK; }
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->stage_free) (void)hipEventDestroy(c->stage_free);
+  c->stage.release();
+  c->results.release();
   if (c->d_tmpl) (void)hipFree(c->d_tmpl);
   c->scratch.release();
   if (c->d_batch) (void)hipFree(c->d_batch);
@@ -434,6 +479,18 @@ int dsh_template_build(dsh_ctx* c, int n, const double* xyz0, int F, const int32
 int dsh_template_set(dsh_ctx* c, int n, const double* xyz0, const uint8_t* boundary, const int32_t* rp, const int32_t* col, const double* w,
                      const double* k0, int E, const int32_t* en, const double* eL, double median_L) {
   if (!c || n <= 0 || E < 0 || !xyz0 || !boundary || !rp || !col || !w || !k0 || !en || !eL) return fail(c, DSH_ERR_ARG, "dsh_template_set: bad argument");
+  // The arrays become indices of the packer (inc[edge_nodes[..]], opt[nbr_col[..]]): a malformed CSR or edge list must be
+  // refused here, not turn into an out-of-bounds write later.
+  if (rp[0] != 0) return fail(c, DSH_ERR_ARG, "dsh_template_set: nbr_rowptr[0] != 0");
+  for (int i = 0; i < n; i++)
+    if (rp[i + 1] < rp[i]) return fail(c, DSH_ERR_ARG, "dsh_template_set: nbr_rowptr is not non-decreasing");
+  for (int p = 0; p < rp[n]; p++)
+    if (col[p] < 0 || col[p] >= n) return fail(c, DSH_ERR_ARG, "dsh_template_set: neighbour index out of range");
+  for (int e = 0; e < E; e++) {
+    if (en[2 * e] < 0 || en[2 * e] >= n || en[2 * e + 1] < 0 || en[2 * e + 1] >= n) return fail(c, DSH_ERR_ARG, "dsh_template_set: edge node out of range");
+    if (!(eL[e] > 0.0)) return fail(c, DSH_ERR_ARG, "dsh_template_set: edge rest length must be positive");
+  }
+  if (!(median_L > 0.0)) return fail(c, DSH_ERR_ARG, "dsh_template_set: median edge length must be positive");
   if (!c->host_only) (void)hipSetDevice(c->device);
   c->tmpl.set(n, xyz0, boundary, rp, col, w, k0, E, en, eL, median_L);
   return upload_template(c);
@@ -506,10 +563,11 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   if (!c->tmpl.valid) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_upload: no template");
   if (!c->host_only) (void)hipSetDevice(c->device);
   c->B = 0;
+  c->ran = false;
   c->packed.assign(B, Packed());
   for (int b = 0; b < B; b++) {
     std::string e;
-    const int rc = pack_problem(c->tmpl, frames[b], c->packed[b], e);
+    const int rc = pack_problem(c->tmpl, frames[b], c->opt.wide_off != 0, c->packed[b], e);
     if (rc != DSH_OK) return fail(c, rc, "problem " + std::to_string(b) + ": " + e);
   }
   if (c->host_only) {  // packed on the host only; dsh_sft_batch_problem_info works, running does not
@@ -518,27 +576,35 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     c->B = B;
     return DSH_OK;
   }
-  // ---- layout: [SftDev table][read-only arrays of every problem] | [workspace of every problem]
+  // ---- layout: [SftDev table][read-only arrays of every problem] | [result region: B headers, bodies] | [workspace]
   Arena a;
-  std::vector<char>& st = c->stage;
-  st.clear();
   const size_t o_tab = a.take(sizeof(SftDev) * B);
-  st.resize(a.size);
   struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, hdr, tmask, cfac, xyz_init, pose_init; };
   std::vector<Offs> ro(B);
   for (int b = 0; b < B; b++) {
     Packed& P = c->packed[b];
     Offs& o = ro[b];
-    o.act = put(st, a, P.act); o.obs_nodes = put(st, a, P.obs_nodes); o.obs_bary = put(st, a, P.obs_bary); o.obs_uv = put(st, a, P.obs_uv);
-    o.obs_w = put(st, a, P.obs_w); o.ref = put(st, a, P.ref_node); o.star = put(st, a, P.star_node); o.sL = put(st, a, P.star_sL);
-    o.strn = put(st, a, P.str_nodes); o.strL = put(st, a, P.str_L0); o.rc = put(st, a, P.blk_rc); o.ptr = put(st, a, P.blk_ptr);
-    o.dblk = put(st, a, P.diag_blk); o.oblk = put(st, a, P.off_blk);
-    o.contrib = put(st, a, P.contrib); o.hdr = put(st, a, P.blk_hdr); o.tmask = put(st, a, P.tmask); o.cfac = put(st, a, P.cfac); o.xyz_init = put(st, a, P.xyz_init);
-    std::vector<double> pi(P.pose_init, P.pose_init + 7);
-    o.pose_init = put(st, a, pi);
+    o.act = reserve(a, P.act); o.obs_nodes = reserve(a, P.obs_nodes); o.obs_bary = reserve(a, P.obs_bary); o.obs_uv = reserve(a, P.obs_uv);
+    o.obs_w = reserve(a, P.obs_w); o.ref = reserve(a, P.ref_node); o.star = reserve(a, P.star_node); o.sL = reserve(a, P.star_sL);
+    o.strn = reserve(a, P.str_nodes); o.strL = reserve(a, P.str_L0); o.rc = reserve(a, P.blk_rc); o.ptr = reserve(a, P.blk_ptr);
+    o.dblk = reserve(a, P.diag_blk); o.oblk = reserve(a, P.off_blk);
+    o.contrib = reserve(a, P.contrib); o.hdr = reserve(a, P.blk_hdr); o.tmask = reserve(a, P.tmask); o.cfac = reserve(a, P.cfac); o.xyz_init = reserve(a, P.xyz_init);
+    o.pose_init = a.take(8 * 8);
   }
   c->ro_bytes = a.size;
-  struct WOffs { size_t xyz, bak, pose, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, chi2, ferr, trace, info, dbg; };
+  // result region: every header first (dsh_sft_batch_counts reads only them), then the bodies
+  c->res_off = a.size;
+  (void)a.take(sizeof(SftResHdr) * (size_t)B);
+  c->res_offs.resize(B);
+  for (int b = 0; b < B; b++) {
+    const SftDev& h = c->packed[b].h;
+    dsh_ctx::ResOffs& r = c->res_offs[b];
+    r.xyz = a.take(8 * 3 * (size_t)h.n) - c->res_off; r.chi2 = a.take(8 * (size_t)h.M) - c->res_off;
+    r.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS) - c->res_off;
+    r.mp = a.take(4 * 3 * (size_t)h.M) - c->res_off; r.outl = a.take((size_t)h.M) - c->res_off;
+  }
+  c->res_bytes = a.size - c->res_off;
+  struct WOffs { size_t bak, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg; };
   std::vector<WOffs> wo(B);
   int max_kd = 0;
   size_t jl_doubles = 0;
@@ -549,36 +615,25 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     bool all_tiles = true;
     for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode == 1;
     if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
-    if (const char* e = std::getenv("DSH_SFT_WAVES")) {
-      const int v = std::atoi(e);
-      if ((v == 4 && all_tiles) || v == 8) nw = v;
-    }
+    if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
   }
-  // tile mode: barrier-free (dataflow) factor steps unless DSH_SFT_DATAFLOW=0 asks for the barrier version (A/B tests)
-  {
-    bool dataflow = true;
-    if (const char* e = std::getenv("DSH_SFT_DATAFLOW")) dataflow = std::atoi(e) != 0;
-    for (int b = 0; b < B; b++) {
-      SftDev& hh = c->packed[b].h;
-      hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && dataflow) ? 2 : 0);
-    }
+  for (int b = 0; b < B; b++) {   // tile mode: barrier-free (dataflow) factor steps; the barrier version exists in lab builds only
+    SftDev& hh = c->packed[b].h;
+    hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);
   }
-  bool dense = false;
-  if (const char* e = std::getenv("DSH_SFT_DENSE")) dense = std::atoi(e) != 0 && nw == 8;
-  if (dense)
-    for (int b = 0; b < B; b++) dense = dense && c->packed[b].h.tile_mode == 1;
-  const size_t jl_cap = ((nw == 4 || dense) ? 72 : 96) * 1024;
+  const size_t jl_cap = (nw == 4 ? 72 : 96) * 1024;
   for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to the solver workspace
     SftDev& hh = c->packed[b].h;
     const size_t need = 4 * ((size_t)hh.S + hh.Es + hh.V);
     hh.jl_lds = (need * 8 <= jl_cap) ? 1 : 0;
     if (hh.jl_lds) jl_doubles = std::max(jl_doubles, need);
   }
+  const size_t ws_off = a.size;
   for (int b = 0; b < B; b++) {
     const SftDev& h = c->packed[b].h;
     const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
     WOffs& w = wo[b];
-    w.xyz = a.take(8 * 3 * (size_t)h.n); w.bak = a.take(8 * 3 * (size_t)h.n); w.pose = a.take(8 * 8);
+    w.bak = a.take(8 * 3 * (size_t)h.n);
     w.Jobs = a.take(8 * (size_t)h.M * SFT_JOBS_STRIDE); w.Jstar = a.take(8 * 4 * (size_t)h.S); w.Jstr = a.take(8 * 4 * (size_t)h.Es); w.Jref = a.take(8 * 4 * (size_t)h.V);
     // tile mode: BT+1 zero tile rows below the matrix and an 8th (zero) border row + one window of columns let the
     // factorisation load every tile of its sliding window unconditionally (SFT_H_PAD_* in sft_problem.h)
@@ -588,23 +643,38 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * bord_elems); w.Lc = a.take(8 * 56);
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.Lt = a.take(h.tile_mode == 2 ? 8 * band_elems : 0); w.LbT = a.take(h.tile_mode == 2 ? 8 * (Dnp / kTS) * (size_t)kTS * kTS : 0);
-    w.x = a.take(8 * (Dnp + 8)); w.chi2 = a.take(8 * (size_t)h.M); w.ferr = a.take(8 * (size_t)h.M);
-    w.trace = a.take(8 * DSH_TRACE_STRIDE * DSH_MAX_ITERS); w.info = a.take(64); w.dbg = a.take(1024);
+    w.x = a.take(8 * (Dnp + 8)); w.dbg = a.take(1024);
     max_kd = std::max(max_kd, h.kd);
   }
   if (sft_lm_kernel_lds_bytes(max_kd, jl_doubles) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
     return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel / workgroup");
+  bool fresh_arena = false;
   if (a.size > c->d_batch_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->d_batch) { (void)hipFree(c->d_batch); c->d_batch = nullptr; c->d_batch_cap = 0; }
     HIPCHK(c, hipMalloc((void**)&c->d_batch, a.size));
     c->d_batch_cap = a.size;
+    fresh_arena = true;
   }
+  // the staging buffer of the previous upload may still be read by its copy
+  if (c->stage_busy) { HIPCHK(c, hipEventSynchronize(c->stage_free)); c->stage_busy = false; }
+  HIPCHK(c, c->stage.ensure(c->ro_bytes, true));
+  char* st = c->stage.p;
   char* base = c->d_batch;
   c->h_probs.resize(B);
+  SftResHdr* d_hdr = (SftResHdr*)(base + c->res_off);
   for (int b = 0; b < B; b++) {
-    SftDev h = c->packed[b].h;
+    Packed& P = c->packed[b];
     const Offs& o = ro[b];
+    put(st, o.act, P.act); put(st, o.obs_nodes, P.obs_nodes); put(st, o.obs_bary, P.obs_bary); put(st, o.obs_uv, P.obs_uv); put(st, o.obs_w, P.obs_w);
+    put(st, o.ref, P.ref_node); put(st, o.star, P.star_node); put(st, o.sL, P.star_sL); put(st, o.strn, P.str_nodes); put(st, o.strL, P.str_L0);
+    put(st, o.rc, P.blk_rc); put(st, o.ptr, P.blk_ptr); put(st, o.dblk, P.diag_blk); put(st, o.oblk, P.off_blk); put(st, o.contrib, P.contrib);
+    put(st, o.hdr, P.blk_hdr); put(st, o.tmask, P.tmask); put(st, o.cfac, P.cfac); put(st, o.xyz_init, P.xyz_init);
+    std::memcpy(st + o.pose_init, P.pose_init, 7 * sizeof(double));
+    SftDev h = P.h;
     const WOffs& w = wo[b];
+    const dsh_ctx::ResOffs& r = c->res_offs[b];
+    char* rbase = base + c->res_off;
     h.xyz0 = c->dt.xyz0; h.nbr_ptr = c->dt.nbr_ptr; h.nbr_idx = c->dt.nbr_idx; h.nbr_w = c->dt.nbr_w; h.nbr_c = c->dt.nbr_c; h.nbr_sumw = c->dt.nbr_sumw; h.k0 = c->dt.k0;
     h.act = (const int32_t*)(base + o.act); h.obs_nodes = (const int32_t*)(base + o.obs_nodes); h.obs_bary = (const double*)(base + o.obs_bary);
     h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w); h.ref_node = (const int32_t*)(base + o.ref);
@@ -612,27 +682,33 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.str_L0 = (const double*)(base + o.strL); h.blk_rc = (const int32_t*)(base + o.rc); h.blk_ptr = (const int32_t*)(base + o.ptr);
     h.diag_blk = (const int32_t*)(base + o.dblk); h.off_blk = (const int32_t*)(base + o.oblk);
     h.contrib = (const uint32_t*)(base + o.contrib); h.blk_hdr = (const int32_t*)(base + o.hdr); h.tmask = (const int32_t*)(base + o.tmask); h.cfac = (const double*)(base + o.cfac); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
-    h.xyz = (double*)(base + w.xyz); h.xyz_bak = (double*)(base + w.bak); h.pose = (double*)(base + w.pose);
+    h.res = d_hdr + b; h.pose = d_hdr[b].pose;   // address arithmetic on a device pointer: nothing is dereferenced on the host
+    h.xyz = (double*)(rbase + r.xyz); h.chi2_obs = (double*)(rbase + r.chi2); h.trace = (double*)(rbase + r.trace);
+    h.mappoint = (float*)(rbase + r.mp); h.outlier = (uint8_t*)(rbase + r.outl);
+    h.xyz_bak = (double*)(base + w.bak);
     h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
     h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
     h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc); h.Linv = (double*)(base + w.Linv);
     h.Lt = (double*)(base + w.Lt); h.LbT = (double*)(base + w.LbT);
-    h.x = (double*)(base + w.x); h.chi2_obs = (double*)(base + w.chi2); h.final_err = (double*)(base + w.ferr);
-    h.trace = (double*)(base + w.trace); h.info = (int32_t*)(base + w.info); h.dbg = (double*)(base + w.dbg);
+    h.x = (double*)(base + w.x); h.dbg = (double*)(base + w.dbg);
     c->h_probs[b] = h;
   }
-  std::memcpy(&st[o_tab], c->h_probs.data(), sizeof(SftDev) * B);
-  HIPCHK(c, hipMemcpyAsync(base, st.data(), c->ro_bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(base + c->ro_bytes, 0, a.size - c->ro_bytes, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(st + o_tab, c->h_probs.data(), sizeof(SftDev) * B);
+  HIPCHK(c, hipMemcpyAsync(base, st, c->ro_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->stage_free, c->stream));
+  c->stage_busy = true;
+  // The kernel initialises everything it reads (state, H with its zero padding, border, x, counters).  A fresh allocation
+  // is cleared once so that no tile of L / Lt that a masked lane may touch holds a NaN pattern; after that the workspace
+  // only ever holds finite numbers this library wrote.  The result region is always cleared (a caller that downloads
+  // without running gets zeros, not the previous batch).
+  if (fresh_arena) HIPCHK(c, hipMemsetAsync(base + ws_off, 0, a.size - ws_off, c->stream));
+  HIPCHK(c, hipMemsetAsync(base + c->res_off, 0, c->res_bytes, c->stream));
   c->d_probs = (SftDev*)(base + o_tab);
   c->B = B;
   c->max_kd = max_kd;
   c->jl_doubles = jl_doubles;
   c->nw = nw;
-  c->dense = dense;
-  c->ran = false;
-  return DSH_OK;
+  return DSH_OK;   // asynchronous: the launch of dsh_sft_batch_run is ordered behind the copy on the same stream
 }
 
 int dsh_sft_batch_run(dsh_ctx* c) {
@@ -640,72 +716,8 @@ int dsh_sft_batch_run(dsh_ctx* c) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
   (void)hipSetDevice(c->device);
-  HIPCHK(c, (c->dense ? sft_lm_launch_dense : sft_lm_launch)(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
   c->ran = true;
-  return DSH_OK;
-}
-
-int dsh_sft_batch_run_timed(dsh_ctx* c, int launches, double* total_ms) {
-  if (!c || launches <= 0 || !total_ms) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_run_timed: bad argument");
-  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run_timed: host-only context, no GPU (there is no CPU fallback)");
-  if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run_timed: nothing uploaded");
-  (void)hipSetDevice(c->device);
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
-  HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, (c->dense ? sft_lm_launch_dense : sft_lm_launch)(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
-  HIPCHK(c, hipEventRecord(e1, c->stream));
-  HIPCHK(c, hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *total_ms = (double)ms;
-  c->ran = true;
-  return DSH_OK;
-}
-
-int dsh_sft_batch_assemble_timed(dsh_ctx* c, int launches, double* total_ms) {
-  if (!c || launches <= 0 || !total_ms) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_assemble_timed: bad argument");
-  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_assemble_timed: host-only context, no GPU (there is no CPU fallback)");
-  if (c->B <= 0 || !c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_assemble_timed: needs an uploaded batch that has run once");
-  (void)hipSetDevice(c->device);
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
-  HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
-  HIPCHK(c, hipEventRecord(e1, c->stream));
-  HIPCHK(c, hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  *total_ms = ms;
-  c->ran = false;   // results of the last full run are gone (state reset, H reassembled at the initial state)
-  return DSH_OK;
-}
-
-int dsh_sft_batch_phase_ms(dsh_ctx* c, int b, double* out8) {
-  if (!c || !out8 || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_batch_phase_ms: bad argument");
-  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_phase_ms: host-only context");
-  if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_phase_ms: no run");
-  (void)hipSetDevice(c->device);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(out8, c->h_probs[b].dbg, 8 * sizeof(double), hipMemcpyDeviceToHost));
-  if (std::getenv("DSH_STEP_TRACE")) {   // tuning aid: per-wave shader-clock stamps of factorisation step 40 (-DSFT_STEP_TRACE builds)
-    double t[96];
-    HIPCHK(c, hipMemcpy(t, c->h_probs[b].dbg, sizeof(t), hipMemcpyDeviceToHost));
-    double t0 = 1e300;
-    for (int w = 0; w < 8; w++) if (t[16 + 8 * w] > 0 && t[16 + 8 * w] < t0) t0 = t[16 + 8 * w];
-    for (int w = 0; w < 8; w++) {
-      std::printf("wave %d:", w);
-      for (int e = 0; e < 8; e++) std::printf(" %8.0f", t[16 + 8 * w + e] > 0 ? t[16 + 8 * w + e] - (std::getenv("DSH_SFT_DATAFLOW") ? 0.0 : t0) : -1.0);
-      std::printf("\n");
-    }
-  }
-  for (int i = 0; i < 8; i++) out8[i] *= 1e-5;  // 100 MHz ticks -> ms
   return DSH_OK;
 }
 
@@ -713,13 +725,14 @@ int dsh_sft_batch_counts(dsh_ctx* c, int64_t* iters, int64_t* trials) {
   if (!c || c->B <= 0 || !c->ran) return DSH_ERR_STATE;
   if (c->host_only) return DSH_ERR_NO_DEVICE;
   (void)hipSetDevice(c->device);
+  // one copy of the B result headers (they are contiguous), ordered behind the run on the context's stream
+  const size_t bytes = sizeof(SftResHdr) * (size_t)c->B;
+  HIPCHK(c, c->results.ensure(std::max(bytes, c->results.cap), true));
+  HIPCHK(c, hipMemcpyAsync(c->results.p, c->d_batch + c->res_off, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const SftResHdr* hd = reinterpret_cast<const SftResHdr*>(c->results.p);
   int64_t it = 0, tr = 0;
-  for (int b = 0; b < c->B; b++) {
-    int32_t info[4];
-    HIPCHK(c, hipMemcpy(info, c->h_probs[b].info, sizeof(info), hipMemcpyDeviceToHost));
-    it += info[0];
-    tr += info[1];
-  }
+  for (int b = 0; b < c->B; b++) { it += hd[b].iters; tr += hd[b].trials; }
   if (iters) *iters = it;
   if (trials) *trials = tr;
   return DSH_OK;
@@ -743,49 +756,35 @@ int dsh_sft_batch_download(dsh_ctx* c, int B, dsh_sft_result* res) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_download: host-only context");
   if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_download: no run");
   (void)hipSetDevice(c->device);
+  // the whole result region (headers + bodies of every problem) in ONE copy into page-locked memory
+  HIPCHK(c, c->results.ensure(c->res_bytes, true));
+  HIPCHK(c, hipMemcpyAsync(c->results.p, c->d_batch + c->res_off, c->res_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  const char* rb = c->results.p;
+  const SftResHdr* hd = reinterpret_cast<const SftResHdr*>(rb);
   for (int b = 0; b < B; b++) {
     const SftDev& h = c->h_probs[b];
     const Packed& P = c->packed[b];
+    const dsh_ctx::ResOffs& o = c->res_offs[b];
     dsh_sft_result& r = res[b];
-    std::vector<double> xyz(3 * (size_t)h.n), chi2(h.M), ferr(h.M);
-    double pose[8];
-    int32_t info[4];
-    HIPCHK(c, hipMemcpy(xyz.data(), h.xyz, 8 * xyz.size(), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(chi2.data(), h.chi2_obs, 8 * (size_t)h.M, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(ferr.data(), h.final_err, 8 * (size_t)h.M, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(pose, h.pose, 8 * 7, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(info, h.info, sizeof(info), hipMemcpyDeviceToHost));
-    if (r.trace) HIPCHK(c, hipMemcpy(r.trace, h.trace, 8 * DSH_TRACE_STRIDE * (size_t)std::max(P.max_iters, 0), hipMemcpyDeviceToHost));
-    // classification + statistics exactly as DefOptimizer.cc:515-559 (float chi2, sequential sums)
-    int nbad = 0;
-    double sum = 0.0;
-    unsigned cnt = 0;
-    for (int m = 0; m < h.M; m++) {
-      const float cf = (float)chi2[m];
-      const bool bad = cf > 5.991;
-      if (r.outlier) r.outlier[m] = bad ? 1 : 0;
-      if (bad) nbad++;
-      else { sum += ferr[m]; cnt++; }
-    }
-    r.rep_error = sum / cnt;
-    r.inliers = h.M - nbad;
-    r.iters = info[0];
-    r.trials = info[1];
-    r.status = info[2];
+    r.rep_error = hd[b].rep_error;
+    r.inliers = hd[b].inliers;
+    r.iters = hd[b].iters;
+    r.trials = hd[b].trials;
+    r.status = hd[b].status;
     r.dim = 6 + h.Dn;
     r.half_bandwidth = h.kd;
-    if (r.chi2_obs) std::memcpy(r.chi2_obs, chi2.data(), 8 * (size_t)h.M);
-    if (r.xyz) std::memcpy(r.xyz, xyz.data(), 8 * xyz.size());
-    if (r.pose7) std::memcpy(r.pose7, pose, 8 * 7);
-    if (r.Tcw) Tcw_from_pose7(pose, r.Tcw);
-    if (r.mappoint_xyz)  // DefMapPoint::RecalculatePosition (DefMapPoint.cc:129-147)
-      for (int m = 0; m < h.M; m++)
-        for (int k = 0; k < 3; k++) {
-          const int32_t* nd = &P.obs_nodes[3 * m];
-          const double* bb = &P.obs_bary[3 * m];
-          r.mappoint_xyz[3 * m + k] = (float)(bb[0] * xyz[3 * nd[0] + k] + bb[1] * xyz[3 * nd[1] + k] + bb[2] * xyz[3 * nd[2] + k]);
-        }
+    if (r.chi2_obs) std::memcpy(r.chi2_obs, rb + o.chi2, 8 * (size_t)h.M);
+    if (r.outlier) std::memcpy(r.outlier, rb + o.outl, (size_t)h.M);
+    if (r.xyz) std::memcpy(r.xyz, rb + o.xyz, 8 * 3 * (size_t)h.n);
+    if (r.pose7) std::memcpy(r.pose7, hd[b].pose, 8 * 7);
+    if (r.Tcw) Tcw_from_pose7(hd[b].pose, r.Tcw);
+    if (r.mappoint_xyz) std::memcpy(r.mappoint_xyz, rb + o.mp, 4 * 3 * (size_t)h.M);
+    if (r.trace) {   // rows of the executed iterations, zeros behind them
+      const size_t rows = (size_t)std::max(P.max_iters, 0), done = std::min(rows, (size_t)std::max(hd[b].iters, 0));
+      std::memcpy(r.trace, rb + o.trace, 8 * DSH_TRACE_STRIDE * done);
+      std::memset(r.trace + DSH_TRACE_STRIDE * done, 0, 8 * DSH_TRACE_STRIDE * (rows - done));
+    }
   }
   return DSH_OK;
 }
@@ -799,18 +798,105 @@ int dsh_sft_solve(dsh_ctx* c, const dsh_sft_frame* frame, dsh_sft_result* result
   return dsh_sft_batch_download(c, 1, result);
 }
 
-int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, double* chi2) {
-  if (!c || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: bad argument");
-  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_debug_system: host-only context");
+#ifdef DSH_LAB
+// ---- lab entry points (include/defslam_hip_debug.h): libdefslam_hip_lab.so only ----------------------------------------
+namespace {
+struct EventPair {   // destroyed on every path
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t create() { hipError_t e = hipEventCreate(&e0); return e != hipSuccess ? e : hipEventCreate(&e1); }
+  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+}  // namespace
+
+int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
+  if (!c || !name) return DSH_ERR_ARG;
+  const std::string k(name);
+  if (k == "waves") { if (value != 0 && value != 4 && value != 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: waves is 0 (automatic), 4 or 8"); c->opt.waves = value; }
+  else if (k == "dataflow") c->opt.dataflow = value != 0;
+  else if (k == "wide_off") c->opt.wide_off = value != 0;
+  else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
+  return DSH_OK;
+}
+
+int dsh_lab_sft_run_timed(dsh_ctx* c, int launches, double* total_ms) {
+  if (!c || launches <= 0 || !total_ms) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_run_timed: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_run_timed: host-only context, no GPU (there is no CPU fallback)");
+  if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_run_timed: nothing uploaded");
   (void)hipSetDevice(c->device);
+  EventPair ev;
+  HIPCHK(c, ev.create());
+  HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
+  HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(ev.e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  *total_ms = (double)ms;
+  c->ran = true;
+  return DSH_OK;
+}
+
+int dsh_lab_sft_assemble_timed(dsh_ctx* c, int launches, double* total_ms) {
+  if (!c || launches <= 0 || !total_ms) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_assemble_timed: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_assemble_timed: host-only context, no GPU (there is no CPU fallback)");
+  if (c->B <= 0 || !c->ran) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_assemble_timed: needs an uploaded batch that has run once");
+  (void)hipSetDevice(c->device);
+  EventPair ev;
+  HIPCHK(c, ev.create());
+  HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(ev.e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  *total_ms = ms;
+  c->ran = false;   // results of the last full run are gone (state reset, H reassembled at the initial state)
+  return DSH_OK;
+}
+
+int dsh_lab_sft_phase_ms(dsh_ctx* c, int b, double* out8) {
+  if (!c || !out8 || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_phase_ms: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_phase_ms: host-only context");
+  if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_phase_ms: no run");
+#ifndef SFT_PHASE_TIMERS
+  return fail(c, DSH_ERR_STATE, "dsh_lab_sft_phase_ms: this build has no phase timers (make lab EXTRA=-DSFT_PHASE_TIMERS)");
+#else
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out8, c->h_probs[b].dbg, 8 * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; i++) out8[i] *= 1e-5;  // 100 MHz ticks -> ms
+  return DSH_OK;
+#endif
+}
+
+int dsh_lab_sft_step_trace(dsh_ctx* c, int b, double* out64) {
+  if (!c || !out64 || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_step_trace: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_step_trace: host-only context");
+  if (!c->ran) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_step_trace: no run");
+#ifndef SFT_STEP_TRACE
+  return fail(c, DSH_ERR_STATE, "dsh_lab_sft_step_trace: this build has no step trace (make lab EXTRA=-DSFT_STEP_TRACE)");
+#else
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out64, c->h_probs[b].dbg + 16, 64 * sizeof(double), hipMemcpyDeviceToHost));
+  return DSH_OK;
+#endif
+}
+
+int dsh_lab_sft_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, double* chi2) {
+  if (!c || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_system: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_system: host-only context");
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // an asynchronous run may still be using the problem table
   SftDev h = c->h_probs[b];
-  if (D != 6 + h.Dn) return fail(c, DSH_ERR_ARG, "dsh_sft_debug_system: D mismatch");
+  if (D != 6 + h.Dn) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_system: D mismatch");
   // flip the mode of this one problem, run it alone, restore
   const int32_t mode_saved = h.mode;
   h.mode = 1;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
-  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->ran = false;   // the state of problem b was reset: a download would not return the results of the last run
   h.mode = mode_saved;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
@@ -855,5 +941,6 @@ int dsh_sft_debug_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, 
   }
   return DSH_OK;
 }
+#endif  // DSH_LAB
 
 }  // extern "C"

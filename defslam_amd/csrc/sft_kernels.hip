@@ -24,13 +24,7 @@
 #include <float.h>
 #define SFT_KERNEL_SOURCE
 #include "sft_problem.h"
-#ifndef SFT_WAVES_PER_EU
-#define SFT_WAVES_PER_EU 2      // 4: the dense build (sft_kernels_dense.hip), 128 VGPRs per wave, two 8-wave problems per CU
-#endif
-#ifndef SFT_LAUNCH_NAME
-#define SFT_LAUNCH_NAME sft_lm_launch
-#define SFT_LDS_BYTES_NAME sft_lm_kernel_lds_bytes
-#endif
+#define SFT_WAVES_PER_EU 2      // 256 VGPRs per wave: the trailing window of the factorisation lives in accumulator registers
 #include "tile_chol.h"
 
 #define NB 32  // panel width of the blocked band Cholesky
@@ -800,6 +794,7 @@ __device__ __forceinline__ T* uni(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+#ifdef DSH_LAB   // the barrier version of the factor steps: A/B reference of the dataflow version below (dsh_lab_set_option "dataflow" 0)
 // Tile-mode factorisation on NW wavefronts (NW = 8: one ring row per wave, lowest latency; NW = 4: two ring rows per
 // wave so that two problems share a CU).  Wave w owns ring rows a = w + NW*t (t < RPW) of the BT x BT accumulator window
 // (slots b = 0..BT-1; tile (I,J) of the window [k+1, k+BT] sits in slot (I mod BT, J mod BT)), the border tiles of the
@@ -1152,6 +1147,8 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   __syncthreads();
 }
 
+#endif  // DSH_LAB
+
 // ------------------------------------------------------------------------------------------
 // Dataflow variant of the tile-mode factorisation (8 wavefronts): no workgroup barriers inside the step loop.
 // Every wave TRSMs the tile of its OWN ring row (X_i = A_i W_k^T: the raw tile is its own publication, private LDS
@@ -1241,11 +1238,6 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
       if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
     }
   }
-#if SFT_WAVES_PER_EU >= 4
-  // dense build (four waves per SIMD, 128 VGPRs): the corner accumulator of wave 0 waits in LDS between the steps
-  lds_double* CaccL = (lds_double*)(F + 48);
-  if (wave == 0) { CaccL[2 * lane] = cacc[0]; CaccL[2 * lane + 1] = cacc[1]; }
-#endif
   for (int i = tid; i < 2 * (BT + 1) * TILE_LDS; i += NT) XpB[i] = 0.0;   // rows 7..15 of both border panel tiles stay zero
   if (tid < 48) F[tid] = (tid == 0 || tid == 1) ? -1 : 0;
   if (tid == 0) ctl->fact_ok = 1;
@@ -1367,14 +1359,6 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
         flag_set(wflag, kc);
         *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
         __builtin_amdgcn_s_setprio(0);
-#if SFT_WAVES_PER_EU >= 4
-        // This wave's ring row is recycled at the next step (it becomes the memory wave): nothing of it is read again.
-        // Telling the compiler (the registers are "redefined" here, without an instruction) frees them across the factorisation.
-#pragma unroll
-        for (int b2 = 0; b2 < BT; b2++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) { double z; asm volatile("" : "=v"(z)); acc[b2][q] = z; }
-#endif
       } else {
         lds_double* dst = Aself + ccol * TP + crow;  // raw tile (I, kc) for the next step's TRSM: private slot
 #pragma unroll
@@ -1415,15 +1399,8 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) bacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], bbord[kk], bacc, 0, 0, 0);
         if (wave == 0) {
-#if SFT_WAVES_PER_EU >= 4
-          v4d cc = {CaccL[2 * lane], CaccL[2 * lane + 1], 0.0, 0.0};
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) cc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cc, 0, 0, 0);
-          CaccL[2 * lane] = cc[0]; CaccL[2 * lane + 1] = cc[1];
-#else
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
-#endif
         }
         if (Jb == kc && kc < nT) {                   // border block of column kc for the next TRSM
           lds_double* Abord = AbordB + p3c * SFT_BORDER * TS;
@@ -1475,11 +1452,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int r = crow + 4 * q;
-#if SFT_WAVES_PER_EU >= 4
-      if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = CaccL[2 * lane + q];
-#else
       if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = cacc[q];
-#endif
     }
   }
   __syncthreads();
@@ -1993,18 +1966,20 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
   if (tid == 0) {
     ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
-    P.info[0] = 0; P.info[1] = 0; P.info[2] = 0;
+    P.res->iters = 0; P.res->trials = 0; P.res->status = 0; P.res->inliers = 0;
     for (int i = 0; i < 96; i++) P.dbg[i] = 0.0;
   }
   __syncthreads();
   PH_T0();
 
-  if (P.mode == 1) {  // test hook: one assembly at the initial state
+#ifdef DSH_LAB
+  if (P.mode == 1) {  // lab hook (dsh_lab_sft_system): one assembly at the initial state
     const double chi = eval_edges<true>(P, ctl, red, out, jp);
     assemble(P, red, out, jp);
     if (tid == 0) P.dbg[0] = chi;
     return;
   }
+#endif
 
   int total_trials = 0, iters = 0;
   for (int it = 0; it < P.max_iters; it++) {
@@ -2037,13 +2012,16 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
           PH_ADD(6);
         }
       } else if (P.tile_mode) {
-        if (P.mode & 2) {
+#ifdef DSH_LAB
+        if (!(P.mode & 2)) factor_tiles<NW>(P, ctl, panel);
+        else
+#endif
+        {
           PH_RESET();
           if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel);
           else factor_tiles_df<NW>(P, ctl, panel);
           PH_ADD(5);
         }
-        else factor_tiles<NW>(P, ctl, panel);
         PH_RESET();
         backsub_tiles<NW>(P, ctl, panel);
         PH_ADD(6);
@@ -2104,7 +2082,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
       t[0] = ctl->chi_ini; t[1] = lambda_start; t[2] = ctl->qmax; t[3] = ctl->chi_cur; t[4] = ctl->lambda; t[5] = ctl->rho;
       t[6] = ctl->accepted; t[7] = all_ok;
     }
-    if (tid == 0 && !all_ok) P.info[2] |= 1;
+    if (tid == 0 && !all_ok) P.res->status |= 1;
     bool term = (ctl->qmax == 10) || (ctl->rho == 0);
     if (!term) {
       if (tid == 0) {
@@ -2116,22 +2094,58 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
     __syncthreads();
     if (term) break;
   }
-  // final reprojection error norms at the final estimate (DefOptimizer.cc:538-559)
-  if (tid == 0) { quat_to_R(P.pose + 3, ctl->R); ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2]; }
+  // ---- classification and statistics (DefOptimizer.cc:515-559), map-point write-back (DefMapPoint.cc:129-147) ----------
+  //   outlier[m] = (float)chi2 > 5.991 with the chi2 of the observation's LAST evaluation (stale when the last damping
+  //   trial was rejected: the reference reads e->chi2() without recomputing the error of inliers);
+  //   repError = sum over the inliers, in index order, of the reprojection error norm at the final estimate, / count.
+  if (tid == 0) { quat_to_R(P.pose + 3, ctl->R); ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2]; ctl->nbad = 0; ctl->chi_tmp = 0.0; }
   __syncthreads();
-  for (int m = tid; m < P.M; m += NT) {
-    const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
-    const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
-    double pw[3], pc[3];
-    for (int k = 0; k < 3; k++) pw[k] = (b0 * P.xyz[3 * n0 + k] + b1 * P.xyz[3 * n1 + k]) + b2 * P.xyz[3 * n2 + k];
-    for (int k = 0; k < 3; k++) pc[k] = (ctl->R[3 * k] * pw[0] + ctl->R[3 * k + 1] * pw[1] + ctl->R[3 * k + 2] * pw[2]) + ctl->t[k];
-    const double e0 = P.obs_uv[2 * m] - ((pc[0] / pc[2]) * P.fx + P.cx);
-    const double e1 = P.obs_uv[2 * m + 1] - ((pc[1] / pc[2]) * P.fy + P.cy);
-    P.final_err[m] = sqrt(e0 * e0 + e1 * e1);
+  {
+    constexpr int CHK = 2048;                 // observations per pass: their error norms wait in LDS for the ordered sum
+    lds_double* ers = to_lds(panel);
+    int nbad = 0;
+    for (int m0 = 0; m0 < P.M; m0 += CHK) {
+      const int mend = min(P.M, m0 + CHK);
+      for (int m = m0 + tid; m < mend; m += NT) {
+        const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
+        const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
+        double pw[3], pc[3];
+        for (int k = 0; k < 3; k++) pw[k] = (b0 * P.xyz[3 * n0 + k] + b1 * P.xyz[3 * n1 + k]) + b2 * P.xyz[3 * n2 + k];
+        for (int k = 0; k < 3; k++) pc[k] = (ctl->R[3 * k] * pw[0] + ctl->R[3 * k + 1] * pw[1] + ctl->R[3 * k + 2] * pw[2]) + ctl->t[k];
+        const double e0 = P.obs_uv[2 * m] - ((pc[0] / pc[2]) * P.fx + P.cx);
+        const double e1 = P.obs_uv[2 * m + 1] - ((pc[1] / pc[2]) * P.fy + P.cy);
+        const double er = sqrt(e0 * e0 + e1 * e1);
+        const bool bad = (double)(float)P.chi2_obs[m] > 5.991;
+        P.outlier[m] = bad ? 1 : 0;
+        nbad += bad ? 1 : 0;
+        ers[m - m0] = bad ? -1.0 : er;          // error norms are >= 0 (or NaN): a negative entry marks an outlier
+        // float32 world position, plain IEEE products and sums like the host code of the reference (no contraction)
+        for (int k = 0; k < 3; k++)
+          P.mappoint[3 * m + k] = (float)__dadd_rn(__dadd_rn(__dmul_rn(b0, P.xyz[3 * n0 + k]), __dmul_rn(b1, P.xyz[3 * n1 + k])), __dmul_rn(b2, P.xyz[3 * n2 + k]));
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double sum = ctl->chi_tmp;
+        const int cnt = mend - m0;
+#pragma unroll 8
+        for (int i = 0; i < cnt; i++) { const double v = ers[i]; if (!(v < 0.0)) sum += v; }
+        ctl->chi_tmp = sum;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nbad += __shfl_down(nbad, off, 64);
+    if ((tid & 63) == 0 && nbad) atomicAdd(&ctl->nbad, nbad);   // integer: order independent
+    __syncthreads();
   }
-  if (tid == 0) { P.info[0] = iters; P.info[1] = total_trials; }
+  if (tid == 0) {
+    const int inl = P.M - ctl->nbad;
+    P.res->iters = iters; P.res->trials = total_trials; P.res->inliers = inl;
+    P.res->rep_error = ctl->chi_tmp / (double)(unsigned)inl;
+  }
 }
 
+#ifdef DSH_LAB
 // Measurement kernel of the Jacobian-assembly roofline: one linearisation (residuals + Jacobian records) and one
 // normal-equation assembly per problem at its uploaded initial state, nothing else.  H and the border keep the zero pattern
 // of the last full run of the batch (the assembly overwrites every structural non-zero).  Same launch shape and LDS layout
@@ -2155,10 +2169,12 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_assembly_kernel
   if (tid == 0) P.dbg[0] = chi;
 }
 
+#endif  // DSH_LAB
+
 }  // namespace
 
 // LDS bytes the kernel needs for a problem with half-bandwidth kd
-extern "C" size_t SFT_LDS_BYTES_NAME(int kd, size_t jl_doubles) {
+extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   const size_t rows = NB + kd + SFT_BORDER;
   const size_t LDP = rows | 1;
   size_t panel = (size_t)NB * LDP + 2 * NB * NB;   // panel + diagraw + lrow
@@ -2171,9 +2187,9 @@ extern "C" size_t SFT_LDS_BYTES_NAME(int kd, size_t jl_doubles) {
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
 
-#ifndef SFT_NO_ASSEMBLY_KERNEL
+#ifdef DSH_LAB
 extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
-  const size_t lds = SFT_LDS_BYTES_NAME(max_kd, jl_doubles);
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
   const void* fn = nw == 4 ? reinterpret_cast<const void*>(sft_assembly_kernel<4>) : reinterpret_cast<const void*>(sft_assembly_kernel<8>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -2183,20 +2199,16 @@ extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_
 }
 #endif
 
-extern "C" hipError_t SFT_LAUNCH_NAME(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream) {
-  const size_t lds = SFT_LDS_BYTES_NAME(max_kd, jl_doubles);
-  static size_t configured[2] = {0, 0};
+// `configured` (two slots, owned by the calling context, i.e. per device): the dynamic LDS size the two kernels were last
+// enabled for on that device -- the function attribute is per device, a process-wide cache would skip the second GPU.
+extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
   const int slot = nw == 4 ? 0 : 1;
   if (lds > configured[slot]) {
     const void* fn = nw == 4 ? reinterpret_cast<const void*>(sft_lm_kernel<4>) : reinterpret_cast<const void*>(sft_lm_kernel<8>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured[slot] = lds;
-    if (std::getenv("DSH_SFT_VERBOSE")) {
-      int nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * nw, lds);
-      std::fprintf(stderr, "[defslam_hip] sft_lm_kernel<%d>: %zu B LDS per workgroup, %d resident workgroups per CU\n", nw, lds, nb);
-    }
   }
   if (nw == 4) hipLaunchKernelGGL(sft_lm_kernel<4>, dim3(B), dim3(256), lds, stream, d_probs);
   else hipLaunchKernelGGL(sft_lm_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs);

@@ -35,6 +35,16 @@
 #define SFT_G
 #endif
 
+// Per-problem result header.  The headers of a batch are contiguous (one copy brings every counter back) and are followed
+// by the result bodies (vertices, per-observation chi2, trace, map points, outlier flags): dsh_sft_batch_download moves the
+// whole region with ONE hipMemcpyAsync.  Classification and statistics are computed by the kernel (DefOptimizer.cc:515-559).
+struct SftResHdr {
+  int32_t iters, trials, status, inliers;   // outer LM iterations, damping trials, bit 0: a factorisation failed, M - nBad
+  double rep_error;                         // sumError / n over the inliers, summed in index order (pFrame->repError)
+  double pose[8];                           // t(3), q(x,y,z,w); [7] unused
+  double pad[5];
+};                                          // 128 bytes
+
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
@@ -79,7 +89,7 @@ struct SftDev {
   // state + workspace
   SFT_G double* xyz;              // n*3
   SFT_G double* xyz_bak;          // n*3
-  SFT_G double* pose;             // 7
+  SFT_G double* pose;             // 7 (inside *res)
   SFT_G double* Jobs;             // M*SFT_JOBS_STRIDE
   SFT_G double* Jstar;            // S*4  (u, r)
   SFT_G double* Jstr;             // Es*4 (g, e)
@@ -99,8 +109,9 @@ struct SftDev {
   SFT_G double* x;                // Dn+6
   // outputs
   SFT_G double* chi2_obs;         // M
-  SFT_G double* final_err;        // M  reprojection error norm at the final estimate
   SFT_G double* trace;            // max_iters*8
-  SFT_G int32_t* info;            // [0] iters [1] trials [2] status
+  SFT_G SftResHdr* res;           // counters, statistics and the final pose (pose points into it)
+  SFT_G uint8_t* outlier;         // M  (float)chi2 > 5.991 (DefOptimizer.cc:515-537)
+  SFT_G float* mappoint;          // M*3 DefMapPoint::RecalculatePosition of every observation's point (DefMapPoint.cc:129-147)
   SFT_G double* dbg;              // [0] robust chi2 of the debug assembly
 };

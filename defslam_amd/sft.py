@@ -61,8 +61,10 @@ class Frame:
 class Context:
     """One GPU context (dsh_ctx): owns the template and the device buffers."""
 
-    def __init__(self, device: int = 0):
-        self._L = _lib.load()
+    def __init__(self, device: int = 0, lab: bool = False):
+        """lab=True binds libdefslam_hip_lab.so (the product ABI + include/defslam_hip_debug.h) instead of the product library."""
+        self.lab = bool(lab)
+        self._L = _lib.load_lab() if lab else _lib.load()
         h = C.c_void_p()
         rc = self._L.dsh_create(C.byref(h), device)
         if rc != _lib.DSH_OK:
@@ -72,6 +74,9 @@ class Context:
         self._keep = None
 
     def close(self):
+        if getattr(self, "_events", None) is not None:
+            self._events.close()
+            self._events = None
         if getattr(self, "_h", None):
             self._L.dsh_destroy(self._h)
             self._h = None
@@ -179,21 +184,49 @@ class Context:
         self._check(self._L.dsh_sft_batch_run(self._h), "dsh_sft_batch_run")
 
     def batch_run_timed(self, launches: int = 1) -> float:
-        """`launches` back-to-back runs timed with HIP events on the context's stream; returns milliseconds."""
+        """`launches` back-to-back runs bracketed by two HIP events recorded on the context's stream (the caller's own
+        events through dsh_stream(): the product ABI has no timing entry point); returns milliseconds."""
+        if getattr(self, "_events", None) is None:
+            self._events = _lib.HipEvents()
+        st = self.stream()
+        self._events.start(st)
+        for _ in range(int(launches)):
+            self.batch_run()
+        return self._events.stop_ms(st)
+
+    # ---- lab build only (include/defslam_hip_debug.h) ---------------------------------------
+    def _need_lab(self, what: str):
+        if not self.lab:
+            raise DshError(f"{what} is a lab entry point (include/defslam_hip_debug.h): create the context with Context(device, lab=True)")
+
+    def set_option(self, name: str, value: int):
+        self._need_lab("dsh_lab_set_option")
+        self._check(self._L.dsh_lab_set_option(self._h, name.encode(), int(value)), "dsh_lab_set_option")
+
+    def lab_run_timed(self, launches: int = 1) -> float:
+        self._need_lab("dsh_lab_sft_run_timed")
         ms = C.c_double()
-        self._check(self._L.dsh_sft_batch_run_timed(self._h, int(launches), C.byref(ms)), "dsh_sft_batch_run_timed")
+        self._check(self._L.dsh_lab_sft_run_timed(self._h, int(launches), C.byref(ms)), "dsh_lab_sft_run_timed")
         return ms.value
 
     def batch_assemble_timed(self, launches: int = 1) -> float:
         """`launches` launches of one linearisation + normal-equation assembly per problem (measurement aid); milliseconds."""
+        self._need_lab("dsh_lab_sft_assemble_timed")
         ms = C.c_double()
-        self._check(self._L.dsh_sft_batch_assemble_timed(self._h, int(launches), C.byref(ms)), "dsh_sft_batch_assemble_timed")
+        self._check(self._L.dsh_lab_sft_assemble_timed(self._h, int(launches), C.byref(ms)), "dsh_lab_sft_assemble_timed")
         return ms.value
 
     def phase_ms(self, b: int = 0):
+        self._need_lab("dsh_lab_sft_phase_ms")
         out = np.zeros(8)
-        self._check(self._L.dsh_sft_batch_phase_ms(self._h, b, _ptr(out, C.c_double)), "dsh_sft_batch_phase_ms")
+        self._check(self._L.dsh_lab_sft_phase_ms(self._h, b, _ptr(out, C.c_double)), "dsh_lab_sft_phase_ms")
         return dict(trsm=out[0], residuals=out[1], assembly=out[2], copy=out[3], panel=out[4], update=out[5], backsub=out[6], control=out[7])
+
+    def step_trace(self, b: int = 0):
+        self._need_lab("dsh_lab_sft_step_trace")
+        out = np.zeros(64)
+        self._check(self._L.dsh_lab_sft_step_trace(self._h, b, _ptr(out, C.c_double)), "dsh_lab_sft_step_trace")
+        return out.reshape(8, 8)
 
     def synchronize(self):
         self._check(self._L.dsh_synchronize(self._h), "dsh_synchronize")
@@ -248,11 +281,50 @@ class Context:
             out.append(int(r.inliers))
         return out
 
+    def prepare_solve(self, f: Frame, RegLap=5000.0, RegInex=5000.0, RegTemp=0.0, NeighboursLayers=1, max_iters=50):
+        """The one-shot ABI call dsh_sft_solve (pack + upload + run + download) with its C structs and output buffers built
+        beforehand: the returned callable makes exactly one C call and then points the Frame's result fields at the
+        buffers -- what bench.py times as the end-to-end frame."""
+        keep: list = []
+        fc = self._frame_c(f, RegLap, RegInex, RegTemp, NeighboursLayers, max_iters, keep)
+        M, n = f.obs_nodes.shape[0], f.nodes_xyz.shape[0]
+        b = dict(Tcw=np.zeros((4, 4), np.float32), pose7=np.zeros(7), xyz=np.zeros((n, 3)), chi2=np.zeros(M), outl=np.zeros(M, np.uint8),
+                 mp=np.zeros((M, 3), np.float32), trace=np.zeros((max(max_iters, 1), _lib.DSH_TRACE_STRIDE)))
+        r = _lib.SftResultC()
+        r.Tcw = _ptr(b["Tcw"], C.c_float)
+        r.pose7 = _ptr(b["pose7"], C.c_double)
+        r.xyz = _ptr(b["xyz"], C.c_double)
+        r.chi2_obs = _ptr(b["chi2"], C.c_double)
+        r.outlier = _ptr(b["outl"], C.c_uint8)
+        r.mappoint_xyz = _ptr(b["mp"], C.c_float)
+        r.trace = _ptr(b["trace"], C.c_double)
+        ctx = self
+
+        class _Call:
+            frame = f
+
+            def __call__(self_inner) -> int:
+                rc = ctx._L.dsh_sft_solve(ctx._h, C.byref(fc), C.byref(r))
+                if rc != _lib.DSH_OK:
+                    ctx._check(rc, "dsh_sft_solve")
+                f.Tcw, f.pose7, f.nodes_xyz, f.chi2_obs, f.mappoints = b["Tcw"], b["pose7"], b["xyz"], b["chi2"], b["mp"]
+                f.mvbOutlier = b["outl"].view(np.bool_)
+                f.repError = float(np.float32(r.rep_error))
+                f.rep_error_f64 = r.rep_error
+                f.iters, f.trials, f.dim, f.half_bandwidth, f.status = r.iters, r.trials, r.dim, r.half_bandwidth, r.status
+                f.trace = b["trace"][:r.iters]
+                return int(r.inliers)
+
+        call = _Call()
+        call._keep = (keep, b, fc, r)
+        return call
+
     def debug_system(self, b: int, D: int):
+        self._need_lab("dsh_lab_sft_system")
         H = np.zeros((D, D), order="F")
         bv = np.zeros(D)
         chi = C.c_double()
-        self._check(self._L.dsh_sft_debug_system(self._h, b, D, _ptr(H, C.c_double), _ptr(bv, C.c_double), C.byref(chi)), "dsh_sft_debug_system")
+        self._check(self._L.dsh_lab_sft_system(self._h, b, D, _ptr(H, C.c_double), _ptr(bv, C.c_double), C.byref(chi)), "dsh_lab_sft_system")
         return H, bv, chi.value
 
 

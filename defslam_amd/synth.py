@@ -101,7 +101,9 @@ def make_frame(tmpl: GridTemplate, n_matches: int, problem_id: int = 0, *,
                bend: float = 0.05, rot_deg: float = 3.0, trans: float = 0.02,
                noise_px: float = 0.5, outlier_frac: float = 0.05,
                n_frame: int = N_FRAME_KEYPOINTS, init_xyz: np.ndarray | None = None,
-               init_Tcw: np.ndarray | None = None, phase: float = 0.0) -> SftFrame:
+               init_Tcw: np.ndarray | None = None, phase: float = 0.0, gt_pose: tuple | None = None) -> SftFrame:
+    """gt_pose = (rotation vector, translation) fixes the ground-truth camera (sequences: a smooth trajectory) instead of
+    drawing it from the problem's random stream; the stream is consumed identically either way."""
     rng = np.random.default_rng(42 + problem_id)
     fx, fy, cx, cy = CAMERA_K
     xyz0 = tmpl.xyz0
@@ -115,6 +117,9 @@ def make_frame(tmpl: GridTemplate, n_matches: int, problem_id: int = 0, *,
     ang = np.deg2rad(rot_deg) * rng.uniform(0.3, 1.0)
     R = _rodrigues(axis * ang)
     t = rng.uniform(-trans, trans, size=3)
+    if gt_pose is not None:
+        R = _rodrigues(np.asarray(gt_pose[0], dtype=np.float64))
+        t = np.asarray(gt_pose[1], dtype=np.float64)
     gtT = np.eye(4)
     gtT[:3, :3] = R
     gtT[:3, 3] = t
@@ -139,6 +144,34 @@ def make_frame(tmpl: GridTemplate, n_matches: int, problem_id: int = 0, *,
     return SftFrame(Tcw=Tcw, K=np.asarray(CAMERA_K, dtype=np.float64), n_frame=n_frame,
                     obs_facet=fac, obs_nodes=nodes, obs_bary=bary, obs_uv=uv, obs_invsig2=invsig2,
                     xyz=xyz, gt_xyz=gt, gt_Tcw=gtT, is_outlier_gt=is_out)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SEQ100 (the runnable substitute of BASELINE.json configs[0] / configs[2], the Mandala sequences that
+# need OpenCV + datasets): a sequence of frames with temporally smooth deformation and camera motion.  Frame k is
+# tracked from the result of frame k-1 (DefTracking.cc:350: each frame starts at the previous pose / mesh; the pose
+# takes the reference's float32 round trip through cv::Mat).
+# ---------------------------------------------------------------------------------------------------------
+SEQ100 = dict(config="C2", n_frames=100, seq_id=0)
+
+
+def sequence_gt_pose(k: int, n_frames: int, rot_deg: float = 3.0, trans: float = 0.02):
+    """Ground-truth camera of frame k: a closed smooth loop (rotation <= rot_deg about a fixed axis, translation on a
+    small ellipse), so consecutive frames differ by ~2*pi/n_frames of it."""
+    a = 2.0 * np.pi * k / n_frames
+    axis = np.array([0.4, 0.8, 0.2]) / np.linalg.norm([0.4, 0.8, 0.2])
+    rotvec = axis * np.deg2rad(rot_deg) * np.sin(a)
+    t = trans * np.array([np.sin(a), 0.5 * (1.0 - np.cos(a)), 0.3 * np.sin(2.0 * a)])
+    return rotvec, t
+
+
+def make_sequence_frame(tmpl: GridTemplate, n_matches: int, k: int, n_frames: int = 100, seq_id: int = 0,
+                        init_xyz: np.ndarray | None = None, init_Tcw: np.ndarray | None = None) -> SftFrame:
+    """Frame k of a smooth sequence: the bend travels one period over the sequence (phase 2 pi k / n), the camera follows
+    sequence_gt_pose, matches are redrawn per frame (problem id = 100000 (seq_id + 1) + k).  init_* = the previous
+    frame's result (warm start); None starts from the rest shape / identity like frame 0 of the reference."""
+    return make_frame(tmpl, n_matches, 100000 * (seq_id + 1) + k, phase=2.0 * np.pi * k / n_frames - 0.3 * (100000 * (seq_id + 1) + k),
+                      init_xyz=init_xyz, init_Tcw=init_Tcw, gt_pose=sequence_gt_pose(k, n_frames))
 
 
 def make_problem(config: str = "C2", problem_id: int = 0):

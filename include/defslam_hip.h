@@ -23,6 +23,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only this ABI is exported */
+#endif
 
 #define DSH_OK 0
 #define DSH_ERR_ARG 1        /* bad argument / size */
@@ -103,36 +106,24 @@ typedef struct dsh_sft_result {
 int dsh_sft_solve(dsh_ctx* ctx, const dsh_sft_frame* frame, dsh_sft_result* result);
 
 /* Batched / device-resident form (independent problems against the current template):
- *   dsh_sft_batch_upload  packs B frames on the host and copies them to HBM,
+ *   dsh_sft_batch_upload  packs B frames on the host and starts ONE asynchronous copy to HBM on dsh_stream
+ *                         (the frame buffers may be reused as soon as it returns),
  *   dsh_sft_batch_run     launches the solve (asynchronous on dsh_stream); may be called
  *                         repeatedly -- every run restarts from the uploaded initial state,
- *   dsh_sft_batch_download copies results back. */
+ *   dsh_sft_batch_download brings every result of the batch back with ONE copy (outlier classification, inlier count,
+ *                         repError and the float32 map points are computed by the kernel) and waits for it.
+ * To time the device work, record your own HIP events on dsh_stream() around dsh_sft_batch_run.
+ * Measurement and debugging aids (per-phase timers, assembly-only launches, the dense normal equations of a problem,
+ * solver A/B switches) are NOT part of this ABI: include/defslam_hip_debug.h, libdefslam_hip_lab.so. */
 int dsh_sft_batch_upload(dsh_ctx* ctx, int B, const dsh_sft_frame* frames);
 int dsh_sft_batch_run(dsh_ctx* ctx);
 int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
-/* `launches` back-to-back runs bracketed by HIP events recorded on dsh_stream; returns the elapsed
- * milliseconds between the two events (device time of the launches, no host round trips inside). */
-int dsh_sft_batch_run_timed(dsh_ctx* ctx, int launches, double* total_ms);
-/* Measurement aid for the Jacobian-assembly roofline: `launches` back-to-back launches in which every problem of
- * the batch does ONE linearisation (residuals + Jacobian records, DefOptimizer.cc:293-507 / g2o linearizeSystem) and one
- * normal-equation assembly at its uploaded initial state and stops; elapsed device milliseconds between two HIP events.
- * Needs a batch that has run once (H keeps the zero pattern of that run); invalidates that run's results. */
-int dsh_sft_batch_assemble_timed(dsh_ctx* ctx, int launches, double* total_ms);
-/* Per-phase device time of problem b in the last run, milliseconds (constant 100 MHz counter read by one lane):
- * out8[1] residuals, [2] normal-equation assembly, [3] H->L copy, [4] panel factorisation, [5] trailing update,
- * [6] back substitution, [7] state update + LM control.  out8[0] is reserved. */
-int dsh_sft_batch_phase_ms(dsh_ctx* ctx, int b, double* out8);
 /* Totals of the last completed run (valid after a synchronise): outer iterations and trials over the batch. */
 int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
 /* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts
  * counts[8] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim,
  * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload. */
 int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int32_t* counts);
-
-/* Test hook: run only "residuals + Jacobians + normal equations" once at the uploaded state of
- * problem b and return the dense system in the reference's index order (camera first, then active
- * nodes ascending; column-major D x D) plus b and the robust chi2.  H/bvec may be NULL. */
-int dsh_sft_debug_system(dsh_ctx* ctx, int b, int32_t D, double* H, double* bvec, double* chi2);
 
 /* ---- NRSfM mapping side ----------------------------------------------------------------------- */
 /* Uniform bicubic B-spline (BBS::bbs_t, Thirdparty/BBS/bbs.h:41-50). */
@@ -262,6 +253,9 @@ int dsh_surface_register(dsh_ctx* ctx, int n, const float* cloud_surface /* n*3 
                          int64_t nu, const float* Twc /* 16 */, double chi_limit, int check_chi, int32_t* registered, double* sim3 /* 8 */,
                          double* s22, float* Tcw_new /* 16 */, double* info /* 8 */);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+/*
+ * defslam_hip_debug.h -- lab / measurement entry points of libdefslam_hip_lab.so (MI355X / gfx950).
+ *
+ * NOT part of the product ABI.  The product library (libdefslam_hip.so, include/defslam_hip.h) does not export these
+ * symbols, reads no environment variables and contains neither the test hooks nor the A/B solver variants.  The lab
+ * library is the same source built with -DDSH_LAB (make -C defslam_amd/csrc lab) and exports the product ABI plus the
+ * functions below; it is what the parity tests of the normal equations, the profiling scripts under tools/ and the
+ * isolated-assembly leg of bench.py load.
+ */
+#ifndef DEFSLAM_HIP_DEBUG_H
+#define DEFSLAM_HIP_DEBUG_H
+
+#include "defslam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only this ABI is exported */
+#endif
+
+/* Solver A/B switches, applied by the next dsh_sft_batch_upload of this context:
+ *   "waves"    0 = automatic (default), 4 or 8 wavefronts per problem of the persistent kernel
+ *   "dataflow" 1 = barrier-free factor steps (default), 0 = the barrier version (only compiled into the lab library)
+ *   "wide_off" 1 = half-bandwidths 128 < kd <= 256 use the row-major band solver instead of the wide tile solver */
+int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
+
+/* `launches` back-to-back runs of the uploaded batch bracketed by HIP events recorded on dsh_stream; elapsed device
+ * milliseconds between the two events. */
+int dsh_lab_sft_run_timed(dsh_ctx* ctx, int launches, double* total_ms);
+/* Measurement aid for the Jacobian-assembly roofline: `launches` back-to-back launches in which every problem
+ * of the batch does ONE linearisation (residuals + Jacobian records, DefOptimizer.cc:293-507 / g2o linearizeSystem) and one
+ * normal-equation assembly at its uploaded initial state and stops; elapsed device milliseconds between two HIP events.
+ * Needs a batch that has run once (H keeps the zero pattern of that run); invalidates that run's results. */
+int dsh_lab_sft_assemble_timed(dsh_ctx* ctx, int launches, double* total_ms);
+/* Per-phase device time of problem b in the last run, milliseconds (constant 100 MHz counter read by one lane):
+ * out8[1] residuals, [2] normal-equation assembly, [3] H->L copy, [4] panel factorisation, [5] trailing update,
+ * [6] back substitution, [7] state update + LM control.  DSH_ERR_STATE unless built with EXTRA=-DSFT_PHASE_TIMERS. */
+int dsh_lab_sft_phase_ms(dsh_ctx* ctx, int b, double* out8);
+/* Shader-clock stamps of factorisation step 40 of problem b: 8 per wavefront (out64[8 w + e]).  DSH_ERR_STATE unless built
+ * with EXTRA=-DSFT_STEP_TRACE. */
+int dsh_lab_sft_step_trace(dsh_ctx* ctx, int b, double* out64);
+/* Run only "residuals + Jacobians + normal equations" once at the uploaded state of problem b and return the dense system
+ * in the reference's index order (camera first, then active nodes ascending; column-major D x D) plus b and the robust
+ * chi2.  H / bvec may be NULL.  Invalidates the results of the last run. */
+int dsh_lab_sft_system(dsh_ctx* ctx, int b, int32_t D, double* H, double* bvec, double* chi2);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFSLAM_HIP_DEBUG_H */

@@ -29,6 +29,15 @@ def gpu_ctx():
 
 
 @pytest.fixture(scope="session")
+def lab_ctx():
+    """A context of the lab build (libdefslam_hip_lab.so: the product ABI + include/defslam_hip_debug.h)."""
+    from defslam_amd import sft
+    ctx = sft.Context(0, lab=True)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
 def host_ctx():
     from defslam_amd import sft
     ctx = sft.Context(-1)

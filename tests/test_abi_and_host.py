@@ -21,6 +21,60 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
 
 
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+
+
+def test_product_library_exports_exactly_the_public_header_and_the_lab_library_adds_the_debug_header():
+    """The product ABI carries no lab equipment: libdefslam_hip.so exports the prototypes of include/defslam_hip.h and nothing
+    else (no timers, no test hooks, no internal launchers), and does not read the environment; the measurement / debugging
+    entry points of include/defslam_hip_debug.h exist only in libdefslam_hip_lab.so (the same sources with -DDSH_LAB)."""
+    import subprocess
+    from defslam_amd import _lib
+    header = open(os.path.join(ROOT, "include", "defslam_hip.h")).read()
+    debug_header = open(os.path.join(ROOT, "include", "defslam_hip_debug.h")).read()
+    declared = sorted(set(re.findall(r"\b(dsh_[a-z0-9_]+)\s*\(", header)))
+    lab_declared = sorted(set(re.findall(r"\b(dsh_lab_[a-z0-9_]+)\s*\(", debug_header)))
+    assert lab_declared and sorted(_lib.LAB_SYMBOLS) == lab_declared
+    assert not re.search(r"timed|phase_ms|debug_system|dsh_lab", header)
+    assert _dynamic_symbols(_lib.LIB_PATH) == declared
+    assert _dynamic_symbols(_lib.LAB_LIB_PATH) == sorted(declared + lab_declared)
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, "the product library must not read environment switches"
+    L = _lib.load_lab()
+    for name in lab_declared:
+        assert hasattr(L, name)
+
+
+def test_template_set_refuses_malformed_index_arrays(host_ctx):
+    """dsh_template_set turns the caller's CSR / edge arrays into indices of the packer: out-of-range or non-monotone
+    input is DSH_ERR_ARG, not a heap overrun (nothing aborts across the ABI)."""
+    from defslam_amd import sft, synth
+    tmpl = synth.make_grid_template(6, 7)
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    t = host_ctx.template_get()
+
+    def attempt(**over):
+        a = dict(t)
+        a.update(over)
+        host_ctx.template_set(tmpl.xyz0, a["boundary"], a["nbr_ptr"], a["nbr_idx"], a["nbr_w"], a["k0"], a["edge_nodes"], a["edge_L0"], a["median_L"])
+
+    attempt()   # the constants the library derived itself are accepted
+    bad_ptr = t["nbr_ptr"].copy(); bad_ptr[3] = bad_ptr[2] - 1
+    bad_ptr0 = t["nbr_ptr"].copy(); bad_ptr0[0] = 1
+    bad_col = t["nbr_idx"].copy(); bad_col[5] = tmpl.n
+    neg_col = t["nbr_idx"].copy(); neg_col[0] = -1
+    bad_edge = t["edge_nodes"].copy(); bad_edge[4, 1] = 10_000
+    bad_len = t["edge_L0"].copy(); bad_len[2] = 0.0
+    for over in (dict(nbr_ptr=bad_ptr), dict(nbr_ptr=bad_ptr0), dict(nbr_idx=bad_col), dict(nbr_idx=neg_col), dict(edge_nodes=bad_edge),
+                 dict(edge_L0=bad_len), dict(median_L=0.0), dict(median_L=float("nan"))):
+        with pytest.raises(sft.DshError, match="dsh_template_set"):
+            attempt(**over)
+    attempt()
+
+
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     """The boundary is a C ABI: include/defslam_hip.h compiles as C99 and as C++11, and a C program linked against the
     shared library creates and destroys a host-only context (what a cgo / JNI / N-API stub would do first)."""

@@ -70,8 +70,9 @@ def test_hip_matches_oracle_seeded(gpu_ctx, oracle_mod, cfg, pid):
 
 
 @pytest.mark.parametrize("shape,m,pid", [((10, 10), 300, 1), ((25, 20), 1000, 2), ((6, 17), 120, 3), ((8, 30), 400, 4), ((6, 41), 400, 5)])
-def test_normal_equations_match_oracle(gpu_ctx, oracle_mod, shape, m, pid):
-    """Residuals + Jacobians + H/b assembly in isolation."""
+def test_normal_equations_match_oracle(lab_ctx, oracle_mod, shape, m, pid):
+    """Residuals + Jacobians + H/b assembly in isolation, through the lab hook dsh_lab_sft_system."""
+    gpu_ctx = lab_ctx
     from defslam_amd import sft, synth
     tmpl = synth.make_grid_template(*shape)
     fr = synth.make_frame(tmpl, m, pid)
@@ -201,22 +202,25 @@ def test_one_batch_may_mix_solvers(gpu_ctx):
 
 
 @pytest.mark.parametrize("cfg,pid", [("smoke", 3), ("C2", 5)])
-def test_four_wavefront_launch_shape_matches_eight(gpu_ctx, oracle_mod, cfg, pid, monkeypatch):
+def test_four_wavefront_launch_shape_matches_eight(lab_ctx, oracle_mod, cfg, pid):
     """The throughput launch shape (4 wavefronts per problem, two ring rows per wave, chosen by the library once a batch
     holds >= 2 problems per CU) and the barrier version of the 8-wavefront shape run the same factorisation as the default
     (8 wavefronts, barrier-free dataflow steps): same LM trajectory as the oracle, vertices equal to rounding."""
     from defslam_amd import sft, synth
+    gpu_ctx = lab_ctx
     tmpl, fr = synth.make_problem(cfg, pid)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
     out = {}
-    for nw, df in (("8", "1"), ("4", "1"), ("8", "0")):
-        monkeypatch.setenv("DSH_SFT_WAVES", nw)     # read by dsh_sft_batch_upload
-        monkeypatch.setenv("DSH_SFT_DATAFLOW", df)  # 8 waves: barrier-free steps (default) or the barrier version
-        f = sft.frame_from_synth(fr)
-        inl = sft.DefPoseOptimization(gpu_ctx, f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
-        out[nw + df] = (f, inl)
-    monkeypatch.delenv("DSH_SFT_WAVES")
-    monkeypatch.delenv("DSH_SFT_DATAFLOW")
+    try:
+        for nw, df in (("8", "1"), ("4", "1"), ("8", "0")):
+            gpu_ctx.set_option("waves", int(nw))      # applied by the next dsh_sft_batch_upload
+            gpu_ctx.set_option("dataflow", int(df))   # barrier-free steps (default) or the barrier version (lab build only)
+            f = sft.frame_from_synth(fr)
+            inl = sft.DefPoseOptimization(gpu_ctx, f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+            out[nw + df] = (f, inl)
+    finally:
+        gpu_ctx.set_option("waves", 0)
+        gpu_ctx.set_option("dataflow", 1)
     f8, i8 = out["81"]
     f4, i4 = out["41"]
     fb, ib = out["80"]
@@ -233,29 +237,34 @@ def test_four_wavefront_launch_shape_matches_eight(gpu_ctx, oracle_mod, cfg, pid
 
 
 @pytest.mark.parametrize("waves", ["8", "4"])
-def test_dataflow_steps_equal_barrier_steps_bit_for_bit_under_load(gpu_ctx, waves, monkeypatch):
+def test_dataflow_steps_equal_barrier_steps_bit_for_bit_under_load(lab_ctx, waves):
     """The barrier-free factor steps hand tiles over through LDS flags; a missed dependency shows up as a (rare, load
     dependent) difference.  Many more problems than CUs, both launch shapes, compared bit for bit with the barrier
     version (same arithmetic order).  Regression test for the per-parity X flags (a wave one step ahead must not
     satisfy a reader of the previous step)."""
     from defslam_amd import sft, synth
+    gpu_ctx = lab_ctx
     tmpl = synth.make_grid_template(12, 14)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
     B = 900
-    monkeypatch.setenv("DSH_SFT_WAVES", waves)
+    gpu_ctx.set_option("waves", int(waves))
 
     def run(df):
-        monkeypatch.setenv("DSH_SFT_DATAFLOW", df)
+        gpu_ctx.set_option("dataflow", int(df))
         frames = [sft.frame_from_synth(synth.make_frame(tmpl, 260 + (p % 7) * 20, p)) for p in range(B)]
         inl = sft.DefPoseOptimizationBatch(gpu_ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
         return np.stack([f.nodes_xyz for f in frames]), np.array([f.trials for f in frames]), np.array(inl)
 
-    ref = run("0")
-    for _ in range(2):
-        cur = run("1")
-        np.testing.assert_array_equal(cur[1], ref[1])
-        np.testing.assert_array_equal(cur[2], ref[2])
-        np.testing.assert_array_equal(cur[0], ref[0])
+    try:
+        ref = run("0")
+        for _ in range(2):
+            cur = run("1")
+            np.testing.assert_array_equal(cur[1], ref[1])
+            np.testing.assert_array_equal(cur[2], ref[2])
+            np.testing.assert_array_equal(cur[0], ref[0])
+    finally:
+        gpu_ctx.set_option("waves", 0)
+        gpu_ctx.set_option("dataflow", 1)
 
 
 def test_mappoint_writeback_float32(gpu_ctx):
@@ -306,20 +315,24 @@ def test_full_size_properties(gpu_ctx, cfg):
 
 
 @pytest.mark.parametrize("cfg,pid", [("W16", 3), ("W12", 4)])
-def test_wide_tile_solver_agrees_with_the_band_solver(gpu_ctx, monkeypatch, cfg, pid):
-    """Half-bandwidths 128 < kd <= 256 run the left-looking MFMA tile factorisation (sft_wide.h); DSH_SFT_WIDE_OFF=1 selects the
+def test_wide_tile_solver_agrees_with_the_band_solver(lab_ctx, cfg, pid):
+    """Half-bandwidths 128 < kd <= 256 run the left-looking MFMA tile factorisation (sft_wide.h); the lab option "wide_off" selects the
     row-major band solver for the same problem.  Both are Cholesky factorisations of the same matrix in different summation
     orders: identical Levenberg-Marquardt trajectories, vertices to 1e-9."""
     from defslam_amd import sft, synth
+    gpu_ctx = lab_ctx
     tmpl, fr = synth.make_problem(cfg, pid)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
     fw = sft.frame_from_synth(fr)
     inl_w = sft.DefPoseOptimization(gpu_ctx, fw, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     _, counts = gpu_ctx.problem_info(0)
     assert 128 < counts[6] <= 256
-    monkeypatch.setenv("DSH_SFT_WIDE_OFF", "1")
-    fb = sft.frame_from_synth(fr)
-    inl_b = sft.DefPoseOptimization(gpu_ctx, fb, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    gpu_ctx.set_option("wide_off", 1)
+    try:
+        fb = sft.frame_from_synth(fr)
+        inl_b = sft.DefPoseOptimization(gpu_ctx, fb, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    finally:
+        gpu_ctx.set_option("wide_off", 0)
     assert fw.status == 0 and fb.status == 0
     assert (fw.iters, fw.trials, inl_w) == (fb.iters, fb.trials, inl_b)
     np.testing.assert_allclose(fw.trace[:fw.iters, :6], fb.trace[:fb.iters, :6], rtol=1e-7)
@@ -327,10 +340,11 @@ def test_wide_tile_solver_agrees_with_the_band_solver(gpu_ctx, monkeypatch, cfg,
     np.testing.assert_allclose(fw.pose7, fb.pose7, rtol=0, atol=1e-9)
 
 
-def test_assembly_only_launches_leave_the_batch_intact(gpu_ctx):
-    """dsh_sft_batch_assemble_timed (measurement aid of the assembly roofline) runs a kernel of its own that does one linearisation +
-    assembly per problem on the batch's buffers: a full run afterwards gives the same results bit for bit."""
+def test_assembly_only_launches_leave_the_batch_intact(lab_ctx):
+    """dsh_lab_sft_assemble_timed (measurement aid of the assembly roofline, lab build) runs a kernel of its own that does one
+    linearisation + assembly per problem on the batch's buffers: a full run afterwards gives the same results bit for bit."""
     from defslam_amd import sft, synth
+    gpu_ctx = lab_ctx
     tmpl, _ = synth.make_problem("smoke", 0)
     gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
     frames = [sft.frame_from_synth(synth.make_frame(tmpl, 300, p)) for p in range(6)]

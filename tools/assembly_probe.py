@@ -1,11 +1,11 @@
-"""Assembly-only launches of a C2 batch (dsh_sft_batch_assemble_timed), for rocprofv3 PMC passes: one full run, then `reps` launches
+"""Assembly-only launches of a C2 batch (dsh_lab_sft_assemble_timed), for rocprofv3 PMC passes: one full run, then `reps` launches
 that do one linearisation + normal-equation assembly per problem."""
 import sys
 sys.path.insert(0, ".")
 from defslam_amd import sft, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-ctx = sft.Context(0)
+ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 rows, cols, m = synth.CONFIGS["C2"]
 tmpl = synth.make_grid_template(rows, cols)
 ctx.template_build(tmpl.xyz0, tmpl.facets)

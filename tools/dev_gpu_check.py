@@ -2,7 +2,7 @@ import sys, time, numpy as np
 sys.path.insert(0, '.')
 import oracle
 from defslam_amd import synth, sft
-ctx = sft.Context(0)
+ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 for cfg in ["smoke", "C2"]:
     tmpl, fr = synth.make_problem(cfg)
     tc = oracle.template_build(tmpl.xyz0, tmpl.facets)

@@ -2,7 +2,7 @@
 import os, sys, numpy as np
 sys.path.insert(0, '.')
 from defslam_amd import synth, sft
-ctx = sft.Context(0)
+ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -11,8 +11,8 @@ rows, cols, m = synth.CONFIGS[cfg]
 tmpl = synth.make_grid_template(rows, cols)
 ctx.template_build(tmpl.xyz0, tmpl.facets)
 def run(df):
-    os.environ["DSH_SFT_WAVES"] = waves
-    os.environ["DSH_SFT_DATAFLOW"] = df
+    ctx.set_option("waves", int(waves))
+    ctx.set_option("dataflow", int(df))
     frames = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(B)]
     inl = sft.DefPoseOptimizationBatch(ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     return np.stack([f.nodes_xyz for f in frames]), np.array([f.trials for f in frames]), np.array(inl)

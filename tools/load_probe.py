@@ -2,7 +2,7 @@
 import sys, numpy as np
 sys.path.insert(0, '.')
 from defslam_amd import synth, sft
-ctx = sft.Context(0)
+ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 rows, cols, m = synth.CONFIGS["C2"]
 tmpl = synth.make_grid_template(rows, cols)
 ctx.template_build(tmpl.xyz0, tmpl.facets)

@@ -3,7 +3,9 @@ sys.path.insert(0, '.')
 from defslam_amd import synth, sft
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-ctx = sft.Context(0)
+WAVES = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
+ctx.set_option("waves", WAVES)
 rows, cols, m = synth.CONFIGS[cfg]
 tmpl = synth.make_grid_template(rows, cols)
 ctx.template_build(tmpl.xyz0, tmpl.facets)
@@ -12,6 +14,9 @@ ctx.batch_upload(frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
 ctx.batch_run(); ctx.synchronize()
 ms = ctx.batch_run_timed(3) / 3
 it, tr = ctx.batch_counts()
-ph = ctx.phase_ms(0)
+try:
+    ph = ctx.phase_ms(0)
+except sft.DshError:
+    ph = {}   # built without EXTRA=-DSFT_PHASE_TIMERS
 print(f"{cfg} B={B}: {ms:.2f} ms/launch, iters {it} trials {tr}, per-trial {ms/ (tr/B):.3f} ms; single-problem it/s {it/B/(ms*1e-3):.0f}")
 print(" phases of problem 0 (ms):", {k: round(v, 2) for k, v in ph.items()}, "sum", round(sum(ph.values()), 2))

@@ -6,13 +6,12 @@ TAG=${1:-mix}; B=${2:-2048}; W=${3:-}
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-[ -n "$W" ] && export DSH_SFT_WAVES=$W
 i=0
 SETS=${PMC_SETS:-"SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_F64,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR,SQ_INSTS_SMEM SQ_WAVE_CYCLES,SQ_WAVES,SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY,SQ_WAIT_ANY,SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_MISC,SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_SCA,SQ_ACTIVE_INST_VMEM,SQ_INSTS_BRANCH"}
 for set in $SETS; do
   set=${set//,/ }
   i=$((i+1))
-  (cd /tmp && PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $OLDPWD/tools/phase_times.py C2 $B > $OUT/p$i.log 2>&1)
+  (cd /tmp && PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $OLDPWD/tools/phase_times.py C2 $B $W > $OUT/p$i.log 2>&1)
 done
 python - <<PY
 import csv, glob, collections
