@@ -9,7 +9,7 @@ from scipy.spatial.transform import Rotation
 
 from conftest import oracle_args
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sft_*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sft_*.npz")) if "sft_C5_" not in os.path.basename(p))
 
 
 def _load(path, oracle):
@@ -198,3 +198,20 @@ def test_curvature_and_stretch_gradients_match_finite_differences(oracle_mod):
         d[k] = 1e-7
         fd = (reg_cost(d) - reg_cost(-d)) / 2e-7
         assert -2 * b_reg[6 + k] == pytest.approx(fd, rel=1e-4, abs=1e-7)
+
+
+def test_c5_fixture_inputs_are_still_what_synth_generates():
+    """tests/golden/sft_C5_p*.npz hold oracle OUTPUTS for problems whose inputs are regenerated from seeds: a change of the
+    generator must fail here (CPU), not silently compare different problems on the GPU box."""
+    import sys
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, here)
+    from make_golden_c5 import input_digest
+    from defslam_amd import synth
+    paths = sorted(glob.glob(os.path.join(here, "sft_C5_p*.npz")))
+    assert paths, "full-size C5 fixtures are missing (tests/golden/make_golden_c5.py)"
+    for p in paths:
+        g = np.load(p)
+        tmpl, fr = synth.make_problem("C5", int(g["problem_id"]))
+        assert input_digest(tmpl, fr) == str(g["input_sha256"])
+        assert int(g["out_dims"][0]) == 6006 and g["out_xyz"].shape == (2000, 3) and g["out_chi2_obs"].shape == (4000,)

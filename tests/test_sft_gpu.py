@@ -17,7 +17,9 @@ from conftest import oracle_args
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sft_*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sft_*.npz")) if "sft_C5_" not in os.path.basename(p))
+# full-size stress problems (BASELINE configs[4]): outputs of the C oracle, inputs regenerated from the seeds (make_golden_c5.py)
+GOLDEN_C5 = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sft_C5_p*.npz")))
 VERT_TOL = 1e-7
 POSE_TOL = 1e-8
 
@@ -52,6 +54,54 @@ def test_hip_matches_golden_vectors(gpu_ctx, path):
     f, inl = _solve_gpu(gpu_ctx, g["xyz0"], g["facets"], g, tuple(g["regs"]), int(g["layers"]))
     _compare(f, inl, g["out_xyz"], g["out_pose7"], g["out_trace"], g["out_outlier"], float(g["out_rep_error"]), int(g["out_inliers"]))
     np.testing.assert_allclose(f.chi2_obs, g["out_chi2_obs"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("path", GOLDEN_C5, ids=[os.path.basename(p) for p in GOLDEN_C5])
+def test_hip_matches_golden_vectors_full_size_c5(gpu_ctx, path):
+    """BASELINE.json configs[4] per problem: 2000-node template (40x50), 4000 matches, D = 6006, half-bandwidth 248 -> the wide
+    tile solver at full size against the C oracle's dense solve (15 minutes of CPU per problem, done once in the build
+    container: tests/golden/make_golden_c5.py).  Same LM trajectory, vertices / pose / per-observation chi2 / outliers."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden_c5 import input_digest
+    from defslam_amd import synth
+    g = np.load(path)
+    pid = int(g["problem_id"])
+    tmpl, fr = synth.make_problem("C5", pid)
+    assert input_digest(tmpl, fr) == str(g["input_sha256"]), "defslam_amd/synth.py no longer generates the inputs this fixture was computed for"
+    f, inl = _solve_gpu(gpu_ctx, tmpl.xyz0, tmpl.facets, dict(Tcw=fr.Tcw, K=fr.K, n_frame=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary,
+                                                              obs_uv=fr.obs_uv, obs_invsig2=fr.obs_invsig2, xyz=fr.xyz), tuple(g["regs"]))
+    assert f.dim == int(g["out_dims"][0]) == 6006 and 128 < f.half_bandwidth <= 256
+    _compare(f, inl, g["out_xyz"], g["out_pose7"], g["out_trace"], g["out_outlier"], float(g["out_rep_error"]), int(g["out_inliers"]))
+    assert f.trials == int(g["out_trials"])
+    np.testing.assert_allclose(f.chi2_obs, g["out_chi2_obs"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(f.Tcw, g["out_Tcw"], atol=2e-7)
+
+
+def test_c5_batch_of_16_equals_singles_bit_for_bit(gpu_ctx):
+    """BASELINE.json configs[4]: 16 concurrent 2000-node x 4000-match problems in ONE launch give, problem by problem, exactly
+    the bits of 16 one-at-a-time solves (and problems 0/1 of them are the oracle-checked fixtures above)."""
+    from defslam_amd import sft, synth
+    rows, cols, m = synth.CONFIGS["C5"]
+    tmpl = synth.make_grid_template(rows, cols)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    frames = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(16)]
+    inl = sft.DefPoseOptimizationBatch(gpu_ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    assert all(f.status == 0 for f in frames)
+    for p in range(16):
+        one = sft.frame_from_synth(synth.make_frame(tmpl, m, p))
+        i1 = sft.DefPoseOptimization(gpu_ctx, one, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        assert (i1, one.iters, one.trials) == (inl[p], frames[p].iters, frames[p].trials)
+        np.testing.assert_array_equal(one.nodes_xyz, frames[p].nodes_xyz)
+        np.testing.assert_array_equal(one.pose7, frames[p].pose7)
+        np.testing.assert_array_equal(one.mvbOutlier, frames[p].mvbOutlier)
+        np.testing.assert_array_equal(one.chi2_obs, frames[p].chi2_obs)
+        assert one.rep_error_f64 == frames[p].rep_error_f64
+    for path in GOLDEN_C5:   # the batch members with a fixture agree with the oracle as well
+        g = np.load(path)
+        f = frames[int(g["problem_id"])]
+        assert f.iters == int(g["out_iters"]) and f.trials == int(g["out_trials"])
+        assert np.abs(f.nodes_xyz - g["out_xyz"]).max() <= VERT_TOL * np.abs(g["out_xyz"]).max()
 
 
 @pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0), ("W12", 1), ("W16", 2), ("B272", 3)])
