@@ -7,12 +7,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/defslam_hip.h"
 #include "dsh_ctx.h"
 #include "dsh_template.h"
+#include "sft_pack.h"
 #include "sft_problem.h"
 
 #ifdef DSH_LAB
@@ -30,71 +32,13 @@ namespace {
 constexpr int kNB = 32;  // must match NB in sft_kernels.hip
 constexpr int kTS = 16, kBT = 8, kWB = 16;  // must match TS / BT in sft_kernels.hip and WB in sft_wide.h
 
-// ---- pose conversions at the float32 boundary (Converter.cc:35-66, se3quat.h:58-64,269-285) -------
-void pose7_from_Tcw(const float* T, double* p) {
-  double R[9];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) R[3 * i + j] = (double)T[4 * i + j];
-  double q[4];
-  double tr = R[0] + R[4] + R[8];
-  if (tr > 0.0) {
-    double t = std::sqrt(tr + 1.0);
-    q[3] = 0.5 * t;
-    t = 0.5 / t;
-    q[0] = (R[7] - R[5]) * t;
-    q[1] = (R[2] - R[6]) * t;
-    q[2] = (R[3] - R[1]) * t;
-  } else {
-    int i = 0;
-    if (R[4] > R[0]) i = 1;
-    if (R[8] > R[4 * i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-    q[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-  }
-  if (q[3] < 0)
-    for (double& c : q) c = -c;
-  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (double& c : q) c /= nrm;
-  p[0] = (double)T[3];
-  p[1] = (double)T[7];
-  p[2] = (double)T[11];
-  p[3] = q[0];
-  p[4] = q[1];
-  p[5] = q[2];
-  p[6] = q[3];
-}
+using dsh::Tcw_from_pose7;
 
-void Tcw_from_pose7(const double* p, float* T) {
-  const double x = p[3], y = p[4], z = p[5], w = p[6];
-  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
-  for (int i = 0; i < 3; i++) {
-    for (int j = 0; j < 3; j++) T[4 * i + j] = (float)R[3 * i + j];
-    T[4 * i + 3] = (float)p[i];
-  }
-  T[12] = T[13] = T[14] = 0.f;
-  T[15] = 1.f;
-}
-
-// ---- one packed problem on the host ---------------------------------------------------------------
+// ---- one packed problem on the host: the shared structure (graph) + the per-frame lists + the scalars of the device record
 struct Packed {
-  SftDev h{};                   // sizes + scalars (pointers filled at upload)
-  std::vector<int32_t> act, obs_nodes, ref_node, star_node, str_nodes, blk_rc, blk_ptr, diag_blk, off_blk;
-  std::vector<uint32_t> contrib;
-  std::vector<int32_t> tmask;        // tile mode 1: per tile row, bit d = tile (I, I-d) structurally non-zero
-  std::vector<int32_t> blk_hdr;      // 4 per block in processing order (diagonal blocks of nodes 0..nA-1, then the off-diagonal blocks): start, count, block row, block col
-  std::vector<double> cfac;          // 2 per contribution: constant factors of curvature / stretch contributions (H factor, b factor)
-  std::vector<double> obs_bary, obs_uv, obs_w, star_sL, str_L0, xyz_init;
-  double pose_init[7];
-  int n_curv_ref = 0;           // curvature edges in the reference's (unfused) count
-  int max_iters = 0;
-  std::vector<int32_t> actnode; // compact index -> node
+  SftDev h{};                          // sizes + scalars (pointers filled at upload)
+  dsh::SftGraph* g = nullptr;          // owned by the context's graph cache
+  dsh::SftFramePack f;
 };
 
 // Host buffer of a context that the copy engine reads / writes directly: page-locked for a GPU context (hipMemcpyAsync
@@ -144,9 +88,11 @@ struct dsh_ctx : dsh_ctx_base {
   char* d_tmpl = nullptr;
   size_t d_tmpl_bytes = 0;
   struct {
-    const double *xyz0, *nbr_w, *nbr_c, *nbr_sumw, *k0;
+    const double *xyz0, *nbr_w, *nbr_sumw, *k0;
     const int32_t *nbr_ptr, *nbr_idx;
   } dt{};
+  // structure of the normal equations per active set of the current template (sft_pack.h), device-resident, built on first use
+  std::vector<std::unique_ptr<dsh::SftGraph>> graphs;
   // batch
   int B = 0;
   std::vector<Packed> packed;
@@ -170,7 +116,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int asm_direct = 0; } opt;
 };
 
 namespace {
@@ -185,9 +131,18 @@ int fail(dsh_ctx* c, int code, const std::string& m) {
     if (e__ != hipSuccess) return fail(c, DSH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+void drop_graphs(dsh_ctx* c) {
+  if (!c->host_only && c->stream) (void)hipStreamSynchronize(c->stream);   // a batch in flight may still read them
+  for (auto& g : c->graphs)
+    if (g->d_base) (void)hipFree(g->d_base);
+  c->graphs.clear();
+  c->packed.clear();
+}
+
 int upload_template(dsh_ctx* c) {
   c->B = 0;
   c->ran = false;
+  drop_graphs(c);
   if (c->host_only) return DSH_OK;
   const dsh::TemplateHost& t = c->tmpl;
   Arena a;
@@ -195,7 +150,6 @@ int upload_template(dsh_ctx* c) {
   const size_t o_ptr = a.take(sizeof(int32_t) * (t.n + 1));
   const size_t o_idx = a.take(sizeof(int32_t) * t.nbr_idx.size());
   const size_t o_w = a.take(sizeof(double) * t.nbr_w.size());
-  const size_t o_c = a.take(sizeof(double) * t.nbr_c.size());
   const size_t o_sw = a.take(sizeof(double) * t.n);
   const size_t o_k0 = a.take(sizeof(double) * t.n);
   if (c->d_tmpl) { (void)hipFree(c->d_tmpl); c->d_tmpl = nullptr; }
@@ -206,7 +160,6 @@ int upload_template(dsh_ctx* c) {
   std::memcpy(&st[o_ptr], t.nbr_ptr.data(), sizeof(int32_t) * (t.n + 1));
   std::memcpy(&st[o_idx], t.nbr_idx.data(), sizeof(int32_t) * t.nbr_idx.size());
   std::memcpy(&st[o_w], t.nbr_w.data(), sizeof(double) * t.nbr_w.size());
-  std::memcpy(&st[o_c], t.nbr_c.data(), sizeof(double) * t.nbr_c.size());
   std::memcpy(&st[o_sw], t.nbr_sumw.data(), sizeof(double) * t.n);
   std::memcpy(&st[o_k0], t.k0.data(), sizeof(double) * t.n);
   HIPCHK(c, hipMemcpy(c->d_tmpl, st.data(), a.size, hipMemcpyHostToDevice));
@@ -214,191 +167,10 @@ int upload_template(dsh_ctx* c) {
   c->dt.nbr_ptr = (const int32_t*)(c->d_tmpl + o_ptr);
   c->dt.nbr_idx = (const int32_t*)(c->d_tmpl + o_idx);
   c->dt.nbr_w = (const double*)(c->d_tmpl + o_w);
-  c->dt.nbr_c = (const double*)(c->d_tmpl + o_c);
   c->dt.nbr_sumw = (const double*)(c->d_tmpl + o_sw);
   c->dt.k0 = (const double*)(c->d_tmpl + o_k0);
   c->B = 0;
   c->ran = false;
-  return DSH_OK;
-}
-
-// Build the graph of DefOptimizer.cc:293-507 as flat arrays + per-block gather lists.
-int pack_problem(const dsh::TemplateHost& t, const dsh_sft_frame& f, bool wide_off, Packed& P, std::string& err) {
-  const int n = t.n, M = f.M;
-  if (M <= 0 || !f.obs_nodes || !f.obs_bary || !f.obs_uv || !f.obs_invsig2 || !f.xyz || !f.Tcw) { err = "empty or null frame"; return DSH_ERR_ARG; }
-  if (f.n_frame <= 0 || f.max_iters < 0 || f.max_iters > DSH_MAX_ITERS) { err = "bad n_frame/max_iters"; return DSH_ERR_ARG; }
-  for (int i = 0; i < 3 * M; i++)
-    if (f.obs_nodes[i] < 0 || f.obs_nodes[i] >= n) { err = "observation node id out of range"; return DSH_ERR_ARG; }
-  std::vector<uint8_t> viewed(n, 0), opt(n, 0);
-  for (int i = 0; i < 3 * M; i++) viewed[f.obs_nodes[i]] = 1;
-  opt = viewed;
-  if (f.neighbour_layers >= 1)  // always the 1-ring of the viewed set (DefOptimizer.cc:388-406)
-    for (int i = 0; i < n; i++)
-      if (viewed[i])
-        for (int p = t.nbr_ptr[i]; p < t.nbr_ptr[i + 1]; p++) opt[t.nbr_idx[p]] = 1;
-  P.act.assign(n, -1);
-  P.actnode.clear();
-  for (int i = 0; i < n; i++)
-    if (opt[i]) { P.act[i] = (int)P.actnode.size(); P.actnode.push_back(i); }
-  const int nA = (int)P.actnode.size();
-
-  P.obs_nodes.assign(f.obs_nodes, f.obs_nodes + 3 * M);
-  P.obs_bary.assign(f.obs_bary, f.obs_bary + 3 * M);
-  P.obs_uv.assign(f.obs_uv, f.obs_uv + 2 * M);
-  P.obs_w.resize(M);
-  for (int i = 0; i < M; i++) P.obs_w[i] = f.obs_invsig2[i] / (double)f.n_frame;  // DefOptimizer.cc:340
-  P.ref_node.clear();
-  for (int i = 0; i < n; i++)
-    if (viewed[i]) P.ref_node.push_back(i);
-  // curvature "stars": the reference adds deg(i) copies of the same residual divided by the incident
-  // edge lengths (DefOptimizer.cc:427-461); they are fused here into one record with sum(1/L^2).
-  P.star_node.clear();
-  P.star_sL.clear();
-  P.n_curv_ref = 0;
-  for (int i = 0; i < n; i++)
-    if (opt[i] && !t.boundary[i]) {
-      double s = 0.0;
-      for (int p = t.inc_ptr[i]; p < t.inc_ptr[i + 1]; p++) { const double il = 1.0 / t.edge_L0[t.inc_edge[p]]; s += il * il; P.n_curv_ref++; }
-      if (t.nbr_ptr[i + 1] - t.nbr_ptr[i] > 14) { err = "node degree > 14 unsupported"; return DSH_ERR_ARG; }
-      P.star_node.push_back(i);
-      P.star_sL.push_back(s);
-    }
-  // stretch edges: mesh edges incident to an active node, creation order (DefOptimizer.cc:468-507)
-  P.str_nodes.clear();
-  P.str_L0.clear();
-  for (int e = 0; e < t.E; e++) {
-    const int a = t.edge_nodes[2 * e], b = t.edge_nodes[2 * e + 1];
-    if (opt[a] || opt[b]) { P.str_nodes.push_back(a); P.str_nodes.push_back(b); P.str_L0.push_back(t.edge_L0[e]); }
-  }
-  const int V = (int)P.ref_node.size(), S = (int)P.star_node.size(), Es = (int)P.str_L0.size();
-
-  // ---- block pattern + gather lists ---------------------------------------------------------
-  // per block row: sorted list of block columns (<= row) with contribution counts
-  struct Col { int c; int cnt; int off; };
-  std::vector<std::vector<Col>> rows(nA);
-  auto touch = [&](int bi, int bj) -> Col& {
-    auto& r = rows[bi];
-    for (auto& cc : r)
-      if (cc.c == bj) return cc;
-    r.push_back({bj, 0, 0});
-    return r.back();
-  };
-  // pass over every edge twice: count, then fill (the emission order is the reference's edge order:
-  // observations, temporal, curvature, stretching -- DefOptimizer.cc:293-507)
-  auto for_each_contrib = [&](auto&& emit) {
-    for (int m = 0; m < M; m++) {
-      int a[3];
-      for (int s = 0; s < 3; s++) a[s] = P.act[P.obs_nodes[3 * m + s]];
-      for (int s = 0; s < 3; s++)
-        for (int u = 0; u < 3; u++)
-          if (a[s] >= 0 && a[u] >= 0 && (a[s] > a[u] || (s == u))) emit(a[s], a[u], SFT_REC(SFT_KIND_OBS, s, u, m));
-    }
-    for (int v = 0; v < V; v++) { const int a = P.act[P.ref_node[v]]; emit(a, a, SFT_REC(SFT_KIND_REF, 0, 0, v)); }
-    for (int s = 0; s < S; s++) {
-      const int nd = P.star_node[s];
-      const int deg = t.nbr_ptr[nd + 1] - t.nbr_ptr[nd];
-      int a[16];
-      a[0] = P.act[nd];
-      for (int j = 0; j < deg; j++) a[1 + j] = P.act[t.nbr_idx[t.nbr_ptr[nd] + j]];
-      for (int p = 0; p <= deg; p++)
-        for (int q = 0; q <= deg; q++)
-          if (a[p] >= 0 && a[q] >= 0 && (a[p] > a[q] || p == q)) emit(a[p], a[q], SFT_REC(SFT_KIND_STAR, p, q, s));
-    }
-    for (int e = 0; e < Es; e++) {
-      const int a[2] = {P.act[P.str_nodes[2 * e]], P.act[P.str_nodes[2 * e + 1]]};
-      for (int p = 0; p < 2; p++)
-        for (int q = 0; q < 2; q++)
-          if (a[p] >= 0 && a[q] >= 0 && (a[p] > a[q] || p == q)) emit(a[p], a[q], SFT_REC(SFT_KIND_STR, p, q, e));
-    }
-  };
-  for (int a = 0; a < nA; a++) touch(a, a);  // every active node owns a diagonal block
-  for_each_contrib([&](int bi, int bj, uint32_t) { touch(bi, bj).cnt++; });
-  int nblk = 0, bwn = 0;
-  size_t total = 0;
-  for (int a = 0; a < nA; a++) {
-    std::sort(rows[a].begin(), rows[a].end(), [](const Col& x, const Col& y) { return x.c < y.c; });
-    for (auto& cc : rows[a]) { cc.off = (int)total; total += cc.cnt; cc.cnt = 0; nblk++; bwn = std::max(bwn, a - cc.c); }
-  }
-  if (total >= (1u << 22) * 64ull) { err = "too many contributions"; return DSH_ERR_ARG; }
-  if ((size_t)std::max(M, std::max(S, Es)) >= (1u << 22)) { err = "edge index exceeds 22 bits"; return DSH_ERR_ARG; }
-  P.contrib.assign(total, 0u);
-  for_each_contrib([&](int bi, int bj, uint32_t rec) {
-    auto& r = rows[bi];
-    // rows are sorted now; binary search
-    int lo = 0, hi = (int)r.size() - 1;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (r[mid].c < bj) lo = mid + 1; else hi = mid; }
-    Col& cc = r[lo];
-    P.contrib[cc.off + cc.cnt++] = rec;
-  });
-  P.blk_rc.clear();
-  P.blk_ptr.clear();
-  for (int a = 0; a < nA; a++)
-    for (auto& cc : rows[a]) { P.blk_rc.push_back(a); P.blk_rc.push_back(cc.c); P.blk_ptr.push_back(cc.off); }
-  P.blk_ptr.push_back((int)total);
-  P.diag_blk.assign(nA, -1);
-  P.off_blk.clear();
-  for (int q = 0; q < nblk; q++) {
-    if (P.blk_rc[2 * q] == P.blk_rc[2 * q + 1]) P.diag_blk[P.blk_rc[2 * q]] = q; else P.off_blk.push_back(q);
-  }
-
-  P.xyz_init.assign(f.xyz, f.xyz + 3 * (size_t)n);
-  pose7_from_Tcw(f.Tcw, P.pose_init);
-  {  // which 16x16 tiles of the band hold an element of some 3x3 block (30 % of the C2 band is structurally zero)
-    const int Dn_ = 3 * nA, nT_ = ((Dn_ + kNB - 1) / kNB) * kNB / kTS;
-    P.tmask.assign((size_t)nT_ + SFT_H_PAD_TILE_ROWS, 0);
-    for (int I = 0; I < nT_; I++) P.tmask[I] = 1;   // diagonal tiles (incl. the identity padding of the last one)
-    for (int q = 0; q < nblk; q++) {
-      const int bi = P.blk_rc[2 * q], bj = P.blk_rc[2 * q + 1];
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
-          const int r = 3 * bi + a, cc = 3 * bj + b;
-          if (cc > r) continue;
-          const int d = (r >> 4) - (cc >> 4);
-          if (d < 31) P.tmask[r >> 4] |= 1 << d;
-        }
-    }
-  }
-  SftDev& h = P.h;
-  h.n = n; h.nA = nA; h.Dn = 3 * nA; h.kd = 3 * bwn + 2; h.ldh = h.kd + 1;
-  // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; the lab option "wide_off"
-  // keeps the row-major band solver for A/B runs), row-major band otherwise
-  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : ((h.kd <= kTS * kWB && !wide_off) ? 2 : 0);
-  h.wbt = h.tile_mode == 1 ? kBT : (h.tile_mode == 2 ? (h.kd + kTS - 1) / kTS : 0);
-  h.tpr = h.tile_mode ? h.wbt + 1 : 0;
-  h.M = M; h.V = V; h.S = S; h.Es = Es; h.nblk = nblk; h.max_iters = f.max_iters; h.mode = 0;
-  h.fx = f.K[0]; h.fy = f.K[1]; h.cx = f.K[2]; h.cy = f.K[3];
-  h.w_ref = f.reg_temp / std::pow(t.median_L, 2);              // DefOptimizer.cc:378
-  h.w_curv = f.reg_lap / (double)nA;                           // :458  (|OptLap|)
-  h.w_str = Es > 0 ? f.reg_inex / (double)Es : 0.0;            // :497  (|medges|)
-  const float deltaMono = (float)std::sqrt(5.991);             // :286
-  h.hub_delta = (double)deltaMono;
-  h.hub_dsqr = h.hub_delta * h.hub_delta;
-  P.max_iters = f.max_iters;
-  // ---- constants of the gather pass: one header per block and, per contribution, the factors that do not depend on the
-  // state (curvature: w_curv * sL_e * c_s * c_t and w_curv * sL_e * c_s; stretch: +-w_str), so that the assembly kernel
-  // needs one dependent load level (record -> Jacobian record) instead of four (record -> star node -> neighbour list -> weight)
-  P.blk_hdr.clear();
-  P.blk_hdr.reserve(4 * (size_t)nblk);
-  for (int a = 0; a < nA; a++) {
-    const int q = P.diag_blk[a];
-    P.blk_hdr.insert(P.blk_hdr.end(), {P.blk_ptr[q], P.blk_ptr[q + 1] - P.blk_ptr[q], a, a});
-  }
-  for (int q : P.off_blk) P.blk_hdr.insert(P.blk_hdr.end(), {P.blk_ptr[q], P.blk_ptr[q + 1] - P.blk_ptr[q], P.blk_rc[2 * q], P.blk_rc[2 * q + 1]});
-  P.cfac.assign(2 * total, 0.0);
-  for (size_t p = 0; p < total; p++) {
-    const uint32_t rec = P.contrib[p], kind = rec >> 30, s = (rec >> 26) & 15u, u = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
-    if (kind == SFT_KIND_STAR) {
-      const int base = t.nbr_ptr[P.star_node[e]];
-      const double cs = (s == 0) ? 1.0 : t.nbr_c[base + s - 1];
-      const double ct = (u == 0) ? 1.0 : t.nbr_c[base + u - 1];
-      const double wt = h.w_curv * P.star_sL[e];
-      P.cfac[2 * p] = wt * (cs * ct);
-      P.cfac[2 * p + 1] = wt * cs;
-    } else if (kind == SFT_KIND_STR) {
-      P.cfac[2 * p] = ((s == 0) == (u == 0)) ? h.w_str : -h.w_str;
-      P.cfac[2 * p + 1] = (s == 0) ? h.w_str : -h.w_str;
-    }
-  }
   return DSH_OK;
 }
 
@@ -407,6 +179,69 @@ size_t reserve(Arena& a, const std::vector<T>& v) { return a.take(sizeof(T) * v.
 template <class T>
 void put(char* st, size_t off, const std::vector<T>& v) {
   if (!v.empty()) std::memcpy(st + off, v.data(), sizeof(T) * v.size());
+}
+
+// The graph of the frame's active set: cached per template, uploaded once, shared by every problem that has it.
+int graph_for(dsh_ctx* c, const std::vector<uint8_t>& opt, dsh::SftGraph** out, std::string& err) {
+  uint64_t h = 1469598103934665603ull;
+  for (uint8_t b : opt) { h ^= b; h *= 1099511628211ull; }
+  for (auto& g : c->graphs)
+    if (g->opt_hash == h && g->opt == opt) { *out = g.get(); return DSH_OK; }
+  if (c->graphs.size() >= 64) {   // a long sequence with an ever-changing view: start over (rebuilding costs one slow frame)
+    const int Bkeep = c->B;
+    drop_graphs(c);
+    c->B = Bkeep;
+  }
+  std::unique_ptr<dsh::SftGraph> g(new dsh::SftGraph());
+  const int rc = dsh::build_graph(c->tmpl, opt, *g, err);
+  if (rc != DSH_OK) return rc;
+  if (!c->host_only) {
+    Arena a;
+    auto& o = g->o;
+    o.act = reserve(a, g->act); o.actnode = reserve(a, g->actnode); o.star_node = reserve(a, g->star_node); o.star_sL = reserve(a, g->star_sL);
+    o.str_nodes = reserve(a, g->str_nodes); o.str_L0 = reserve(a, g->str_L0); o.off_ptr = reserve(a, g->off_ptr); o.off_rc = reserve(a, g->off_rc);
+    o.sh_ptr = reserve(a, g->sh_ptr); o.sh_rec = reserve(a, g->sh_rec); o.sh_cf = reserve(a, g->sh_cf); o.tmask = reserve(a, g->tmask);
+    std::vector<char> st(a.size, 0);
+    put(st.data(), o.act, g->act); put(st.data(), o.actnode, g->actnode); put(st.data(), o.star_node, g->star_node); put(st.data(), o.star_sL, g->star_sL);
+    put(st.data(), o.str_nodes, g->str_nodes); put(st.data(), o.str_L0, g->str_L0); put(st.data(), o.off_ptr, g->off_ptr); put(st.data(), o.off_rc, g->off_rc);
+    put(st.data(), o.sh_ptr, g->sh_ptr); put(st.data(), o.sh_rec, g->sh_rec); put(st.data(), o.sh_cf, g->sh_cf); put(st.data(), o.tmask, g->tmask);
+    if (hipMalloc((void**)&g->d_base, a.size) != hipSuccess) { err = "out of device memory (graph)"; return DSH_ERR_HIP; }
+    g->d_bytes = a.size;
+    if (hipMemcpy(g->d_base, st.data(), a.size, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g->d_base); err = "graph upload failed"; return DSH_ERR_HIP; }
+  }
+  *out = g.get();
+  c->graphs.push_back(std::move(g));
+  return DSH_OK;
+}
+
+// Build the graph of DefOptimizer.cc:293-507 as flat arrays: shared structure from the cache, per-frame lists, scalars.
+int pack_problem(dsh_ctx* c, const dsh_sft_frame& f, bool wide_off, Packed& P, std::string& err) {
+  const dsh::TemplateHost& t = c->tmpl;
+  std::vector<uint8_t> viewed, opt;
+  int rc = dsh::frame_active_set(t, f, viewed, opt, err);
+  if (rc != DSH_OK) return rc;
+  rc = graph_for(c, opt, &P.g, err);
+  if (rc != DSH_OK) return rc;
+  const dsh::SftGraph& g = *P.g;
+  rc = dsh::pack_frame(t, g, f, viewed, P.f, err);
+  if (rc != DSH_OK) return rc;
+  SftDev& h = P.h;
+  h = SftDev{};
+  h.n = t.n; h.nA = g.nA; h.Dn = 3 * g.nA; h.kd = g.kd; h.ldh = h.kd + 1;
+  // solver per half-bandwidth: register-window tiles (<= 128), left-looking wide tiles (<= 256; the lab option "wide_off"
+  // keeps the row-major band solver for A/B runs), row-major band otherwise
+  h.tile_mode = (h.kd <= kTS * kBT) ? 1 : ((h.kd <= kTS * kWB && !wide_off) ? 2 : 0);
+  h.wbt = h.tile_mode == 1 ? kBT : (h.tile_mode == 2 ? (h.kd + kTS - 1) / kTS : 0);
+  h.tpr = h.tile_mode ? h.wbt + 1 : 0;
+  h.M = f.M; h.V = P.f.V; h.S = g.S; h.Es = g.Es; h.noff = g.noff; h.max_iters = f.max_iters; h.mode = 0;
+  h.fx = f.K[0]; h.fy = f.K[1]; h.cx = f.K[2]; h.cy = f.K[3];
+  h.w_ref = f.reg_temp / std::pow(t.median_L, 2);              // DefOptimizer.cc:378
+  h.w_curv = f.reg_lap / (double)g.nA;                         // :458  (|OptLap|)
+  h.w_str = g.Es > 0 ? f.reg_inex / (double)g.Es : 0.0;        // :497  (|medges|)
+  const float deltaMono = (float)std::sqrt(5.991);             // :286
+  h.hub_delta = (double)deltaMono;
+  h.hub_dsqr = h.hub_delta * h.hub_delta;
+  return DSH_OK;
 }
 
 }  // namespace
@@ -447,6 +282,7 @@ int dsh_destroy(dsh_ctx* c) {
   if (!c) return DSH_ERR_ARG;
   if (c->host_only) { c->stage.release(); c->results.release(); delete c; return DSH_OK; }
   (void)hipSetDevice(c->device);
+  drop_graphs(c);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
   c->stage.release();
@@ -564,31 +400,60 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   if (!c->host_only) (void)hipSetDevice(c->device);
   c->B = 0;
   c->ran = false;
-  c->packed.assign(B, Packed());
+  if ((int)c->packed.size() != B) c->packed.resize(B);   // the vectors inside keep their capacity from frame to frame
   for (int b = 0; b < B; b++) {
     std::string e;
-    const int rc = pack_problem(c->tmpl, frames[b], c->opt.wide_off != 0, c->packed[b], e);
+    const int rc = pack_problem(c, frames[b], c->opt.wide_off != 0, c->packed[b], e);
     if (rc != DSH_OK) return fail(c, rc, "problem " + std::to_string(b) + ": " + e);
+  }
+  // Launch shape: 8 wavefronts per problem give the lowest latency; with at least two problems per CU, 4 wavefronts
+  // per problem (two problems resident per CU, <= 80 KB of LDS each) give the higher throughput.  Band mode needs 8.
+  int nw = 8;
+  {
+    bool all_tiles = true;
+    for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode == 1;
+    if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
+    if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
+  }
+  // LDS of the assembly (it aliases the solver workspace): one staged tile row of H per wavefront, then the records a gather
+  // touches most often, as far as the budget goes (4 wavefronts: two problems share a CU's 160 KB)
+  size_t jl_doubles = 0;
+  int max_kd = 0;
+  const size_t lds_budget = ((nw == 4 ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
+  for (int b = 0; b < B; b++) {
+    SftDev& hh = c->packed[b].h;
+    const dsh::SftGraph& g = *c->packed[b].g;
+    hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);   // the barrier version of the factor steps exists in lab builds only
+    size_t used = 0;
+    hh.asm_slots = 0;
+    hh.lds_flags = 0;
+    if (hh.tile_mode == 1 && !c->opt.asm_direct && (size_t)nw * g.max_slots * (kTS * kTS) <= lds_budget) { hh.asm_slots = g.max_slots; used = (size_t)nw * g.max_slots * (kTS * kTS); }
+    const size_t need[4] = {((size_t)hh.M + 1) & ~(size_t)1, 6 * (size_t)hh.nA, 4 * (size_t)hh.S, 4 * (size_t)hh.Es};
+    const int order[4] = {0, 2, 1, 3};   // observation weights, curvature records, node matrices, stretch records
+    for (int k : order)
+      if (used + need[k] <= lds_budget) { hh.lds_flags |= 1 << k; used += need[k]; }
+    // the kernel lays the regions out in flag order (tiles, wt, A, star, str): same total
+    jl_doubles = std::max(jl_doubles, used);
+    max_kd = std::max(max_kd, hh.kd);
   }
   if (c->host_only) {  // packed on the host only; dsh_sft_batch_problem_info works, running does not
     c->h_probs.resize(B);
     for (int b = 0; b < B; b++) c->h_probs[b] = c->packed[b].h;
     c->B = B;
+    c->nw = nw;
     return DSH_OK;
   }
-  // ---- layout: [SftDev table][read-only arrays of every problem] | [result region: B headers, bodies] | [workspace]
+  // ---- layout: [SftDev table][per-frame read-only arrays of every problem] | [result region: B headers, bodies] | [workspace]
   Arena a;
   const size_t o_tab = a.take(sizeof(SftDev) * B);
-  struct Offs { size_t act, obs_nodes, obs_bary, obs_uv, obs_w, ref, star, sL, strn, strL, rc, ptr, dblk, oblk, contrib, hdr, tmask, cfac, xyz_init, pose_init; };
+  struct Offs { size_t obs_nodes, obs_bary, obs_uv, obs_w, ob_ptr, ob_m, ob_c, viewed, xyz_init, pose_init; };
   std::vector<Offs> ro(B);
   for (int b = 0; b < B; b++) {
-    Packed& P = c->packed[b];
+    dsh::SftFramePack& F = c->packed[b].f;
     Offs& o = ro[b];
-    o.act = reserve(a, P.act); o.obs_nodes = reserve(a, P.obs_nodes); o.obs_bary = reserve(a, P.obs_bary); o.obs_uv = reserve(a, P.obs_uv);
-    o.obs_w = reserve(a, P.obs_w); o.ref = reserve(a, P.ref_node); o.star = reserve(a, P.star_node); o.sL = reserve(a, P.star_sL);
-    o.strn = reserve(a, P.str_nodes); o.strL = reserve(a, P.str_L0); o.rc = reserve(a, P.blk_rc); o.ptr = reserve(a, P.blk_ptr);
-    o.dblk = reserve(a, P.diag_blk); o.oblk = reserve(a, P.off_blk);
-    o.contrib = reserve(a, P.contrib); o.hdr = reserve(a, P.blk_hdr); o.tmask = reserve(a, P.tmask); o.cfac = reserve(a, P.cfac); o.xyz_init = reserve(a, P.xyz_init);
+    o.obs_nodes = reserve(a, F.obs_nodes); o.obs_bary = reserve(a, F.obs_bary); o.obs_uv = reserve(a, F.obs_uv); o.obs_w = reserve(a, F.obs_w);
+    o.ob_ptr = reserve(a, F.ob_ptr); o.ob_m = reserve(a, F.ob_m); o.ob_c = reserve(a, F.ob_c); o.viewed = reserve(a, F.viewed);
+    o.xyz_init = reserve(a, F.xyz_init);
     o.pose_init = a.take(8 * 8);
   }
   c->ro_bytes = a.size;
@@ -604,37 +469,17 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     r.mp = a.take(4 * 3 * (size_t)h.M) - c->res_off; r.outl = a.take((size_t)h.M) - c->res_off;
   }
   c->res_bytes = a.size - c->res_off;
-  struct WOffs { size_t bak, Jobs, Jstar, Jstr, Jref, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg; };
+  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg; };
   std::vector<WOffs> wo(B);
-  int max_kd = 0;
-  size_t jl_doubles = 0;
-  // Launch shape: 8 wavefronts per problem give the lowest latency; with at least two problems per CU, 4 wavefronts
-  // per problem (two problems resident per CU, <= 80 KB of LDS each) give the higher throughput.  Band mode needs 8.
-  int nw = 8;
-  {
-    bool all_tiles = true;
-    for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode == 1;
-    if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
-    if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
-  }
-  for (int b = 0; b < B; b++) {   // tile mode: barrier-free (dataflow) factor steps; the barrier version exists in lab builds only
-    SftDev& hh = c->packed[b].h;
-    hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);
-  }
-  const size_t jl_cap = (nw == 4 ? 72 : 96) * 1024;
-  for (int b = 0; b < B; b++) {   // small Jacobian records live in LDS when they fit next to the solver workspace
-    SftDev& hh = c->packed[b].h;
-    const size_t need = 4 * ((size_t)hh.S + hh.Es + hh.V);
-    hh.jl_lds = (need * 8 <= jl_cap) ? 1 : 0;
-    if (hh.jl_lds) jl_doubles = std::max(jl_doubles, need);
-  }
   const size_t ws_off = a.size;
   for (int b = 0; b < B; b++) {
     const SftDev& h = c->packed[b].h;
     const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
     WOffs& w = wo[b];
     w.bak = a.take(8 * 3 * (size_t)h.n);
-    w.Jobs = a.take(8 * (size_t)h.M * SFT_JOBS_STRIDE); w.Jstar = a.take(8 * 4 * (size_t)h.S); w.Jstr = a.take(8 * 4 * (size_t)h.Es); w.Jref = a.take(8 * 4 * (size_t)h.V);
+    w.camrec = a.take(8 * (size_t)h.M * SFT_CAM_STRIDE);
+    w.wtv = a.take((h.lds_flags & 1) ? 0 : 8 * ((size_t)h.M + 1)); w.Anode = a.take((h.lds_flags & 2) ? 0 : 8 * 6 * (size_t)h.nA);
+    w.Jstar = a.take((h.lds_flags & 4) ? 0 : 8 * 4 * (size_t)h.S); w.Jstr = a.take((h.lds_flags & 8) ? 0 : 8 * 4 * (size_t)h.Es);
     // tile mode: BT+1 zero tile rows below the matrix and an 8th (zero) border row + one window of columns let the
     // factorisation load every tile of its sliding window unconditionally (SFT_H_PAD_* in sft_problem.h)
     const size_t band_elems = h.tile_mode ? (Dnp / kTS + SFT_H_PAD_TILE_ROWS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;
@@ -644,7 +489,6 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.Lt = a.take(h.tile_mode == 2 ? 8 * band_elems : 0); w.LbT = a.take(h.tile_mode == 2 ? 8 * (Dnp / kTS) * (size_t)kTS * kTS : 0);
     w.x = a.take(8 * (Dnp + 8)); w.dbg = a.take(1024);
-    max_kd = std::max(max_kd, h.kd);
   }
   if (sft_lm_kernel_lds_bytes(max_kd, jl_doubles) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
     return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel / workgroup");
@@ -665,28 +509,33 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   SftResHdr* d_hdr = (SftResHdr*)(base + c->res_off);
   for (int b = 0; b < B; b++) {
     Packed& P = c->packed[b];
+    const dsh::SftFramePack& F = P.f;
+    const dsh::SftGraph& g = *P.g;
     const Offs& o = ro[b];
-    put(st, o.act, P.act); put(st, o.obs_nodes, P.obs_nodes); put(st, o.obs_bary, P.obs_bary); put(st, o.obs_uv, P.obs_uv); put(st, o.obs_w, P.obs_w);
-    put(st, o.ref, P.ref_node); put(st, o.star, P.star_node); put(st, o.sL, P.star_sL); put(st, o.strn, P.str_nodes); put(st, o.strL, P.str_L0);
-    put(st, o.rc, P.blk_rc); put(st, o.ptr, P.blk_ptr); put(st, o.dblk, P.diag_blk); put(st, o.oblk, P.off_blk); put(st, o.contrib, P.contrib);
-    put(st, o.hdr, P.blk_hdr); put(st, o.tmask, P.tmask); put(st, o.cfac, P.cfac); put(st, o.xyz_init, P.xyz_init);
-    std::memcpy(st + o.pose_init, P.pose_init, 7 * sizeof(double));
+    put(st, o.obs_nodes, F.obs_nodes); put(st, o.obs_bary, F.obs_bary); put(st, o.obs_uv, F.obs_uv); put(st, o.obs_w, F.obs_w);
+    put(st, o.ob_ptr, F.ob_ptr); put(st, o.ob_m, F.ob_m); put(st, o.ob_c, F.ob_c); put(st, o.viewed, F.viewed); put(st, o.xyz_init, F.xyz_init);
+    std::memcpy(st + o.pose_init, F.pose_init, 7 * sizeof(double));
     SftDev h = P.h;
     const WOffs& w = wo[b];
     const dsh_ctx::ResOffs& r = c->res_offs[b];
     char* rbase = base + c->res_off;
-    h.xyz0 = c->dt.xyz0; h.nbr_ptr = c->dt.nbr_ptr; h.nbr_idx = c->dt.nbr_idx; h.nbr_w = c->dt.nbr_w; h.nbr_c = c->dt.nbr_c; h.nbr_sumw = c->dt.nbr_sumw; h.k0 = c->dt.k0;
-    h.act = (const int32_t*)(base + o.act); h.obs_nodes = (const int32_t*)(base + o.obs_nodes); h.obs_bary = (const double*)(base + o.obs_bary);
-    h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w); h.ref_node = (const int32_t*)(base + o.ref);
-    h.star_node = (const int32_t*)(base + o.star); h.star_sL = (const double*)(base + o.sL); h.str_nodes = (const int32_t*)(base + o.strn);
-    h.str_L0 = (const double*)(base + o.strL); h.blk_rc = (const int32_t*)(base + o.rc); h.blk_ptr = (const int32_t*)(base + o.ptr);
-    h.diag_blk = (const int32_t*)(base + o.dblk); h.off_blk = (const int32_t*)(base + o.oblk);
-    h.contrib = (const uint32_t*)(base + o.contrib); h.blk_hdr = (const int32_t*)(base + o.hdr); h.tmask = (const int32_t*)(base + o.tmask); h.cfac = (const double*)(base + o.cfac); h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
+    const char* gb = g.d_base;
+    h.xyz0 = c->dt.xyz0; h.nbr_ptr = c->dt.nbr_ptr; h.nbr_idx = c->dt.nbr_idx; h.nbr_w = c->dt.nbr_w; h.nbr_sumw = c->dt.nbr_sumw; h.k0 = c->dt.k0;
+    h.act = (const int32_t*)(gb + g.o.act); h.actnode = (const int32_t*)(gb + g.o.actnode); h.star_node = (const int32_t*)(gb + g.o.star_node);
+    h.star_sL = (const double*)(gb + g.o.star_sL); h.str_nodes = (const int32_t*)(gb + g.o.str_nodes); h.str_L0 = (const double*)(gb + g.o.str_L0);
+    h.off_ptr = (const int32_t*)(gb + g.o.off_ptr); h.off_rc = (const int32_t*)(gb + g.o.off_rc); h.sh_ptr = (const int32_t*)(gb + g.o.sh_ptr);
+    h.sh_rec = (const uint32_t*)(gb + g.o.sh_rec); h.sh_cf = (const double*)(gb + g.o.sh_cf); h.tmask = (const int32_t*)(gb + g.o.tmask);
+    h.obs_nodes = (const int32_t*)(base + o.obs_nodes); h.obs_bary = (const double*)(base + o.obs_bary);
+    h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w);
+    h.ob_ptr = (const int32_t*)(base + o.ob_ptr); h.ob_m = (const int32_t*)(base + o.ob_m); h.ob_c = (const double*)(base + o.ob_c);
+    h.viewed = (const uint8_t*)(base + o.viewed);
+    h.xyz_init = (const double*)(base + o.xyz_init); h.pose_init = (const double*)(base + o.pose_init);
     h.res = d_hdr + b; h.pose = d_hdr[b].pose;   // address arithmetic on a device pointer: nothing is dereferenced on the host
     h.xyz = (double*)(rbase + r.xyz); h.chi2_obs = (double*)(rbase + r.chi2); h.trace = (double*)(rbase + r.trace);
     h.mappoint = (float*)(rbase + r.mp); h.outlier = (uint8_t*)(rbase + r.outl);
     h.xyz_bak = (double*)(base + w.bak);
-    h.Jobs = (double*)(base + w.Jobs); h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr); h.Jref = (double*)(base + w.Jref);
+    h.camrec = (double*)(base + w.camrec); h.wtv = (double*)(base + w.wtv); h.Anode = (double*)(base + w.Anode);
+    h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr);
     h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
     h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc); h.Linv = (double*)(base + w.Linv);
     h.Lt = (double*)(base + w.Lt); h.LbT = (double*)(base + w.LbT);
@@ -743,11 +592,11 @@ int dsh_sft_batch_problem_info(dsh_ctx* c, int b, int64_t* bytes, int32_t* count
   const Packed& P = c->packed[b];
   const SftDev& h = P.h;
   // materialised-Jacobian convention, reference edge counts (curvature unfused)
-  const int64_t M = h.M, n = h.n, C = P.n_curv_ref, E = h.Es, V = h.V;
+  const int64_t M = h.M, n = h.n, C = P.g->n_curv_ref, E = h.Es, V = h.V;
   const int64_t reads = 60 * M + 24 * n + 88 + 92 * C + 16 * E + 28 * V;
   const int64_t writes = 8 * (30 * M + 21 * C + 6 * E + 9 * V) + 8 * (2 * M + C + E + 3 * V) + 8 * M;
   if (bytes) *bytes = reads + writes;
-  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; counts[6] = h.kd; counts[7] = c->nw; }
+  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.g->n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; counts[6] = h.kd; counts[7] = c->nw; }
   return DSH_OK;
 }
 
@@ -781,7 +630,7 @@ int dsh_sft_batch_download(dsh_ctx* c, int B, dsh_sft_result* res) {
     if (r.Tcw) Tcw_from_pose7(hd[b].pose, r.Tcw);
     if (r.mappoint_xyz) std::memcpy(r.mappoint_xyz, rb + o.mp, 4 * 3 * (size_t)h.M);
     if (r.trace) {   // rows of the executed iterations, zeros behind them
-      const size_t rows = (size_t)std::max(P.max_iters, 0), done = std::min(rows, (size_t)std::max(hd[b].iters, 0));
+      const size_t rows = (size_t)std::max(P.f.max_iters, 0), done = std::min(rows, (size_t)std::max(hd[b].iters, 0));
       std::memcpy(r.trace, rb + o.trace, 8 * DSH_TRACE_STRIDE * done);
       std::memset(r.trace + DSH_TRACE_STRIDE * done, 0, 8 * DSH_TRACE_STRIDE * (rows - done));
     }
@@ -814,6 +663,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   if (k == "waves") { if (value != 0 && value != 4 && value != 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: waves is 0 (automatic), 4 or 8"); c->opt.waves = value; }
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
+  else if (k == "asm_direct") c->opt.asm_direct = value != 0;
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;
 }

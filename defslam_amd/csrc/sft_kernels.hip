@@ -216,17 +216,37 @@ __device__ __forceinline__ void huber(const SftDev& P, double e2, double& rho0, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Residuals (+ Jacobian records when WANT_J): returns the robust chi2 in ctl-independent LDS out[0]
+// Residuals (+ assembly records when WANT_J): returns the robust chi2 in ctl-independent LDS out[0]
 // ------------------------------------------------------------------------------------------
-struct JPtr { double *star, *str, *ref; };   // small Jacobian records: LDS when they fit (P.jl_lds), else global
+// Solver workspace and assembly records share the LDS panel.  Explicit address space: see to_lds below.
+using lds_double = __attribute__((address_space(3))) double;
+__device__ __forceinline__ lds_double* to_lds(double* p) { return (lds_double*)p; }
 
-__device__ __forceinline__ JPtr jrecords(const SftDev& P, double* lds) {
-  if (P.jl_lds) return JPtr{lds, lds + 4 * (size_t)P.S, lds + 4 * ((size_t)P.S + P.Es)};
-  return JPtr{P.Jstar, P.Jstr, P.Jref};
+// Records of one linearisation that the assembly gathers from.  Each array lives in LDS when the host packer found room for it
+// (P.lds_flags, in the order of how often a gather touches it) and in the problem's workspace otherwise:
+//   wt[m]      rho'_m w_m of observation m (robust weight x information)
+//   A[6 a]     the 2x3 matrix A_a of active node a: the reference linearises an observation at every node's OWN camera-frame
+//              depth (sft_types.h:176-205), so J_node(m, s) = b_ms A_node -- the Jacobian of an observation with respect to a node
+//              depends on the observation only through its barycentric coordinate.  H_ij(obs) = (sum_m wt_m b_mi b_mj) A_i^T A_j.
+//   star[4 s]  unit vector u and residual r of curvature star s;  str[4 e]  gradient g and residual of stretch edge e
+//   tiles      tile mode 1: one tile row of H per wavefront (P.asm_slots tiles of 2 KB), flushed to HBM as whole tiles
+struct AsmRec { double *wt, *A, *star, *str; lds_double* tiles; };
+
+template <int NW>
+__device__ __forceinline__ AsmRec asm_records(const SftDev& P, double* lds) {
+  AsmRec r;
+  size_t off = (size_t)NW * P.asm_slots * (TS * TS);
+  r.tiles = to_lds(lds);
+  const int fl = P.lds_flags;
+  if (fl & 1) { r.wt = lds + off; off += (size_t)(P.M + 1) & ~(size_t)1; } else r.wt = P.wtv;
+  if (fl & 2) { r.A = lds + off; off += 6 * (size_t)P.nA; } else r.A = P.Anode;
+  if (fl & 4) { r.star = lds + off; off += 4 * (size_t)P.S; } else r.star = P.Jstar;
+  if (fl & 8) { r.str = lds + off; off += 4 * (size_t)P.Es; } else r.str = P.Jstr;
+  return r;
 }
 
 template <bool WANT_J>
-__device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, JPtr jp) {
+__device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, const AsmRec& ar) {
   if (threadIdx.x == 0) {
     quat_to_R(P.pose + 3, ctl->R);
     ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2];
@@ -236,9 +256,9 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
 #pragma unroll
   for (int i = 0; i < 9; i++) R[i] = ctl->R[i];
   t[0] = ctl->t[0]; t[1] = ctl->t[1]; t[2] = ctl->t[2];
-  const double* xyz = P.xyz;
+  const auto xyz = P.xyz;
   double chi = 0.0;
-  const int total = P.M + P.V + P.S + P.Es;
+  const int total = P.M + P.n + P.S + P.Es;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     if (idx < P.M) {
       const int m = idx;
@@ -261,7 +281,8 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       chi += rho0;
       P.chi2_obs[m] = c2;
       if (WANT_J) {
-        double* rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
+        // camera record: robust information, error, the ten non-zero entries of J_cam (sft_types.h:162-174, columns [omega, upsilon]);
+        // the point is the barycentric combination of the nodes' camera-frame positions, like the reference
         double c[3][3];
 #pragma unroll
         for (int s = 0; s < 3; s++)
@@ -271,41 +292,48 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
         const double y = (c[0][1] * b0 + c[1][1] * b1) + c[2][1] * b2;
         const double z = (c[0][2] * b0 + c[1][2] * b1) + c[2][2] * b2;
         const double z2 = z * z, fx = P.fx, fy = P.fy;
-        rec[0] = e0; rec[1] = e1; rec[2] = rho1 * w; rec[3] = c2;
-        rec[4] = x * y / z2 * fx;
-        rec[5] = -(1 + (x * x / z2)) * fx;
-        rec[6] = y / z * fx;
-        rec[7] = -1. / z * fx;
-        rec[8] = 0;
-        rec[9] = x / z2 * fx;
-        rec[10] = (1 + y * y / z2) * fy;
-        rec[11] = -x * y / z2 * fy;
-        rec[12] = -x / z * fy;
-        rec[13] = 0;
-        rec[14] = -1. / z * fy;
-        rec[15] = y / z2 * fy;
-        const double bb[3] = {b0, b1, b2};
-#pragma unroll
-        for (int s = 0; s < 3; s++) {
-          // the reference linearises each node at ITS OWN camera-frame depth (sft_types.h:176-205)
-          const double xs = c[s][0], ys = c[s][1], zs = c[s][2];
+        const auto rec = P.camrec + (size_t)m * SFT_CAM_STRIDE;
+        const double wt = rho1 * w;
+        rec[0] = wt; rec[1] = e0; rec[2] = e1;
+        rec[3] = x * y / z2 * fx;            // row 0: columns 0, 1, 2, 3, 5 (column 4 is zero)
+        rec[4] = -(1 + (x * x / z2)) * fx;
+        rec[5] = y / z * fx;
+        rec[6] = -1. / z * fx;
+        rec[7] = x / z2 * fx;
+        rec[8] = (1 + y * y / z2) * fy;      // row 1: columns 0, 1, 2, 4, 5 (column 3 is zero)
+        rec[9] = -x * y / z2 * fy;
+        rec[10] = -x / z * fy;
+        rec[11] = -1. / z * fy;
+        rec[12] = y / z2 * fy;
+        rec[13] = c2;
+        ar.wt[m] = wt;
+      }
+    } else if (idx < P.M + P.n) {
+      const int nd = idx - P.M;
+      const int a = P.act[nd];
+      if (a >= 0) {
+        const double p0 = xyz[3 * nd], p1 = xyz[3 * nd + 1], p2 = xyz[3 * nd + 2];
+        if (P.viewed[a]) {   // reference (temporal) edge, EdgesReference: e = v - v_ref (sft_types.h:401-408)
+          const double e0 = p0 - P.xyz0[3 * nd], e1 = p1 - P.xyz0[3 * nd + 1], e2 = p2 - P.xyz0[3 * nd + 2];
+          chi += (e0 * (P.w_ref * e0) + e1 * (P.w_ref * e1)) + e2 * (P.w_ref * e2);
+        }
+        if (WANT_J) {
+          // A_a = -(1/z) [[fx, 0, -x/z fx], [0, fy, -y/z fy]] R at the node's own camera-frame position (sft_types.h:176-205)
+          const double xs = (R[0] * p0 + R[1] * p1 + R[2] * p2) + t[0];
+          const double ys = (R[3] * p0 + R[4] * p1 + R[5] * p2) + t[1];
+          const double zs = (R[6] * p0 + R[7] * p1 + R[8] * p2) + t[2];
           const double sc = -1. / zs;
-          const double t00 = sc * fx, t02 = sc * (-xs / zs * fx), t11 = sc * fy, t12 = sc * (-ys / zs * fy);
+          const double t00 = sc * P.fx, t02 = sc * (-xs / zs * P.fx), t11 = sc * P.fy, t12 = sc * (-ys / zs * P.fy);
+          double* A = ar.A + 6 * (size_t)a;
 #pragma unroll
           for (int cc = 0; cc < 3; cc++) {
-            rec[16 + 6 * s + cc] = ((t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc]) * bb[s];
-            rec[16 + 6 * s + 3 + cc] = ((0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc]) * bb[s];
+            A[cc] = (t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc];
+            A[3 + cc] = (0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc];
           }
         }
       }
-    } else if (idx < P.M + P.V) {
-      const int v = idx - P.M;
-      const int nd = P.ref_node[v];
-      const double e0 = xyz[3 * nd] - P.xyz0[3 * nd], e1 = xyz[3 * nd + 1] - P.xyz0[3 * nd + 1], e2 = xyz[3 * nd + 2] - P.xyz0[3 * nd + 2];
-      chi += (e0 * (P.w_ref * e0) + e1 * (P.w_ref * e1)) + e2 * (P.w_ref * e2);
-      if (WANT_J) { double* r = jp.ref + 4 * v; r[0] = e0; r[1] = e1; r[2] = e2; r[3] = 0; }
-    } else if (idx < P.M + P.V + P.S) {
-      const int s = idx - P.M - P.V;
+    } else if (idx < P.M + P.n + P.S) {
+      const int s = idx - P.M - P.n;
       const int nd = P.star_node[s];
       double a0 = 0, a1 = 0, a2 = 0;
       for (int q = P.nbr_ptr[nd]; q < P.nbr_ptr[nd + 1]; q++) {
@@ -319,13 +347,13 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       const double r = nrm - P.k0[nd];
       chi += (P.w_curv * P.star_sL[s]) * (r * r);
       if (WANT_J) {
-        double* rr = jp.star + 4 * s;
+        double* rr = ar.star + 4 * s;
         if (nrm < 1E-15) { rr[0] = rr[1] = rr[2] = 0.0; }
         else { rr[0] = m0 / nrm; rr[1] = m1 / nrm; rr[2] = m2 / nrm; }
         rr[3] = r;
       }
     } else {
-      const int e = idx - P.M - P.V - P.S;
+      const int e = idx - P.M - P.n - P.S;
       const int a = P.str_nodes[2 * e], b = P.str_nodes[2 * e + 1];
       const double d0 = xyz[3 * a] - xyz[3 * b], d1 = xyz[3 * a + 1] - xyz[3 * b + 1], d2 = xyz[3 * a + 2] - xyz[3 * b + 2];
       const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
@@ -334,7 +362,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       chi += er * (P.w_str * er);
       if (WANT_J) {
         const double ddo = 1.0 / (nrm * L0);
-        double* r = jp.str + 4 * e;
+        double* r = ar.str + 4 * e;
         r[0] = d0 * ddo; r[1] = d1 * ddo; r[2] = d2 * ddo; r[3] = er;
       }
     }
@@ -344,29 +372,33 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
 }
 
 // ------------------------------------------------------------------------------------------
-// Normal equations: gather per 3x3 block from the Jacobian records (fixed contribution order).
+// Normal equations: one gather per 3x3 block, fixed contribution order (no atomics: a run is bit-reproducible).
+//
+// A wavefront owns one tile row of H at a time (16 scalar rows = the 5-7 active nodes whose rows touch it): 8 lanes per
+// diagonal block (observations, curvature, stretching, reference edge, the 6x3 camera block and b of that node), one lane
+// per off-diagonal block.  In tile mode 1 the blocks land in the wavefront's private LDS tiles and leave as whole 2 KB
+// tiles in accumulator order (one coalesced 32-byte store per lane and tile; the scattered 8-byte elements of a 3x3 block
+// would each dirty a quarter of a 32-byte sector).  No workgroup barrier inside: the wavefronts of a problem drift apart
+// and cover each other's gather latency.  A node whose three rows straddle two tile rows is gathered for both.
+// Other storage modes (wide tiles, row-major band) and oversized tile rows store the blocks straight to global memory.
 // ------------------------------------------------------------------------------------------
-// six consecutive doubles of a Jacobian record as three 16-byte loads (records are 288-byte strided, rows start at
-// 128 + 48 s bytes): the gathers are bound by address-processing cycles per lane, not by bytes
 typedef double v2d __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void load6(const SFT_G double* p, double* o) {
-  const SFT_G v2d* q = reinterpret_cast<const SFT_G v2d*>(p);
-  const v2d a = q[0], b = q[1], c = q[2];
-  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y;
-}
-__device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
+
+template <int NW>
+__device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec& ar) {
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // camera corner: H_cc (lower 21) and b_c (6) as a block-wide reduction over the observations
   {
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0.0;
     for (int m = threadIdx.x; m < P.M; m += blockDim.x) {
-      const auto rec = P.Jobs + (size_t)m * SFT_JOBS_STRIDE;
-      const double wt = rec[2], e0 = rec[0], e1 = rec[1];
-      double j0[6], j1[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) { j0[k] = rec[4 + k]; j1[k] = rec[10 + k]; }
+      const auto rec = P.camrec + (size_t)m * SFT_CAM_STRIDE;
+      const double wt = rec[0], e0 = rec[1], e1 = rec[2];
+      const double j0[6] = {rec[3], rec[4], rec[5], rec[6], 0.0, rec[7]};
+      const double j1[6] = {rec[8], rec[9], rec[10], 0.0, rec[11], rec[12]};
       int q = 0;
 #pragma unroll
       for (int r = 0; r < 6; r++)
@@ -385,151 +417,173 @@ __device__ void assemble(const SftDev& P, double* red, double* out, JPtr jp) {
     }
     __syncthreads();
   }
-  // one contribution into the accumulators of a block (H 3x3; for diagonal blocks also the 6x3 camera block and b)
-  auto contribute = [&](uint32_t rec, double cf, double cg, bool diag, double* H, double* Hc, double* bn) {
-    const uint32_t kind = rec >> 30, s = (rec >> 26) & 15u, t = (rec >> 22) & 15u, e = rec & 0x3FFFFFu;
-    if (kind == SFT_KIND_OBS) {
-      const auto r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
-      const double wt = r[2];
-      double js[6], jt[6];
-      load6(r + 16 + 6 * s, js);
-      load6(r + 16 + 6 * t, jt);
+  const bool staged = P.tile_mode == 1 && P.asm_slots > 0;
+  const int slots = P.asm_slots;
+  lds_double* mytiles = ar.tiles + (size_t)wave * slots * (TS * TS);
+  const int ngroups = staged ? (P.Dn + TS - 1) / TS : (P.nA + 4) / 5;
+  const auto Hg = P.Hb;
+  if (staged)
+    for (int i = lane; i < slots * (TS * TS) / 2; i += 64) reinterpret_cast<__attribute__((address_space(3))) v2d*>(mytiles)[i] = (v2d){0.0, 0.0};
+
+#pragma unroll 1
+  for (int I = wave; I < ngroups; I += NW) {
+    const int row_lo = staged ? TS * I : 0, row_hi = staged ? TS * I + TS - 1 : 0x7fffffff;
+    const int a_lo = staged ? row_lo / 3 : 5 * I;
+    const int a_hi = min(staged ? row_hi / 3 : 5 * I + 4, P.nA - 1);
+    const int mask = staged ? P.tmask[I] : 0;
+    // element (r, c), c <= r, of H (and its mirror inside a diagonal tile, which is stored symmetric)
+    auto put = [&](int r, int c, double v) {
+      if (staged) {
+        if (r < row_lo || r > row_hi) return;
+        const int d = I - (c >> 4);
+        lds_double* tl = mytiles + __builtin_popcount(mask & ((1 << d) - 1)) * (TS * TS);
+        tl[tile_elem(r & 15, c & 15)] = v;
+        if (d == 0 && c < r) tl[tile_elem(c & 15, r & 15)] = v;
+      } else {
+        const size_t idx = h_index(P, r, c);
+        Hg[idx] = v;
+        if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) {
+          const int e1 = tile_elem(r & 15, c & 15), e2 = tile_elem(c & 15, r & 15);
+          Hg[idx + (P.tile_mode == 2 ? e1 - e2 : e2 - e1)] = v;
+        }
+      }
+    };
+    // ---- diagonal blocks: 8 lanes per node, contributions dealt round-robin, partial sums combined by a fixed xor butterfly
+    {
+      const int sub = lane & 7, a = a_lo + (lane >> 3);
+      const bool on = (lane >> 3) < 7 && a <= a_hi;
+      double sii = 0.0, G0[5], G1[5], g0 = 0.0, g1 = 0.0, Hs[6], bn[3];
+#pragma unroll
+      for (int k = 0; k < 5; k++) { G0[k] = 0.0; G1[k] = 0.0; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) Hs[k] = 0.0;
+      bn[0] = bn[1] = bn[2] = 0.0;
+      if (on) {
+        for (int p = P.ob_ptr[a] + sub, pe = P.ob_ptr[a + 1]; p < pe; p += 8) {
+          const auto rec = P.camrec + (size_t)P.ob_m[p] * SFT_CAM_STRIDE;
+          const double b = P.ob_c[p];
+          const double om = rec[0] * b;
+          sii += om * b;
+#pragma unroll
+          for (int k = 0; k < 5; k++) { G0[k] += om * rec[3 + k]; G1[k] += om * rec[8 + k]; }
+          g0 += om * rec[1];
+          g1 += om * rec[2];
+        }
+        for (int p = P.sh_ptr[a] + sub, pe = P.sh_ptr[a + 1]; p < pe; p += 8) {
+          const uint32_t rc = P.sh_rec[p];
+          const bool is_star = (rc >> 30) == SFT_KIND_STAR;
+          const double* r = (is_star ? ar.star : ar.str) + 4 * (size_t)(rc & 0x3FFFFFu);
+          const double wgt = is_star ? P.w_curv : P.w_str;
+          const double f = wgt * P.sh_cf[2 * p], g = (wgt * P.sh_cf[2 * p + 1]) * r[3];
+          const double u0 = r[0], u1 = r[1], u2 = r[2];
+          Hs[0] += f * (u0 * u0); Hs[1] += f * (u1 * u0); Hs[2] += f * (u1 * u1);
+          Hs[3] += f * (u2 * u0); Hs[4] += f * (u2 * u1); Hs[5] += f * (u2 * u2);
+          bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
+        }
+      }
+      auto bfly = [](double v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
+      sii = bfly(sii); g0 = bfly(g0); g1 = bfly(g1);
+#pragma unroll
+      for (int k = 0; k < 5; k++) { G0[k] = bfly(G0[k]); G1[k] = bfly(G1[k]); }
+#pragma unroll
+      for (int k = 0; k < 6; k++) Hs[k] = bfly(Hs[k]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) bn[k] = bfly(bn[k]);
+      if (on && sub == 0) {
+        double A[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) A[k] = ar.A[6 * (size_t)a + k];
+        const bool vw = P.viewed[a] != 0;
+        const double wr = vw ? P.w_ref : 0.0;
+        // lower triangle of the 3x3 block: observations (s_ii A^T A), curvature + stretching, reference edge (J = I)
+        put(3 * a, 3 * a, (sii * (A[0] * A[0] + A[3] * A[3]) + Hs[0]) + wr);
+        put(3 * a + 1, 3 * a, sii * (A[1] * A[0] + A[4] * A[3]) + Hs[1]);
+        put(3 * a + 1, 3 * a + 1, (sii * (A[1] * A[1] + A[4] * A[4]) + Hs[2]) + wr);
+        put(3 * a + 2, 3 * a, sii * (A[2] * A[0] + A[5] * A[3]) + Hs[3]);
+        put(3 * a + 2, 3 * a + 1, sii * (A[2] * A[1] + A[5] * A[4]) + Hs[4]);
+        put(3 * a + 2, 3 * a + 2, (sii * (A[2] * A[2] + A[5] * A[5]) + Hs[5]) + wr);
+        if (3 * a >= row_lo) {   // camera x node block and b of the node: once (with the tile row that holds the node's first row)
+          const double G0f[6] = {G0[0], G0[1], G0[2], G0[3], 0.0, G0[4]};
+          const double G1f[6] = {G1[0], G1[1], G1[2], 0.0, G1[3], G1[4]};
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) P.Hbord[(size_t)k * Dnp + 3 * a + c] = G0f[k] * A[c] + G1f[k] * A[3 + c];
+          double e[3] = {0.0, 0.0, 0.0};
+          if (vw) {
+            const int nd = P.actnode[a];
+#pragma unroll
+            for (int c = 0; c < 3; c++) e[c] = P.xyz[3 * nd + c] - P.xyz0[3 * nd + c];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) P.Hbord[(size_t)6 * Dnp + 3 * a + c] = (bn[c] - (A[c] * g0 + A[3 + c] * g1)) - wr * e[c];
+        }
+      }
+    }
+    // ---- off-diagonal blocks of the block rows a_lo .. a_hi: one lane per block
+    const int qb = P.off_ptr[a_lo], qe = P.off_ptr[a_hi + 1];
+    for (int q = qb + lane; q < qe; q += 64) {
+      const int bi = P.off_rc[2 * q], bj = P.off_rc[2 * q + 1];
+      const int blk = P.nA + q;
+      double Ai[6], Aj[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { Ai[k] = ar.A[6 * (size_t)bi + k]; Aj[k] = ar.A[6 * (size_t)bj + k]; }
+      double s = 0.0;
+      {
+        const int p0 = P.ob_ptr[blk], p1 = P.ob_ptr[blk + 1];
+        constexpr int CH = 4;   // four list entries and their weights in flight; the sum keeps the list order
+        for (int p = p0; p < p1; p += CH) {
+          double wv[CH], cv[CH];
+#pragma unroll
+          for (int i = 0; i < CH; i++) {
+            const bool in = p + i < p1;
+            const int m = in ? P.ob_m[p + i] : 0;
+            cv[i] = in ? P.ob_c[p + i] : 0.0;
+            wv[i] = ar.wt[m];
+          }
+#pragma unroll
+          for (int i = 0; i < CH; i++) s += wv[i] * cv[i];
+        }
+      }
+      double H[9];
 #pragma unroll
       for (int a = 0; a < 3; a++)
 #pragma unroll
-        for (int b = 0; b < 3; b++) H[3 * a + b] += wt * (js[a] * jt[b] + js[3 + a] * jt[3 + b]);
-      if (diag) {
-        const double e0 = r[0], e1 = r[1];
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-#pragma unroll
-          for (int a = 0; a < 3; a++) Hc[3 * k + a] += wt * (r[4 + k] * js[a] + r[10 + k] * js[3 + a]);
-#pragma unroll
-        for (int a = 0; a < 3; a++) bn[a] -= wt * (js[a] * e0 + js[3 + a] * e1);
+        for (int b = 0; b < 3; b++) H[3 * a + b] = s * (Ai[a] * Aj[b] + Ai[3 + a] * Aj[3 + b]);
+      for (int p = P.sh_ptr[blk], pe = P.sh_ptr[blk + 1]; p < pe; p++) {
+        const uint32_t rc = P.sh_rec[p];
+        const bool is_star = (rc >> 30) == SFT_KIND_STAR;
+        const double* r = (is_star ? ar.star : ar.str) + 4 * (size_t)(rc & 0x3FFFFFu);
+        const double f = (is_star ? P.w_curv : P.w_str) * P.sh_cf[2 * p];
+        const double u0 = r[0], u1 = r[1], u2 = r[2];
+        H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
+        H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
+        H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
       }
-    } else if (kind == SFT_KIND_STAR) {
-      const double* r = jp.star + 4 * e;
-      const double u0 = r[0], u1 = r[1], u2 = r[2];
-      const double f = cf;      // w_curv * sL_e * (c_s * c_t), precomputed by the packer (state independent)
-      H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
-      H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
-      H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
-      if (diag) {
-        const double g = cg * r[3];   // cg = w_curv * sL_e * c_s
-        bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
-      }
-    } else if (kind == SFT_KIND_STR) {
-      const double* r = jp.str + 4 * e;
-      const double sg = cf;     // +-w_str
-      const double g0 = r[0], g1 = r[1], g2 = r[2];
-      H[0] += sg * (g0 * g0); H[1] += sg * (g0 * g1); H[2] += sg * (g0 * g2);
-      H[3] += sg * (g1 * g0); H[4] += sg * (g1 * g1); H[5] += sg * (g1 * g2);
-      H[6] += sg * (g2 * g0); H[7] += sg * (g2 * g1); H[8] += sg * (g2 * g2);
-      if (diag) {
-        const double g = cg * r[3];
-        bn[0] -= g * g0; bn[1] -= g * g1; bn[2] -= g * g2;
-      }
-    } else {  // SFT_KIND_REF (diagonal only, J = I)
-      const double* r = jp.ref + 4 * e;
-      H[0] += P.w_ref; H[4] += P.w_ref; H[8] += P.w_ref;
-      bn[0] -= P.w_ref * r[0]; bn[1] -= P.w_ref * r[1]; bn[2] -= P.w_ref * r[2];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) put(3 * bi + a, 3 * bj + b, H[3 * a + b]);
     }
-  };
-  auto store_block = [&](int bi, int bj, const double* H) {
+    // ---- the wavefront's tile row leaves as whole tiles (accumulator order, 32 bytes per lane); the LDS copy is cleared
+    if (staged) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wavefront's own LDS stores have landed (no other wave touches these tiles)
+      const int crow = lane >> 4, ccol = lane & 15;
+      int sl = 0;
+      for (int d = 0; d <= BT; d++) {
+        if (!((mask >> d) & 1)) continue;
+        lds_double* tl = mytiles + sl * (TS * TS) + 4 * lane;
+        v4d x = *reinterpret_cast<__attribute__((address_space(3))) v4d*>(tl);
+        if (d == 0) {   // identity padding behind the last unknown (rows >= Dn of the last tile)
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const int r = 3 * bi + a;
-#pragma unroll
-      for (int b = 0; b < 3; b++) {
-        const int c = 3 * bj + b;
-        if (c <= r) {
-          const size_t idx = h_index(P, r, c);
-          P.Hb[idx] = H[3 * a + b];
-          if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) {   // diagonal tiles are stored symmetric: the mirrored element of the same tile
-            const int e1 = tile_elem(r & 15, c & 15), e2 = tile_elem(c & 15, r & 15);
-            P.Hb[idx + (P.tile_mode == 2 ? e1 - e2 : e2 - e1)] = H[3 * a + b];
-          }
+          for (int q = 0; q < 4; q++)
+            if (crow + 4 * q == ccol && TS * I + ccol >= P.Dn) x[q] = 1.0;
         }
+        *reinterpret_cast<SFT_G v4d*>(Hg + tile_off(I, d) + 4 * lane) = x;
+        *reinterpret_cast<__attribute__((address_space(3))) v4d*>(tl) = (v4d){0.0, 0.0, 0.0, 0.0};
+        sl++;
       }
     }
-  };
-  // ---- diagonal blocks (longest contribution lists): a group of DG lanes per block, contributions dealt round-robin,
-  //      partial sums combined with a fixed xor-butterfly (deterministic)
-  constexpr int DG = 8;
-  {
-    const int sub = threadIdx.x & (DG - 1), grp = threadIdx.x / DG;
-    for (int a0 = 0; a0 < P.nA; a0 += (int)blockDim.x / DG) {
-      const int a = a0 + grp;
-      double acc[30];
-#pragma unroll
-      for (int i = 0; i < 30; i++) acc[i] = 0.0;
-      if (a < P.nA) {
-        const int p0 = P.blk_hdr[4 * a], p1 = p0 + P.blk_hdr[4 * a + 1];
-        for (int p = p0 + sub; p < p1; p += DG) contribute(P.contrib[p], P.cfac[2 * p], P.cfac[2 * p + 1], true, acc, acc + 9, acc + 27);
-      }
-#pragma unroll
-      for (int i = 0; i < 30; i++) {
-        double v = acc[i];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        acc[i] = v;
-      }
-      if (a < P.nA && sub == 0) {
-        store_block(a, a, acc);
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) P.Hbord[(size_t)k * Dnp + 3 * a + c] = acc[9 + 3 * k + c];
-#pragma unroll
-        for (int c = 0; c < 3; c++) P.Hbord[(size_t)6 * Dnp + 3 * a + c] = acc[27 + c];
-      }
-    }
-  }
-  // ---- off-diagonal blocks: one lane per block, contributions in the reference's edge order
-  const int noff = P.nblk - P.nA;
-  for (int o = threadIdx.x; o < noff; o += blockDim.x) {
-    const int4 hd = *reinterpret_cast<const SFT_G int4*>(P.blk_hdr + 4 * (P.nA + o));   // start, count, block row, block col
-    double H[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) H[i] = 0.0;
-    // Contributions in chunks of CH: all records first, then all Jacobian rows of the chunk (independent loads in flight),
-    // then the sums in list order -- same arithmetic and order as one at a time, a third of the dependent round trips.
-    constexpr int CH = 4;
-    for (int p0 = hd.x; p0 < hd.x + hd.y; p0 += CH) {
-      uint32_t rc[CH];
-      double cf[CH];
-#pragma unroll
-      for (int i = 0; i < CH; i++) {
-        const bool on = p0 + i < hd.x + hd.y;
-        rc[i] = on ? P.contrib[p0 + i] : 0xFFFFFFFFu;
-        cf[i] = on ? P.cfac[2 * (p0 + i)] : 0.0;
-      }
-      double wt[CH], js[CH][6], jt[CH][6];
-#pragma unroll
-      for (int i = 0; i < CH; i++) {
-        if (rc[i] != 0xFFFFFFFFu && (rc[i] >> 30) == SFT_KIND_OBS) {
-          const uint32_t s2 = (rc[i] >> 26) & 15u, t2 = (rc[i] >> 22) & 15u, e = rc[i] & 0x3FFFFFu;
-          const auto r = P.Jobs + (size_t)e * SFT_JOBS_STRIDE;
-          wt[i] = r[2];
-          load6(r + 16 + 6 * s2, js[i]);
-          load6(r + 16 + 6 * t2, jt[i]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < CH; i++) {
-        if (rc[i] == 0xFFFFFFFFu) continue;
-        if ((rc[i] >> 30) == SFT_KIND_OBS) {
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) H[3 * a + b] += wt[i] * (js[i][a] * jt[i][b] + js[i][3 + a] * jt[i][3 + b]);
-        } else {
-          contribute(rc[i], cf[i], 0.0, false, H, nullptr, nullptr);
-        }
-      }
-    }
-    store_block(hd.z, hd.w, H);
   }
   __syncthreads();
 }
@@ -781,8 +835,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // The solver workspace lives in LDS.  A non-inlined function only sees a generic pointer; the explicit address space keeps
 // its accesses on ds_* instructions (generic = flat_* instructions, which count on both the LDS and the memory counter).
-using lds_double = __attribute__((address_space(3))) double;
-__device__ __forceinline__ lds_double* to_lds(double* p) { return (lds_double*)p; }
 
 // Wave-uniform values that reach a (non-inlined) device function through memory or VGPR arguments: moving them to
 // scalar registers keeps ring bookkeeping, tile addresses and branches on the scalar unit.
@@ -1936,7 +1988,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   double* red = reinterpret_cast<double*>(smem + 512);   // 16*27 doubles
   double* out = red + 16 * 27 + 5;                        // 27 doubles
   double* panel = out + 32;
-  const JPtr jp = jrecords(P, panel);   // the small Jacobian records alias the solver workspace (dead once H is assembled)
+  const AsmRec jp = asm_records<NW>(P, panel);   // the assembly records and staging tiles alias the solver workspace (dead once H is assembled)
   const int tid = threadIdx.x;
   const int Dn = P.Dn, ldh = P.ldh, kd = P.kd;
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
@@ -1975,7 +2027,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 #ifdef DSH_LAB
   if (P.mode == 1) {  // lab hook (dsh_lab_sft_system): one assembly at the initial state
     const double chi = eval_edges<true>(P, ctl, red, out, jp);
-    assemble(P, red, out, jp);
+    assemble<NW>(P, red, out, jp);
     if (tid == 0) P.dbg[0] = chi;
     return;
   }
@@ -1985,7 +2037,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   for (int it = 0; it < P.max_iters; it++) {
     const double chi0 = eval_edges<true>(P, ctl, red, out, jp);
     PH_ADD(1);
-    assemble(P, red, out, jp);
+    assemble<NW>(P, red, out, jp);
     PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
@@ -2159,13 +2211,13 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_assembly_kernel
   double* red = reinterpret_cast<double*>(smem + 512);
   double* out = red + 16 * 27 + 5;
   double* panel = out + 32;
-  const JPtr jp = jrecords(P, panel);
+  const AsmRec jp = asm_records<NW>(P, panel);
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
   __syncthreads();
   const double chi = eval_edges<true>(P, ctl, red, out, jp);
-  assemble(P, red, out, jp);
+  assemble<NW>(P, red, out, jp);
   if (tid == 0) P.dbg[0] = chi;
 }
 

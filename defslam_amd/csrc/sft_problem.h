@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #define SFT_NT 512             // threads of the band-mode workgroup / upper bound of the tile-mode one (8 wavefronts)
-#define SFT_JOBS_STRIDE 36     // doubles per observation Jacobian record
+#define SFT_CAM_STRIDE 14      // doubles per observation camera record: rho' w, e0, e1, five non-zero entries of each row of J_cam (+1 pad: 16-byte rows)
 #define SFT_BORDER 7           // 6 camera rows + the right-hand side carried through the factorisation
 // tile mode keeps zero padding around H so that the sliding window loads every tile unconditionally:
 #define SFT_H_PAD_TILE_ROWS 9  // zero tile rows below the band matrix (window height BT + the look-ahead tile)
@@ -47,12 +47,16 @@ struct SftResHdr {
 
 struct SftDev {
   // sizes
-  int32_t n, nA, Dn, kd, ldh, M, V, S, Es, nblk, max_iters, mode;
-  int32_t tile_mode, jl_lds;  // 1: 16x16-tile band storage + register-window MFMA factorisation (kd <= 128); 2: wide tile band, left-looking
+  int32_t n, nA, Dn, kd, ldh, M, V, S, Es, noff, max_iters, mode;
+  int32_t tile_mode;          // 1: 16x16-tile band storage + register-window MFMA factorisation (kd <= 128); 2: wide tile band, left-looking
                               // MFMA factorisation (kd <= 256, sft_wide.h); 0: row-major band (general)
+  int32_t asm_slots;          // tile mode 1: LDS tiles per tile row of the assembly's staging buffer (= most structurally non-zero tiles of
+                              // a tile row); 0: the assembly stores its 3x3 blocks straight to global memory
+  int32_t lds_flags;          // assembly records kept in LDS instead of the workspace: bit 0 observation weights, 1 node matrices, 2 curvature, 3 stretch
   int32_t tpr, wbt;           // tile modes: pitch of a tile row of the band storage in tiles (wbt + 1), sub-diagonal tiles per block
                               // column (mode 1: 8; mode 2: ceil(kd/16); an even pitch, i.e. an odd tile distance between (I,K) and
                               // (I,K+1), was tried against L2 channel aliasing: no effect)
+  int32_t pad0;
   double fx, fy, cx, cy;
   double w_ref, w_curv, w_str, hub_delta, hub_dsqr;
   // template (shared by every problem of a batch)
@@ -60,29 +64,32 @@ struct SftDev {
   const SFT_G int32_t* nbr_ptr;
   const SFT_G int32_t* nbr_idx;
   const SFT_G double* nbr_w;
-  const SFT_G double* nbr_c;      // -(w_j / sum_j w_j)
   const SFT_G double* nbr_sumw;   // per node
   const SFT_G double* k0;
-  // frame / graph
+  // graph: structure of the normal equations for this template and active set (sft_pack.h: SftGraph), device-resident and
+  // shared by every problem with the same active set.  Blocks: q < nA diagonal block of active node q, q >= nA off-diagonal block q - nA.
   const SFT_G int32_t* act;       // n: compact index or -1
-  const SFT_G int32_t* obs_nodes; // M*3
-  const SFT_G double* obs_bary;   // M*3
-  const SFT_G double* obs_uv;     // M*2
-  const SFT_G double* obs_w;      // M  invSigma2 / N_frame
-  const SFT_G int32_t* ref_node;  // V
+  const SFT_G int32_t* actnode;   // nA: node of compact index a
   const SFT_G int32_t* star_node; // S
   const SFT_G double* star_sL;    // S  sum over incident mesh edges of 1/L^2
   const SFT_G int32_t* str_nodes; // Es*2
   const SFT_G double* str_L0;     // Es
-  const SFT_G int32_t* blk_rc;    // nblk*2 (block row, block col), lower, sorted
-  const SFT_G int32_t* blk_ptr;   // nblk+1
-  const SFT_G int32_t* diag_blk;  // nA: block index of every diagonal block
-  const SFT_G int32_t* off_blk;   // nblk-nA: block indices of the off-diagonal blocks
-  const SFT_G uint32_t* contrib;
-  const SFT_G int32_t* blk_hdr;   // 4 per block in processing order (nA diagonal blocks, then the off-diagonal ones): start, count, block row, block col
-  const SFT_G double* cfac;       // 2 per contribution: state-independent factors (H, b) of curvature / stretch contributions
+  const SFT_G int32_t* off_ptr;   // nA+1: off-diagonal blocks of block row a (columns ascending)
+  const SFT_G int32_t* off_rc;    // noff*2 (block row, block col)
+  const SFT_G int32_t* sh_ptr;    // nblk+1: curvature / stretch contributions of block q
+  const SFT_G uint32_t* sh_rec;   // SFT_REC
+  const SFT_G double* sh_cf;      // 2 per contribution: H and b factors without the regulariser weight
   const SFT_G int32_t* tmask;     // tile mode 1: per tile row I (nT + SFT_H_PAD_TILE_ROWS entries) bit d set if tile (I, I-d) holds any element of H;
                                   // the factorisation reads the other (structurally zero) tiles from one shared zero tile instead of HBM
+  // frame
+  const SFT_G int32_t* obs_nodes; // M*3
+  const SFT_G double* obs_bary;   // M*3
+  const SFT_G double* obs_uv;     // M*2
+  const SFT_G double* obs_w;      // M  invSigma2 / N_frame
+  const SFT_G int32_t* ob_ptr;    // nblk+1: observation contributions of block q, observation order
+  const SFT_G int32_t* ob_m;      // observation index
+  const SFT_G double* ob_c;       // diagonal block: b_s; off-diagonal block: b_s b_t
+  const SFT_G uint8_t* viewed;    // nA: the node carries a reference (temporal) edge
   // initial state (restored at the start of every run)
   const SFT_G double* xyz_init;   // n*3
   const SFT_G double* pose_init;  // 7: t, q(x,y,z,w)
@@ -90,10 +97,11 @@ struct SftDev {
   SFT_G double* xyz;              // n*3
   SFT_G double* xyz_bak;          // n*3
   SFT_G double* pose;             // 7 (inside *res)
-  SFT_G double* Jobs;             // M*SFT_JOBS_STRIDE
-  SFT_G double* Jstar;            // S*4  (u, r)
-  SFT_G double* Jstr;             // Es*4 (g, e)
-  SFT_G double* Jref;             // V*4  (e)
+  SFT_G double* camrec;           // M*SFT_CAM_STRIDE: rho' w, e, the non-zero entries of J_cam (sft_types.h:162-174)
+  SFT_G double* wtv;              // M     rho' w            (when not in LDS)
+  SFT_G double* Anode;            // nA*6  node matrices A_i (when not in LDS): J_node of an observation = b_s A_node (sft_types.h:176-205)
+  SFT_G double* Jstar;            // S*4  (u, r)           (when not in LDS)
+  SFT_G double* Jstr;             // Es*4 (g, e)           (when not in LDS)
   SFT_G double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
                             // tile mode: nT*tpr 16x16 tiles, tile (I,J) at (I*tpr + I-J)*256, element (row,col) at
                             //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register);
@@ -113,5 +121,5 @@ struct SftDev {
   SFT_G SftResHdr* res;           // counters, statistics and the final pose (pose points into it)
   SFT_G uint8_t* outlier;         // M  (float)chi2 > 5.991 (DefOptimizer.cc:515-537)
   SFT_G float* mappoint;          // M*3 DefMapPoint::RecalculatePosition of every observation's point (DefMapPoint.cc:129-147)
-  SFT_G double* dbg;              // [0] robust chi2 of the debug assembly
+  SFT_G double* dbg;              // lab builds: [0] robust chi2 of dsh_lab_sft_system, phase timers, step stamps
 };
