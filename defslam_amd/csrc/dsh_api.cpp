@@ -426,13 +426,11 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);   // the barrier version of the factor steps exists in lab builds only
     size_t used = 0;
     hh.asm_slots = 0;
-    hh.lds_flags = 0;
     if (hh.tile_mode == 1 && !c->opt.asm_direct && (size_t)nw * g.max_slots * (kTS * kTS) <= lds_budget) { hh.asm_slots = g.max_slots; used = (size_t)nw * g.max_slots * (kTS * kTS); }
-    const size_t need[4] = {((size_t)hh.M + 1) & ~(size_t)1, 6 * (size_t)hh.nA, 4 * (size_t)hh.S, 4 * (size_t)hh.Es};
-    const int order[4] = {0, 2, 1, 3};   // observation weights, curvature records, node matrices, stretch records
-    for (int k : order)
-      if (used + need[k] <= lds_budget) { hh.lds_flags |= 1 << k; used += need[k]; }
-    // the kernel lays the regions out in flag order (tiles, wt, A, star, str): same total
+    // placement class of the records (sft_kernels.hip: AsmRec): 1 = observation weights + curvature records, 2 = + node matrices + stretch records
+    const size_t need1 = (((size_t)hh.M + 1) & ~(size_t)1) + 4 * (size_t)hh.S, need2 = need1 + 6 * (size_t)hh.nA + 4 * (size_t)hh.Es;
+    hh.lds_class = (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
+    used += hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
     jl_doubles = std::max(jl_doubles, used);
     max_kd = std::max(max_kd, hh.kd);
   }
@@ -478,8 +476,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     WOffs& w = wo[b];
     w.bak = a.take(8 * 3 * (size_t)h.n);
     w.camrec = a.take(8 * (size_t)h.M * SFT_CAM_STRIDE);
-    w.wtv = a.take((h.lds_flags & 1) ? 0 : 8 * ((size_t)h.M + 1)); w.Anode = a.take((h.lds_flags & 2) ? 0 : 8 * 6 * (size_t)h.nA);
-    w.Jstar = a.take((h.lds_flags & 4) ? 0 : 8 * 4 * (size_t)h.S); w.Jstr = a.take((h.lds_flags & 8) ? 0 : 8 * 4 * (size_t)h.Es);
+    w.wtv = a.take(h.lds_class >= 1 ? 0 : 8 * ((size_t)h.M + 1)); w.Jstar = a.take(h.lds_class >= 1 ? 0 : 8 * 4 * (size_t)h.S);
+    w.Anode = a.take(h.lds_class >= 2 ? 0 : 8 * 6 * (size_t)h.nA); w.Jstr = a.take(h.lds_class >= 2 ? 0 : 8 * 4 * (size_t)h.Es);
     // tile mode: BT+1 zero tile rows below the matrix and an 8th (zero) border row + one window of columns let the
     // factorisation load every tile of its sliding window unconditionally (SFT_H_PAD_* in sft_problem.h)
     const size_t band_elems = h.tile_mode ? (Dnp / kTS + SFT_H_PAD_TILE_ROWS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;
@@ -715,6 +713,12 @@ int dsh_lab_sft_phase_ms(dsh_ctx* c, int b, double* out8) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out8, c->h_probs[b].dbg, 8 * sizeof(double), hipMemcpyDeviceToHost));
   for (int i = 0; i < 8; i++) out8[i] *= 1e-5;  // 100 MHz ticks -> ms
+  {   // sections of the assembly (shader-clock cycles of wave 0), printed for tuning runs
+    double as[6];
+    HIPCHK(c, hipMemcpy(as, c->h_probs[b].dbg + 32, sizeof(as), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[lab] assembly sections of problem %d, kcycles of wave 0: corner %.0f, diagonal gather %.0f, butterfly+finish %.0f, off-diagonal %.0f, flush %.0f; rounds %.0f\n",
+                 b, as[0] * 1e-3, as[1] * 1e-3, as[2] * 1e-3, as[3] * 1e-3, as[4] * 1e-3, as[5]);
+  }
   return DSH_OK;
 #endif
 }

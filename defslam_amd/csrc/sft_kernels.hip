@@ -31,7 +31,7 @@
 
 // Phase timers (thread 0, constant 100 MHz counter): dbg[1] residuals, [2] assembly, [3] H->L copy,
 // [4] panel factorisation, [5] trailing update, [6] back substitution, [7] update + control
-#ifdef SFT_PHASE_TIMERS
+#if defined(SFT_PHASE_TIMERS) && defined(DSH_LAB)   // lab builds only: make lab EXTRA=-DSFT_PHASE_TIMERS
 #define PH_T0() long long ph_t0__ = wall_clock64()
 #define PH_ADD(slot)                                                          \
   do {                                                                        \
@@ -40,14 +40,20 @@
     ph_t0__ = t1__;                                                           \
   } while (0)
 #define PH_RESET() ph_t0__ = wall_clock64()
+// sections of the assembly (shader clock, wave 0): dbg[32] corner reduction, [33] diagonal gather, [34] butterfly + diagonal finish,
+// [35] off-diagonal blocks, [36] tile flush, [37] rounds
+#define AS_T0() long long as_t0__ = clock64()
+#define AS_ADD(slot) do { const long long t1__ = clock64(); if (threadIdx.x == 0) P.dbg[slot] += (double)(t1__ - as_t0__); as_t0__ = t1__; } while (0)
 #else
+#define AS_T0() do {} while (0)
+#define AS_ADD(slot) do {} while (0)
 #define PH_T0() do {} while (0)
 #define PH_ADD(slot) do {} while (0)
 #define PH_RESET() do {} while (0)
 #endif
 
 // Per-wave time stamps of one factorisation step (shader clock), for tuning: -DSFT_STEP_TRACE
-#ifdef SFT_STEP_TRACE
+#if defined(SFT_STEP_TRACE) && defined(DSH_LAB)
 #define ST_MARK(ev) do { if (st_on && k == 40 && (threadIdx.x & 63) == 0) st_buf[(threadIdx.x >> 6) * 8 + (ev)] = (double)clock64(); } while (0)
 #define ST_DONE() do {} while (0)
 #define ST_BEGIN() lds_double* st_buf = to_lds(ws) + 5376; const bool st_on = P.dbg[8] < 0.5   /* LDS scratch: stamps must not add global traffic */
@@ -75,7 +81,8 @@ __device__ __forceinline__ size_t tile_off(int I, int d) { return ((size_t)I * (
 // MFMA accumulator layout (rows (lane>>4) + 4q, column lane & 15) are contiguous -> two 16-byte accesses per lane and tile.
 __device__ __forceinline__ int tile_elem(int row, int col) { return (((row & 3) << 4) + col) * 4 + (row >> 2); }
 
-__device__ __forceinline__ size_t h_index(const SftDev& P, int r, int c) {
+template <class PT>
+__device__ __forceinline__ size_t h_index(const PT& P, int r, int c) {
   if (P.tile_mode == 1) return tile_off(r >> 4, (r >> 4) - (c >> 4)) + tile_elem(r & 15, c & 15);
   if (P.tile_mode == 2) return ((size_t)(r >> 4) * P.tpr + ((r >> 4) - (c >> 4))) * (TS * TS) + tile_elem(c & 15, r & 15);   // wide mode: tiles hold H(I,J)^T
   return (size_t)r * P.ldh + (c - r + P.kd);
@@ -230,23 +237,62 @@ __device__ __forceinline__ lds_double* to_lds(double* p) { return (lds_double*)p
 //              depends on the observation only through its barycentric coordinate.  H_ij(obs) = (sum_m wt_m b_mi b_mj) A_i^T A_j.
 //   star[4 s]  unit vector u and residual r of curvature star s;  str[4 e]  gradient g and residual of stretch edge e
 //   tiles      tile mode 1: one tile row of H per wavefront (P.asm_slots tiles of 2 KB), flushed to HBM as whole tiles
-struct AsmRec { double *wt, *A, *star, *str; lds_double* tiles; };
+// Placement class of the records (P.lds_class, chosen by the host packer from the LDS budget of the launch shape):
+//   0: everything in the workspace (global memory)   1: observation weights + curvature records in LDS
+//   2: all four arrays in LDS
+// The class is a template parameter: every access names its address space at compile time.  (A run-time choice per access
+// would put a branch and a wait of its own around every load -- the gathers then cannot batch their loads -- and a generic
+// pointer compiles to flat_* instructions, which count on the LDS counter AND the memory counter.)
+using gdouble = SFT_G double;
+template <int CLS>
+struct AsmRec {
+  static constexpr bool WT_L = CLS >= 1, STAR_L = CLS >= 1, A_L = CLS >= 2, STR_L = CLS >= 2;
+  lds_double *wt_l, *A_l, *star_l, *str_l, *tiles;
+  gdouble *wt_g, *A_g, *star_g, *str_g;
+  __device__ __forceinline__ double wt(int m) const { if constexpr (WT_L) return wt_l[m]; else return wt_g[m]; }
+  __device__ __forceinline__ void set_wt(int m, double v) const { if constexpr (WT_L) wt_l[m] = v; else wt_g[m] = v; }
+  __device__ __forceinline__ double A(size_t i) const { if constexpr (A_L) return A_l[i]; else return A_g[i]; }
+  __device__ __forceinline__ void set_A(size_t i, double v) const { if constexpr (A_L) A_l[i] = v; else A_g[i] = v; }
+  // curvature (star = true) or stretch record e: four doubles (direction, residual).  Both candidates are loaded and one is
+  // selected: two independent loads, no branch.
+  __device__ __forceinline__ void rec4(bool star, size_t e, bool valid, double* o) const {
+    double a[4], b[4];
+    const size_t ea = (valid && star) ? e : 0, eb = (valid && !star) ? e : 0;
+    if constexpr (STAR_L) { const lds_double* r = star_l + 4 * ea; a[0] = r[0]; a[1] = r[1]; a[2] = r[2]; a[3] = r[3]; }
+    else { const gdouble* r = star_g + 4 * ea; a[0] = r[0]; a[1] = r[1]; a[2] = r[2]; a[3] = r[3]; }
+    if constexpr (STR_L) { const lds_double* r = str_l + 4 * eb; b[0] = r[0]; b[1] = r[1]; b[2] = r[2]; b[3] = r[3]; }
+    else { const gdouble* r = str_g + 4 * eb; b[0] = r[0]; b[1] = r[1]; b[2] = r[2]; b[3] = r[3]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = star ? a[k] : b[k];
+  }
+  __device__ __forceinline__ void set_star(size_t e, double a, double b, double c, double d) const {
+    if constexpr (STAR_L) { lds_double* r = star_l + 4 * e; r[0] = a; r[1] = b; r[2] = c; r[3] = d; }
+    else { gdouble* r = star_g + 4 * e; r[0] = a; r[1] = b; r[2] = c; r[3] = d; }
+  }
+  __device__ __forceinline__ void set_str(size_t e, double a, double b, double c, double d) const {
+    if constexpr (STR_L) { lds_double* r = str_l + 4 * e; r[0] = a; r[1] = b; r[2] = c; r[3] = d; }
+    else { gdouble* r = str_g + 4 * e; r[0] = a; r[1] = b; r[2] = c; r[3] = d; }
+  }
+};
 
-template <int NW>
-__device__ __forceinline__ AsmRec asm_records(const SftDev& P, double* lds) {
-  AsmRec r;
+template <int NW, int CLS>
+__device__ __forceinline__ AsmRec<CLS> asm_records(const SftDev& P, double* lds) {
+  AsmRec<CLS> r;
+  lds_double* base = to_lds(lds);
   size_t off = (size_t)NW * P.asm_slots * (TS * TS);
-  r.tiles = to_lds(lds);
-  const int fl = P.lds_flags;
-  if (fl & 1) { r.wt = lds + off; off += (size_t)(P.M + 1) & ~(size_t)1; } else r.wt = P.wtv;
-  if (fl & 2) { r.A = lds + off; off += 6 * (size_t)P.nA; } else r.A = P.Anode;
-  if (fl & 4) { r.star = lds + off; off += 4 * (size_t)P.S; } else r.star = P.Jstar;
-  if (fl & 8) { r.str = lds + off; off += 4 * (size_t)P.Es; } else r.str = P.Jstr;
+  r.tiles = base;
+  r.wt_l = base + off; if (AsmRec<CLS>::WT_L) off += (size_t)(P.M + 1) & ~(size_t)1;
+  r.star_l = base + off; if (AsmRec<CLS>::STAR_L) off += 4 * (size_t)P.S;
+  r.A_l = base + off; if (AsmRec<CLS>::A_L) off += 6 * (size_t)P.nA;
+  r.str_l = base + off; if (AsmRec<CLS>::STR_L) off += 4 * (size_t)P.Es;
+  r.wt_g = P.wtv; r.A_g = P.Anode; r.star_g = P.Jstar; r.str_g = P.Jstr;
   return r;
 }
 
-template <bool WANT_J>
-__device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, const AsmRec& ar) {
+// (force-inlined like assemble: inside the kernel `P` is a kernel-argument-derived reference whose fields are scalar loads; as a
+// separate function it would arrive as a generic pointer in vector registers and every P.field would be a flat vector load)
+template <bool WANT_J, int CLS>
+__device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, const AsmRec<CLS>& ar) {
   if (threadIdx.x == 0) {
     quat_to_R(P.pose + 3, ctl->R);
     ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2];
@@ -306,7 +352,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
         rec[11] = -1. / z * fy;
         rec[12] = y / z2 * fy;
         rec[13] = c2;
-        ar.wt[m] = wt;
+        ar.set_wt(m, wt);
       }
     } else if (idx < P.M + P.n) {
       const int nd = idx - P.M;
@@ -324,11 +370,10 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
           const double zs = (R[6] * p0 + R[7] * p1 + R[8] * p2) + t[2];
           const double sc = -1. / zs;
           const double t00 = sc * P.fx, t02 = sc * (-xs / zs * P.fx), t11 = sc * P.fy, t12 = sc * (-ys / zs * P.fy);
-          double* A = ar.A + 6 * (size_t)a;
 #pragma unroll
           for (int cc = 0; cc < 3; cc++) {
-            A[cc] = (t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc];
-            A[3 + cc] = (0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc];
+            ar.set_A(6 * (size_t)a + cc, (t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc]);
+            ar.set_A(6 * (size_t)a + 3 + cc, (0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc]);
           }
         }
       }
@@ -347,10 +392,8 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       const double r = nrm - P.k0[nd];
       chi += (P.w_curv * P.star_sL[s]) * (r * r);
       if (WANT_J) {
-        double* rr = ar.star + 4 * s;
-        if (nrm < 1E-15) { rr[0] = rr[1] = rr[2] = 0.0; }
-        else { rr[0] = m0 / nrm; rr[1] = m1 / nrm; rr[2] = m2 / nrm; }
-        rr[3] = r;
+        if (nrm < 1E-15) ar.set_star(s, 0.0, 0.0, 0.0, r);
+        else ar.set_star(s, m0 / nrm, m1 / nrm, m2 / nrm, r);
       }
     } else {
       const int e = idx - P.M - P.n - P.S;
@@ -362,8 +405,7 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
       chi += er * (P.w_str * er);
       if (WANT_J) {
         const double ddo = 1.0 / (nrm * L0);
-        double* r = ar.str + 4 * e;
-        r[0] = d0 * ddo; r[1] = d1 * ddo; r[2] = d2 * ddo; r[3] = er;
+        ar.set_str(e, d0 * ddo, d1 * ddo, d2 * ddo, er);
       }
     }
   }
@@ -384,11 +426,36 @@ __device__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out
 // ------------------------------------------------------------------------------------------
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-template <int NW>
-__device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec& ar) {
+// Sum over the 8 lanes of a group into its first lane with data-parallel-primitive moves (row_shl: lane i reads lane i + n of its
+// 16-lane row; no LDS crossbar, no wait): only the lanes that feed lane 0 of a group matter, and they read inside the group.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double group8_sum(double v) {
+  v += dpp_mov<0x104>(v);   // row_shl:4
+  v += dpp_mov<0x102>(v);   // row_shl:2
+  v += dpp_mov<0x101>(v);   // row_shl:1
+  return v;
+}
+
+template <int NW, int CLS>
+__device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* out, const AsmRec<CLS>& ar) {
+  // The pointers and scalars the gathers use, read once: wave-uniform values stay in scalar registers instead of being re-read
+  // from the problem record (a scalar load + a wait that also drains the LDS counter) inside the loops.
+  struct {
+    int Dn, nA, M, tile_mode, tpr, kd, ldh, asm_slots;
+    double w_ref, w_curv, w_str;
+    decltype(P_.camrec) camrec; decltype(P_.ob_ptr) ob_ptr, sh_ptr, ob_m, off_ptr, off_rc, tmask, actnode; decltype(P_.ob_c) ob_c, sh_cf, xyz0;
+    decltype(P_.sh_rec) sh_rec; decltype(P_.viewed) viewed; decltype(P_.Hb) Hb, Hbord, Hcorner, xyz, dbg;
+  } P{P_.Dn, P_.nA, P_.M, P_.tile_mode, P_.tpr, P_.kd, P_.ldh, P_.asm_slots, P_.w_ref, P_.w_curv, P_.w_str, P_.camrec, P_.ob_ptr, P_.sh_ptr, P_.ob_m, P_.off_ptr,
+      P_.off_rc, P_.tmask, P_.actnode, P_.ob_c, P_.sh_cf, P_.xyz0, P_.sh_rec, P_.viewed, P_.Hb, P_.Hbord, P_.Hcorner, P_.xyz, P_.dbg};
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  AS_T0();
   // camera corner: H_cc (lower 21) and b_c (6) as a block-wide reduction over the observations
   {
     double acc[27];
@@ -417,6 +484,7 @@ __device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec
     }
     __syncthreads();
   }
+  AS_ADD(32);
   const bool staged = P.tile_mode == 1 && P.asm_slots > 0;
   const int slots = P.asm_slots;
   lds_double* mytiles = ar.tiles + (size_t)wave * slots * (TS * TS);
@@ -424,13 +492,41 @@ __device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec
   const auto Hg = P.Hb;
   if (staged)
     for (int i = lane; i < slots * (TS * TS) / 2; i += 64) reinterpret_cast<__attribute__((address_space(3))) v2d*>(mytiles)[i] = (v2d){0.0, 0.0};
+  // node range of group I and the headers of a lane's first off-diagonal block: fetched one group ahead
+  auto group_nodes = [&](int I, int& a_lo, int& a_hi) {
+    a_lo = staged ? (TS * I) / 3 : 5 * I;
+    a_hi = min(staged ? (TS * I + TS - 1) / 3 : 5 * I + 4, P.nA - 1);
+  };
+  struct Hdr { int q, qe, bi, bj, ob0, ob1, sh0, sh1, dob0, dob1, dsh0, dsh1; };
+  auto load_hdr = [&](int I) -> Hdr {
+    Hdr h{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (I >= ngroups) return h;
+    int a_lo, a_hi;
+    group_nodes(I, a_lo, a_hi);
+    {   // list bounds of the lane's diagonal block
+      const int a = a_lo + (lane >> 3);
+      if ((lane >> 3) < 7 && a <= a_hi) { h.dob0 = P.ob_ptr[a]; h.dob1 = P.ob_ptr[a + 1]; h.dsh0 = P.sh_ptr[a]; h.dsh1 = P.sh_ptr[a + 1]; }
+    }
+    const int qb = P.off_ptr[a_lo];
+    h.qe = P.off_ptr[a_hi + 1];
+    h.q = qb + lane;
+    if (h.q < h.qe) {
+      h.bi = P.off_rc[2 * h.q]; h.bj = P.off_rc[2 * h.q + 1];
+      const int blk = P.nA + h.q;
+      h.ob0 = P.ob_ptr[blk]; h.ob1 = P.ob_ptr[blk + 1]; h.sh0 = P.sh_ptr[blk]; h.sh1 = P.sh_ptr[blk + 1];
+    }
+    return h;
+  };
+  Hdr nxt = load_hdr(wave);
 
 #pragma unroll 1
   for (int I = wave; I < ngroups; I += NW) {
     const int row_lo = staged ? TS * I : 0, row_hi = staged ? TS * I + TS - 1 : 0x7fffffff;
-    const int a_lo = staged ? row_lo / 3 : 5 * I;
-    const int a_hi = min(staged ? row_hi / 3 : 5 * I + 4, P.nA - 1);
+    int a_lo, a_hi;
+    group_nodes(I, a_lo, a_hi);
     const int mask = staged ? P.tmask[I] : 0;
+    Hdr cur = nxt;
+    nxt = load_hdr(I + NW);
     // element (r, c), c <= r, of H (and its mirror inside a diagonal tile, which is stored symmetric)
     auto put = [&](int r, int c, double v) {
       if (staged) {
@@ -448,7 +544,8 @@ __device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec
         }
       }
     };
-    // ---- diagonal blocks: 8 lanes per node, contributions dealt round-robin, partial sums combined by a fixed xor butterfly
+    // ---- diagonal blocks: 8 lanes per node, contributions dealt round-robin, partial sums combined by a fixed xor butterfly.
+    // Every level of the gather (list entries -> records) is issued for up to DCH contributions at once.
     {
       const int sub = lane & 7, a = a_lo + (lane >> 3);
       const bool on = (lane >> 3) < 7 && a <= a_hi;
@@ -458,42 +555,83 @@ __device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec
 #pragma unroll
       for (int k = 0; k < 6; k++) Hs[k] = 0.0;
       bn[0] = bn[1] = bn[2] = 0.0;
-      if (on) {
-        for (int p = P.ob_ptr[a] + sub, pe = P.ob_ptr[a + 1]; p < pe; p += 8) {
-          const auto rec = P.camrec + (size_t)P.ob_m[p] * SFT_CAM_STRIDE;
-          const double b = P.ob_c[p];
-          const double om = rec[0] * b;
-          sii += om * b;
+      // what the finishing lane of the node needs besides the sums: issued now, used after the gather
+      double A[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, eref[3] = {0.0, 0.0, 0.0};
+      bool vw = false;
+      if (on && sub == 0) {
 #pragma unroll
-          for (int k = 0; k < 5; k++) { G0[k] += om * rec[3 + k]; G1[k] += om * rec[8 + k]; }
-          g0 += om * rec[1];
-          g1 += om * rec[2];
+        for (int k = 0; k < 6; k++) A[k] = ar.A(6 * (size_t)a + k);
+        vw = P.viewed[a] != 0;
+        const int nd = P.actnode[a];
+#pragma unroll
+        for (int c = 0; c < 3; c++) eref[c] = P.xyz[3 * nd + c] - P.xyz0[3 * nd + c];
+      }
+      if (on) {
+        const int ob0 = cur.dob0, ob1 = cur.dob1, sh0 = cur.dsh0, sh1 = cur.dsh1;
+        constexpr int DCH = 2;   // per lane: 8 lanes x 2 = 16 contributions of each kind per round trip
+        for (int p0 = ob0 + sub; p0 < ob1; p0 += 8 * DCH) {
+          int mm[DCH];
+          double bb[DCH];
+#pragma unroll
+          for (int i = 0; i < DCH; i++) {
+            const int p = p0 + 8 * i;
+            const bool in = p < ob1;
+            mm[i] = in ? P.ob_m[p] : 0;
+            bb[i] = in ? P.ob_c[p] : 0.0;      // a zero coefficient switches a padding entry off
+          }
+          double rr[DCH][13];
+#pragma unroll
+          for (int i = 0; i < DCH; i++) {
+            const auto rec = P.camrec + (size_t)mm[i] * SFT_CAM_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 13; k++) rr[i][k] = rec[k];
+          }
+#pragma unroll
+          for (int i = 0; i < DCH; i++) {
+            if (p0 + 8 * i >= ob1) continue;
+            const double om = rr[i][0] * bb[i];
+            sii += om * bb[i];
+#pragma unroll
+            for (int k = 0; k < 5; k++) { G0[k] += om * rr[i][3 + k]; G1[k] += om * rr[i][8 + k]; }
+            g0 += om * rr[i][1];
+            g1 += om * rr[i][2];
+          }
         }
-        for (int p = P.sh_ptr[a] + sub, pe = P.sh_ptr[a + 1]; p < pe; p += 8) {
-          const uint32_t rc = P.sh_rec[p];
-          const bool is_star = (rc >> 30) == SFT_KIND_STAR;
-          const double* r = (is_star ? ar.star : ar.str) + 4 * (size_t)(rc & 0x3FFFFFu);
-          const double wgt = is_star ? P.w_curv : P.w_str;
-          const double f = wgt * P.sh_cf[2 * p], g = (wgt * P.sh_cf[2 * p + 1]) * r[3];
-          const double u0 = r[0], u1 = r[1], u2 = r[2];
-          Hs[0] += f * (u0 * u0); Hs[1] += f * (u1 * u0); Hs[2] += f * (u1 * u1);
-          Hs[3] += f * (u2 * u0); Hs[4] += f * (u2 * u1); Hs[5] += f * (u2 * u2);
-          bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
+        for (int p0 = sh0 + sub; p0 < sh1; p0 += 8 * DCH) {
+          uint32_t rc[DCH];
+          double c0[DCH], c1[DCH];
+#pragma unroll
+          for (int i = 0; i < DCH; i++) {
+            const int p = p0 + 8 * i;
+            const bool in = p < sh1;
+            rc[i] = in ? P.sh_rec[p] : 0xFFFFFFFFu;
+            c0[i] = in ? P.sh_cf[2 * p] : 0.0;
+            c1[i] = in ? P.sh_cf[2 * p + 1] : 0.0;
+          }
+          double r[DCH][4];
+#pragma unroll
+          for (int i = 0; i < DCH; i++) ar.rec4((rc[i] >> 30) == SFT_KIND_STAR, rc[i] & 0x3FFFFFu, rc[i] != 0xFFFFFFFFu, r[i]);
+#pragma unroll
+          for (int i = 0; i < DCH; i++) {
+            if (rc[i] == 0xFFFFFFFFu) continue;
+            const double wgt = (rc[i] >> 30) == SFT_KIND_STAR ? P.w_curv : P.w_str;
+            const double f = wgt * c0[i], g = (wgt * c1[i]) * r[i][3];
+            const double u0 = r[i][0], u1 = r[i][1], u2 = r[i][2];
+            Hs[0] += f * (u0 * u0); Hs[1] += f * (u1 * u0); Hs[2] += f * (u1 * u1);
+            Hs[3] += f * (u2 * u0); Hs[4] += f * (u2 * u1); Hs[5] += f * (u2 * u2);
+            bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
+          }
         }
       }
-      auto bfly = [](double v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
-      sii = bfly(sii); g0 = bfly(g0); g1 = bfly(g1);
+      AS_ADD(33);
+      sii = group8_sum(sii); g0 = group8_sum(g0); g1 = group8_sum(g1);   // fixed tree: ((0+4)+(2+6)) + ((1+5)+(3+7))
 #pragma unroll
-      for (int k = 0; k < 5; k++) { G0[k] = bfly(G0[k]); G1[k] = bfly(G1[k]); }
+      for (int k = 0; k < 5; k++) { G0[k] = group8_sum(G0[k]); G1[k] = group8_sum(G1[k]); }
 #pragma unroll
-      for (int k = 0; k < 6; k++) Hs[k] = bfly(Hs[k]);
+      for (int k = 0; k < 6; k++) Hs[k] = group8_sum(Hs[k]);
 #pragma unroll
-      for (int k = 0; k < 3; k++) bn[k] = bfly(bn[k]);
+      for (int k = 0; k < 3; k++) bn[k] = group8_sum(bn[k]);
       if (on && sub == 0) {
-        double A[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) A[k] = ar.A[6 * (size_t)a + k];
-        const bool vw = P.viewed[a] != 0;
         const double wr = vw ? P.w_ref : 0.0;
         // lower triangle of the 3x3 block: observations (s_ii A^T A), curvature + stretching, reference edge (J = I)
         put(3 * a, 3 * a, (sii * (A[0] * A[0] + A[3] * A[3]) + Hs[0]) + wr);
@@ -509,81 +647,111 @@ __device__ void assemble(const SftDev& P, double* red, double* out, const AsmRec
           for (int k = 0; k < 6; k++)
 #pragma unroll
             for (int c = 0; c < 3; c++) P.Hbord[(size_t)k * Dnp + 3 * a + c] = G0f[k] * A[c] + G1f[k] * A[3 + c];
-          double e[3] = {0.0, 0.0, 0.0};
-          if (vw) {
-            const int nd = P.actnode[a];
 #pragma unroll
-            for (int c = 0; c < 3; c++) e[c] = P.xyz[3 * nd + c] - P.xyz0[3 * nd + c];
-          }
-#pragma unroll
-          for (int c = 0; c < 3; c++) P.Hbord[(size_t)6 * Dnp + 3 * a + c] = (bn[c] - (A[c] * g0 + A[3 + c] * g1)) - wr * e[c];
+          for (int c = 0; c < 3; c++) P.Hbord[(size_t)6 * Dnp + 3 * a + c] = (bn[c] - (A[c] * g0 + A[3 + c] * g1)) - wr * eref[c];
         }
       }
     }
-    // ---- off-diagonal blocks of the block rows a_lo .. a_hi: one lane per block
-    const int qb = P.off_ptr[a_lo], qe = P.off_ptr[a_hi + 1];
-    for (int q = qb + lane; q < qe; q += 64) {
-      const int bi = P.off_rc[2 * q], bj = P.off_rc[2 * q + 1];
-      const int blk = P.nA + q;
+    AS_ADD(34);
+    // ---- off-diagonal blocks of the block rows a_lo .. a_hi: one lane per block; the headers of the first 64 came a group ahead
+    for (int q = cur.q; q < cur.qe; q += 64) {
+      Hdr h = cur;
+      if (q != cur.q) {   // more than 64 off-diagonal blocks in the group (rare): headers on demand
+        h.bi = P.off_rc[2 * q]; h.bj = P.off_rc[2 * q + 1];
+        const int blk = P.nA + q;
+        h.ob0 = P.ob_ptr[blk]; h.ob1 = P.ob_ptr[blk + 1]; h.sh0 = P.sh_ptr[blk]; h.sh1 = P.sh_ptr[blk + 1];
+      }
+      const int bi = h.bi, bj = h.bj;
+      // first chunk of both lists in one round trip; the records (LDS when they fit) in the next
+      constexpr int OCH = 4, SCH = 6;
+      int om[OCH];
+      double oc[OCH];
+      uint32_t rc[SCH];
+      double c0[SCH];
+#pragma unroll
+      for (int i = 0; i < OCH; i++) {
+        const bool in = h.ob0 + i < h.ob1;
+        om[i] = in ? P.ob_m[h.ob0 + i] : 0;
+        oc[i] = in ? P.ob_c[h.ob0 + i] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < SCH; i++) {
+        const bool in = h.sh0 + i < h.sh1;
+        rc[i] = in ? P.sh_rec[h.sh0 + i] : 0xFFFFFFFFu;
+        c0[i] = in ? P.sh_cf[2 * (h.sh0 + i)] : 0.0;
+      }
       double Ai[6], Aj[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { Ai[k] = ar.A[6 * (size_t)bi + k]; Aj[k] = ar.A[6 * (size_t)bj + k]; }
+      for (int k = 0; k < 6; k++) { Ai[k] = ar.A(6 * (size_t)bi + k); Aj[k] = ar.A(6 * (size_t)bj + k); }
       double s = 0.0;
       {
-        const int p0 = P.ob_ptr[blk], p1 = P.ob_ptr[blk + 1];
-        constexpr int CH = 4;   // four list entries and their weights in flight; the sum keeps the list order
-        for (int p = p0; p < p1; p += CH) {
-          double wv[CH], cv[CH];
+        double wv[OCH];
 #pragma unroll
-          for (int i = 0; i < CH; i++) {
-            const bool in = p + i < p1;
-            const int m = in ? P.ob_m[p + i] : 0;
-            cv[i] = in ? P.ob_c[p + i] : 0.0;
-            wv[i] = ar.wt[m];
-          }
+        for (int i = 0; i < OCH; i++) wv[i] = ar.wt(om[i]);
 #pragma unroll
-          for (int i = 0; i < CH; i++) s += wv[i] * cv[i];
-        }
+        for (int i = 0; i < OCH; i++) s += wv[i] * oc[i];
+        for (int p = h.ob0 + OCH; p < h.ob1; p++) s += ar.wt(P.ob_m[p]) * P.ob_c[p];   // more than OCH observations on one mesh edge
       }
       double H[9];
 #pragma unroll
       for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) H[3 * a + b] = s * (Ai[a] * Aj[b] + Ai[3 + a] * Aj[3 + b]);
-      for (int p = P.sh_ptr[blk], pe = P.sh_ptr[blk + 1]; p < pe; p++) {
-        const uint32_t rc = P.sh_rec[p];
-        const bool is_star = (rc >> 30) == SFT_KIND_STAR;
-        const double* r = (is_star ? ar.star : ar.str) + 4 * (size_t)(rc & 0x3FFFFFu);
-        const double f = (is_star ? P.w_curv : P.w_str) * P.sh_cf[2 * p];
+      auto add_shared = [&](uint32_t rcv, double cf, const double* r) {
+        const double f = ((rcv >> 30) == SFT_KIND_STAR ? P.w_curv : P.w_str) * cf;
         const double u0 = r[0], u1 = r[1], u2 = r[2];
         H[0] += f * (u0 * u0); H[1] += f * (u0 * u1); H[2] += f * (u0 * u2);
         H[3] += f * (u1 * u0); H[4] += f * (u1 * u1); H[5] += f * (u1 * u2);
         H[6] += f * (u2 * u0); H[7] += f * (u2 * u1); H[8] += f * (u2 * u2);
+      };
+      {
+        double r[SCH][4];
+#pragma unroll
+        for (int i = 0; i < SCH; i++) ar.rec4((rc[i] >> 30) == SFT_KIND_STAR, rc[i] & 0x3FFFFFu, rc[i] != 0xFFFFFFFFu, r[i]);
+#pragma unroll
+        for (int i = 0; i < SCH; i++)
+          if (rc[i] != 0xFFFFFFFFu) add_shared(rc[i], c0[i], r[i]);
+        for (int p = h.sh0 + SCH; p < h.sh1; p++) {
+          const uint32_t rcv = P.sh_rec[p];
+          double r1[4];
+          ar.rec4((rcv >> 30) == SFT_KIND_STAR, rcv & 0x3FFFFFu, true, r1);
+          add_shared(rcv, P.sh_cf[2 * p], r1);
+        }
       }
 #pragma unroll
       for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) put(3 * bi + a, 3 * bj + b, H[3 * a + b]);
     }
+    AS_ADD(35);
     // ---- the wavefront's tile row leaves as whole tiles (accumulator order, 32 bytes per lane); the LDS copy is cleared
     if (staged) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wavefront's own LDS stores have landed (no other wave touches these tiles)
       const int crow = lane >> 4, ccol = lane & 15;
-      int sl = 0;
-      for (int d = 0; d <= BT; d++) {
-        if (!((mask >> d) & 1)) continue;
-        lds_double* tl = mytiles + sl * (TS * TS) + 4 * lane;
-        v4d x = *reinterpret_cast<__attribute__((address_space(3))) v4d*>(tl);
-        if (d == 0) {   // identity padding behind the last unknown (rows >= Dn of the last tile)
+      using lds_v4d = __attribute__((address_space(3))) v4d;
+      lds_v4d* tl = reinterpret_cast<lds_v4d*>(mytiles + 4 * lane);
+      v4d x[BT + 1];
 #pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (crow + 4 * q == ccol && TS * I + ccol >= P.Dn) x[q] = 1.0;
-        }
-        *reinterpret_cast<SFT_G v4d*>(Hg + tile_off(I, d) + 4 * lane) = x;
-        *reinterpret_cast<__attribute__((address_space(3))) v4d*>(tl) = (v4d){0.0, 0.0, 0.0, 0.0};
-        sl++;
+      for (int sl = 0; sl <= BT; sl++)
+        if (sl < slots) x[sl] = tl[sl * (TS * TS / 4)];
+      int dd[BT + 1];   // tile distance of slot sl: the sl-th set bit of the mask
+      {
+        int mm = mask;
+#pragma unroll
+        for (int sl = 0; sl <= BT; sl++) { dd[sl] = mm ? __builtin_ctz(mm) : -1; mm &= mm - 1; }
       }
+#pragma unroll
+      for (int q = 0; q < 4; q++)   // identity padding behind the last unknown (rows >= Dn of the last diagonal tile; slot 0 is d = 0)
+        if (crow + 4 * q == ccol && TS * I + ccol >= P.Dn) x[0][q] = 1.0;
+#pragma unroll
+      for (int sl = 0; sl <= BT; sl++)
+        if (sl < slots && dd[sl] >= 0) {
+          *reinterpret_cast<SFT_G v4d*>(Hg + tile_off(I, dd[sl]) + 4 * lane) = x[sl];
+          tl[sl * (TS * TS / 4)] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
     }
+    AS_ADD(36);
+    if (threadIdx.x == 0) P.dbg[37] += 1.0;
   }
   __syncthreads();
 }
@@ -1255,7 +1423,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
   const auto Linv_g = uni(P.Linv);
   v4d acc[BT];
   v4d bacc;
-#ifdef SFT_STEP_TRACE
+#if defined(SFT_STEP_TRACE) && defined(DSH_LAB)
   long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt0;   // cycles spent waiting: [0] buffers free [1] W [2] X1 [3] X2..i [4] border [5] store flags [6] chol [7] whole loop
   const long long wloop0 = clock64();
 #define WT_BEGIN() wt0 = clock64()
@@ -1493,7 +1661,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
       }
     }
   }
-#ifdef SFT_STEP_TRACE
+#if defined(SFT_STEP_TRACE) && defined(DSH_LAB)
   wt[7] = clock64() - wloop0;
   if (lane == 0 && P.dbg[8] < 0.5) { for (int e = 0; e < 8; e++) P.dbg[16 + 8 * wave + e] = (double)wt[e] + 1.0; }
   __syncthreads();
@@ -1564,7 +1732,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   const auto Linv_g = uni(P.Linv);
   v4d acc[RPW][BT];
   v4d bacc[RPW];
-#ifdef SFT_STEP_TRACE
+#if defined(SFT_STEP_TRACE) && defined(DSH_LAB)
   long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt0;   // cycles spent waiting: [0] buffers free [1] W [2] X1 [3] X2..i [4] border [5] store flags [6] chol [7] whole loop
   const long long wloop0 = clock64();
 #define WT_BEGIN() wt0 = clock64()
@@ -1833,7 +2001,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
         }
     }
   }
-#ifdef SFT_STEP_TRACE
+#if defined(SFT_STEP_TRACE) && defined(DSH_LAB)
   wt[7] = clock64() - wloop0;
   if (lane == 0 && P.dbg[8] < 0.5) { for (int e = 0; e < 8; e++) P.dbg[16 + 8 * wave + e] = (double)wt[e] + 1.0; }
   __syncthreads();
@@ -1988,7 +2156,17 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   double* red = reinterpret_cast<double*>(smem + 512);   // 16*27 doubles
   double* out = red + 16 * 27 + 5;                        // 27 doubles
   double* panel = out + 32;
-  const AsmRec jp = asm_records<NW>(P, panel);   // the assembly records and staging tiles alias the solver workspace (dead once H is assembled)
+  // One linearisation: residuals + assembly records, then the normal equations.  The records and the staging tiles alias the
+  // solver workspace (dead once H is assembled); their placement class is a template parameter (AsmRec).
+  auto linearise = [&](auto ph_residuals) -> double {
+    double chi = 0.0;
+    switch (P.lds_class) {
+      case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 2>(P, red, out, jp); break; }
+      case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 1>(P, red, out, jp); break; }
+      default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 0>(P, red, out, jp); break; }
+    }
+    return chi;
+  };
   const int tid = threadIdx.x;
   const int Dn = P.Dn, ldh = P.ldh, kd = P.kd;
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
@@ -2026,8 +2204,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 
 #ifdef DSH_LAB
   if (P.mode == 1) {  // lab hook (dsh_lab_sft_system): one assembly at the initial state
-    const double chi = eval_edges<true>(P, ctl, red, out, jp);
-    assemble<NW>(P, red, out, jp);
+    const double chi = linearise([] {});
     if (tid == 0) P.dbg[0] = chi;
     return;
   }
@@ -2035,9 +2212,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 
   int total_trials = 0, iters = 0;
   for (int it = 0; it < P.max_iters; it++) {
-    const double chi0 = eval_edges<true>(P, ctl, red, out, jp);
-    PH_ADD(1);
-    assemble<NW>(P, red, out, jp);
+    const double chi0 = linearise([&] { PH_ADD(1); });
     PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
@@ -2099,7 +2274,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
       const double scale = out[0];
       __syncthreads();
       PH_ADD(7);
-      const double chi_new = eval_edges<false>(P, ctl, red, out, jp);
+      const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
       PH_ADD(1);
       if (tid == 0) {
         double tempChi = ok ? chi_new : DBL_MAX;
@@ -2211,13 +2386,16 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_assembly_kernel
   double* red = reinterpret_cast<double*>(smem + 512);
   double* out = red + 16 * 27 + 5;
   double* panel = out + 32;
-  const AsmRec jp = asm_records<NW>(P, panel);
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
   __syncthreads();
-  const double chi = eval_edges<true>(P, ctl, red, out, jp);
-  assemble<NW>(P, red, out, jp);
+  double chi = 0.0;
+  switch (P.lds_class) {
+    case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); assemble<NW, 2>(P, red, out, jp); break; }
+    case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); assemble<NW, 1>(P, red, out, jp); break; }
+    default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); assemble<NW, 0>(P, red, out, jp); break; }
+  }
   if (tid == 0) P.dbg[0] = chi;
 }
 

@@ -52,7 +52,7 @@ struct SftDev {
                               // MFMA factorisation (kd <= 256, sft_wide.h); 0: row-major band (general)
   int32_t asm_slots;          // tile mode 1: LDS tiles per tile row of the assembly's staging buffer (= most structurally non-zero tiles of
                               // a tile row); 0: the assembly stores its 3x3 blocks straight to global memory
-  int32_t lds_flags;          // assembly records kept in LDS instead of the workspace: bit 0 observation weights, 1 node matrices, 2 curvature, 3 stretch
+  int32_t lds_class;          // assembly records kept in LDS instead of the workspace: 0 none, 1 observation weights + curvature records, 2 also node matrices + stretch records
   int32_t tpr, wbt;           // tile modes: pitch of a tile row of the band storage in tiles (wbt + 1), sub-diagonal tiles per block
                               // column (mode 1: 8; mode 2: ceil(kd/16); an even pitch, i.e. an odd tile distance between (I,K) and
                               // (I,K+1), was tried against L2 channel aliasing: no effect)
@@ -98,7 +98,7 @@ struct SftDev {
   SFT_G double* xyz_bak;          // n*3
   SFT_G double* pose;             // 7 (inside *res)
   SFT_G double* camrec;           // M*SFT_CAM_STRIDE: rho' w, e, the non-zero entries of J_cam (sft_types.h:162-174)
-  SFT_G double* wtv;              // M     rho' w            (when not in LDS)
+  SFT_G double* wtv;              // M     rho' w            (lds_class < 1)
   SFT_G double* Anode;            // nA*6  node matrices A_i (when not in LDS): J_node of an observation = b_s A_node (sft_types.h:176-205)
   SFT_G double* Jstar;            // S*4  (u, r)           (when not in LDS)
   SFT_G double* Jstr;             // Es*4 (g, e)           (when not in LDS)
