@@ -746,7 +746,9 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
 #pragma unroll
       for (int sl = 0; sl <= BT; sl++)
         if (sl < slots && dd[sl] >= 0) {
-          *reinterpret_cast<SFT_G v4d*>(Hg + tile_off(I, dd[sl]) + 4 * lane) = x[sl];
+          // streaming store: 1.1 MB of tiles per problem and pass must not evict the records and gather lists the other wavefronts
+          // (and the problem sharing the CU) are reading through the same L2
+          __builtin_nontemporal_store(x[sl], reinterpret_cast<SFT_G v4d*>(Hg + tile_off(I, dd[sl]) + 4 * lane));
           tl[sl * (TS * TS / 4)] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
     }

@@ -1,7 +1,7 @@
 """Assembly-only launches of a C2 batch (dsh_lab_sft_assemble_timed), for rocprofv3 PMC passes: one full run, then `reps` launches
 that do one linearisation + normal-equation assembly per problem."""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import sft, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5

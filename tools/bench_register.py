@@ -1,7 +1,7 @@
 """Surface registration timing: device path (scaleMinMedian + OptimizeHorn + composition, template embedding) vs the CPU oracle, 1 core."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import sft, register, synth
 import oracle
 ctx = sft.Context(0)

@@ -1,7 +1,7 @@
 """Shape-from-Normals timing: device path vs the CPU oracle (Householder QR, 1 core)."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import sft, nrsfm, synth
 import oracle
 ctx = sft.Context(0)

@@ -1,5 +1,5 @@
 import sys, numpy as np, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import synth, sft, _lib
 ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 rows, cols, m = synth.CONFIGS["C2"]

@@ -1,6 +1,6 @@
 """Stress: barrier-free factor steps vs the barrier version on many problems, bit for bit, repeated."""
 import os, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import synth, sft
 ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"

@@ -1,6 +1,6 @@
 """Per-problem phase times under load (needs a build with EXTRA=-DSFT_PHASE_TIMERS): is one problem slower when all CUs are busy?"""
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import synth, sft
 ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 rows, cols, m = synth.CONFIGS["C2"]

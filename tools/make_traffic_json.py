@@ -1,0 +1,46 @@
+"""Turns the rocprofv3 PMC passes of tools/profile_round.sh into traffic.json (what bench.py carries as roofline.traffic).
+FETCH_SIZE reports half of the bytes of wide streaming reads on gfx950 (MI355X_MICROARCH.md, calibrated with tools/probes/pmc_calib.hip):
+x2; WRITE_SIZE is exact; both in KiB.  Per launch = mean over the dispatches of the kernel in the pass."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
+
+out_dir, commit = sys.argv[1], sys.argv[2]
+
+
+def per_launch(sub, counter, kernel):
+    tot = collections.defaultdict(float)
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                tot[r["Dispatch_Id"]] += float(r["Counter_Value"])
+    v = list(tot.values())
+    return (sum(v) / len(v), len(v)) if v else (None, 0)
+
+
+def avg_ms(sub, kernel):
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Name"]:
+                return float(r["AverageNs"]) * 1e-6, int(r["Calls"])
+    return None, 0
+
+
+res = {"_comment": "HBM traffic per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, --kernel-trace only; "
+                   "FETCH_SIZE x2, both KiB); bench.py drops these numbers when its device code hash differs",
+       "kernel_source_hash": kernel_source_hash(), "commit": commit}
+for key, kernel, fs, ws, st in (("C2_B8192", "sft_lm_kernel", "pmc_fetch", "pmc_write", "stats"),
+                                ("C2_B8192_assembly", "sft_assembly_kernel", "asm_fetch", "asm_write", "asm_stats")):
+    f, nf = per_launch(fs, "FETCH_SIZE", kernel)
+    w, nw = per_launch(ws, "WRITE_SIZE", kernel)
+    ms, calls = avg_ms(st, kernel)
+    if f is None or w is None:
+        continue
+    res[key] = {"fetch_kib": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024), "launches_in_pass": [nf, nw], "kernel_ms_rocprof_avg": ms, "calls": calls}
+print(json.dumps(res, indent=1))

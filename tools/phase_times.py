@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import synth, sft
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
