@@ -381,3 +381,55 @@ def make_register_scene(n: int = 600, seed: int = 5, noise: float = 2e-3, outlie
     Twc[:3, 3] = np.array([0.2, -0.1, 0.3], np.float32)
     u = rng.random(n + n * n)
     return dict(surface=surf.astype(np.float32), map=mp.astype(np.float32), Twc=Twc, u=u, scale=scale, R=R, t=t, outlier=bad)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# One coherent mapping scene for the chained NRSfM loop (DefLocalMapping::NRSfM, DefLocalMapping.cc:160-234 and
+# SchwarpDatabase::add): a smooth surface seen from a reference keyframe and `n_kf - 1` later keyframes.  Key points of
+# the reference keyframe carry ORB-like descriptors; the first `n_tracked` of them are already matched in the later
+# keyframes (tracked map points), the others are what the warp-guided search has to find.
+# ---------------------------------------------------------------------------------------------------------
+def make_mapping_scene(n_points: int = 520, n_tracked: int = 380, n_kf: int = 3, seed: int = 11, scale_true: float = 1.3):
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 520.0, 515.0, 322.5, 241.25
+    u = rng.uniform(-0.5, 0.5, n_points)
+    v = rng.uniform(-0.38, 0.38, n_points)
+    depth = 1.0 + 0.12 * u - 0.08 * v + 0.05 * np.sin(2.0 * u) * np.cos(1.5 * v)
+    X = np.stack([u * depth, v * depth, depth], 1)                      # reference camera frame
+    desc0 = rng.integers(0, 256, (n_points, 32), dtype=np.uint8)
+    octave = rng.integers(0, 6, n_points)
+    invsig = np.sqrt((1.2 ** (-2.0 * octave)).astype(np.float32)).astype(np.float32)
+    kfs = []
+    for j in range(1, n_kf):
+        R = _rodrigues(np.array([0.03 * j, -0.05 * j, 0.02]) * (1.0 + 0.1 * rng.standard_normal()))
+        t = np.array([0.05 * j, -0.03 * j, 0.02 * j])
+        Xc = X @ R.T + t
+        kp = Xc[:, :2] / Xc[:, 2:3] + rng.normal(scale=3e-4, size=(n_points, 2))
+        pix = kp * np.array([fx, fy]) + np.array([cx, cy])
+        desc = desc0.copy()
+        for i in range(n_points):                                      # noisy copies: a few flipped bits
+            for f in rng.integers(0, 256, int(rng.integers(0, 24))):
+                desc[i, f // 8] ^= np.uint8(1 << (f % 8))
+        n_extra = 300                                                   # distractors without a counterpart
+        pix_all = np.vstack([pix, np.stack([rng.uniform(0, 640, n_extra), rng.uniform(0, 480, n_extra)], 1)])
+        desc_all = np.vstack([desc, rng.integers(0, 256, (n_extra, 32), dtype=np.uint8)])
+        perm = rng.permutation(pix_all.shape[0])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.shape[0])
+        has_mp = np.zeros(pix_all.shape[0], np.uint8)
+        has_mp[inv[:n_tracked]] = 1                                     # tracked map points already own their key point
+        kfs.append(dict(R=R, t=t, kp_norm=kp.astype(np.float32), pix=pix_all[perm].astype(np.float32), desc=desc_all[perm], index_of_point=inv[:n_points],
+                        has_mp=has_mp))
+    umin, umax = float(u.min() - 0.10), float(u.max() + 0.10)
+    vmin, vmax = float(v.min() - 0.10), float(v.max() + 0.10)
+    # the keyframe's pose in the map and the map points the surface is registered against (another scale, small noise)
+    Rwc = _rodrigues(np.array([0.06, 0.03, -0.04]))
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, :3] = Rwc.astype(np.float32)
+    Twc[:3, 3] = np.array([0.1, -0.05, 0.2], np.float32)
+    Xw = scale_true * (X @ Rwc.T) + Twc[:3, 3].astype(np.float64)
+    map_pts = (Xw + 1e-3 * rng.standard_normal(Xw.shape)).astype(np.float32)
+    return dict(bbs2=(umin, umax, 13, vmin, vmax, 15, 2), bbs1=(umin, umax, 13, vmin, vmax, 15, 1), kp0=np.stack([u, v], 1).astype(np.float32), desc0=desc0,
+                invsig=invsig, depth=depth, X=X, kfs=kfs, n_tracked=n_tracked, cam=np.array([fx, fy, cx, cy], np.float32),
+                bounds=np.array([0.0, 640.0, 0.0, 480.0], np.float32), Twc=Twc, map_pts=map_pts, scale_true=scale_true,
+                u_stream=rng.random(n_points + n_points * n_points))

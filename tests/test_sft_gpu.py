@@ -201,6 +201,40 @@ def test_warm_started_sequence(gpu_ctx, oracle_mod):
         Tg, xg, To, xo = f.Tcw, f.nodes_xyz, r.Tcw, r.xyz
 
 
+def test_seq100_tracking_sequence_against_the_oracle_every_10th_frame(gpu_ctx, oracle_mod):
+    """SEQ100 (the runnable substitute of the Mandala sequences, BASELINE configs[2]): 100 frames of the C2 workload
+    (500-node template, 1000 matches per frame) with temporally smooth deformation and camera motion, every frame tracked from
+    the previous result through the one-shot call dsh_sft_solve (float32 pose round trip, DefTracking.cc:350).  Every 10th
+    frame the oracle solves the same frame from the same previous state: same LM trajectory, vertices, pose, outliers."""
+    from defslam_amd import sft, synth
+    rows, cols, m = synth.CONFIGS[synth.SEQ100["config"]]
+    n_frames = synth.SEQ100["n_frames"]
+    tmpl = synth.make_grid_template(rows, cols)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    T, x = np.eye(4, dtype=np.float32), tmpl.xyz0.copy()
+    checked = 0
+    total_iters = 0
+    for k in range(n_frames):
+        fr = synth.make_sequence_frame(tmpl, m, k, n_frames, synth.SEQ100["seq_id"], init_xyz=x, init_Tcw=T)
+        f = sft.frame_from_synth(fr)
+        call = gpu_ctx.prepare_solve(f, *regs, 1, 50)
+        inl = call()
+        assert f.status == 0 and f.iters >= 1
+        total_iters += f.iters
+        if k % 10 == 0 or k == n_frames - 1:
+            r = oracle_mod.sft_solve(tc, T, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, x, *regs, ldlt_mode=1)
+            _compare(f, inl, r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+            np.testing.assert_allclose(f.Tcw, r.Tcw, atol=2e-7)
+            checked += 1
+        assert inl > 0.85 * m                       # tracking holds: the 5 % synthetic outliers and little else are rejected
+        T, x = f.Tcw.copy(), f.nodes_xyz.copy()
+    assert checked == 11
+    # warm starts converge in fewer iterations than the cold first frame of the workload (about 10)
+    assert total_iters / n_frames < 10
+
+
 @pytest.mark.parametrize("shape", [(10, 10), (6, 41)], ids=["narrow", "wide-band"])
 def test_batch_equals_single_and_is_reproducible(gpu_ctx, shape):
     """Independent problems in one launch give bit-identical results to one-at-a-time solves, run after run (register-window
