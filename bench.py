@@ -132,6 +132,42 @@ def e2e_legs(ctx, tmpl, m, frames, regs):
     return out
 
 
+def shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch):
+    """One JOINT Shape-from-Template problem over all ranks: every rank holds one C2-sized patch (its own 500-node template and 1000
+    matches), all patches are seen by one camera; per damping trial the ranks all-reduce their 6x6 Schur complement of the camera
+    (dsh_sft_shared_solve: RCCL, 32 doubles, three times per trial).  Wall clock of the collective call, max over ranks."""
+    from defslam_amd import sft, synth
+    gt = synth.sequence_gt_pose(7, 100)             # the same ground-truth camera for every patch
+    fr = synth.make_frame(tmpl, m, 5000 + rank, gt_pose=gt)
+    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(sft.comm_unique_id()), dtype=torch.uint8).cuda()
+    if dist is not None:
+        dist.broadcast(uid, 0)
+    comm = sft.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+    try:
+        ts = []
+        f = None
+        for _ in range(4):
+            f = sft.frame_from_synth(fr)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sft.SharedCameraPoseOptimization(ctx, comm, f, *regs)
+            ts.append(time.perf_counter() - t0)
+        t = torch.tensor([min(ts[1:])], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finally:
+        comm.close()
+    return {"ranks": world, "patches": world, "nodes_total": world * tmpl.n, "matches_total": world * m, "iters": int(f.iters), "trials": int(f.trials),
+            "ms_per_joint_frame": 1e3 * dt, "joint_iters_per_s": f.iters / dt, "collectives_per_trial": 3, "doubles_per_collective": 32,
+            "what": "optional mode (SURVEY 8e): one joint problem, one patch per rank, shared camera; host-sequenced phase kernels with an RCCL "
+                    "all-reduce of the camera block between them -- latency-bound by design, the default for independent problems is the replica batch above"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +257,18 @@ def main():
     g_iters, g_trials, g_problems = (float(v) for v in tot.tolist())
     n_gpus = len(set(int(v) for v in devs.tolist()))   # distinct devices behind the ranks the collective saw
 
+    # ---- optional mode of the north star, measured next to the replicas: ONE joint problem, one patch per rank, shared camera,
+    # RCCL all-reduce of the camera block (collective: every rank takes part)
+    shared = None
+    if not args.no_extra_legs and args.config == "C2" and args.dist_backend == "nccl":
+        try:
+            shared = shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch)
+        except Exception as e:  # noqa: BLE001
+            shared = {"error": f"{type(e).__name__}: {e}"}
+        ctx.batch_upload(frames, *regs, 1, 50)      # the legs below expect the replica batch
+        ctx.batch_run()
+        ctx.synchronize()
+
     if rank == 0:
         # HBM traffic per launch: rocprofv3 PMC passes of exactly this configuration, carried with their provenance and dropped when the
         # device code has changed since (profiles/<round>/traffic.json; tools/profile_bench.sh regenerates it)
@@ -282,6 +330,8 @@ def main():
                          "note": "one persistent kernel = residuals + Jacobian assembly + banded-arrowhead Cholesky (FP64 MFMA) + LM control; "
                                  "frac = algorithmic solve flops / FP64 peak over the WHOLE kernel time; hbm_assembly = SURVEY 8d assembly bytes over the same time"},
         }
+        if shared is not None:
+            out["shared_camera"] = shared
         if not args.no_extra_legs:
             # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
             ctx.batch_upload(frames[:1], *regs, 1, 50)

@@ -80,7 +80,9 @@ EXPORTED_SYMBOLS = [
     "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit",
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
     "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
+    "dsh_comm_unique_id", "dsh_comm_create", "dsh_comm_destroy", "dsh_sft_shared_solve", "dsh_sft_shared_solve_group",
 ]
+DSH_COMM_ID_BYTES = 128
 
 # include/defslam_hip_debug.h: only libdefslam_hip_lab.so exports these
 LAB_SYMBOLS = ["dsh_lab_set_option", "dsh_lab_sft_run_timed", "dsh_lab_sft_assemble_timed", "dsh_lab_sft_phase_ms", "dsh_lab_sft_step_trace",
@@ -151,6 +153,11 @@ def _bind(path: str, lab: bool) -> C.CDLL:
     L.dsh_optimize_horn.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_double_p, C.c_double, C.c_double, c_i32_p, c_double_p]
     L.dsh_surface_register.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_double_p, C.c_int64, c_float_p, C.c_double, C.c_int, c_i32_p, c_double_p,
                                        c_double_p, c_float_p, c_double_p]
+    L.dsh_comm_unique_id.argtypes = [vp]
+    L.dsh_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.dsh_comm_destroy.argtypes = [vp]
+    L.dsh_sft_shared_solve.argtypes = [vp, vp, C.POINTER(SftFrameC), C.POINTER(SftResultC)]
+    L.dsh_sft_shared_solve_group.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(SftFrameC), C.POINTER(SftResultC)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("dsh_last_error", "dsh_stream"):

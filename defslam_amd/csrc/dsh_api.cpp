@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+
 #include <memory>
 #include <string>
 #include <vector>
@@ -23,6 +25,8 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
+extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
+extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
 #ifdef DSH_LAB
 extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 #endif
@@ -112,6 +116,9 @@ struct dsh_ctx : dsh_ctx_base {
   size_t jl_doubles = 0;
   int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
   size_t lds_configured[2] = {0, 0};   // dynamic LDS size the two launch shapes were last enabled for on THIS device
+  size_t lds_configured_sc = 0;        // the same for the phase kernel of the shared-camera mode
+  SftSc* d_sc = nullptr;               // shared-camera mode: LM state between the phase kernels
+  int force_waves = 0;                 // set while the shared-camera mode packs its problem (always the 8-wavefront shape)
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
@@ -290,6 +297,7 @@ int dsh_destroy(dsh_ctx* c) {
   if (c->d_tmpl) (void)hipFree(c->d_tmpl);
   c->scratch.release();
   if (c->d_batch) (void)hipFree(c->d_batch);
+  if (c->d_sc) (void)hipFree(c->d_sc);
   delete c;
   return DSH_OK;
 }
@@ -414,6 +422,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode == 1;
     if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
     if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
+    if (c->force_waves == 8) nw = 8;
   }
   // LDS of the assembly (it aliases the solver workspace): one staged tile row of H per wavefront, then the records a gather
   // touches most often, as far as the budget goes (4 wavefronts: two problems share a CU's 160 KB)
@@ -644,6 +653,203 @@ int dsh_sft_solve(dsh_ctx* c, const dsh_sft_frame* frame, dsh_sft_result* result
   if (rc != DSH_OK) return rc;
   return dsh_sft_batch_download(c, 1, result);
 }
+
+// ---- shared-camera mode across GPUs -------------------------------------------------------------------------------------
+// RCCL is bound at run time (dlopen): a process that never creates a communicator does not load it, and a host process that
+// already carries an RCCL (PyTorch) keeps a single copy.
+namespace {
+struct RcclUniqueId { char internal[128]; };
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load(std::string& err) {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) { err = std::string("RCCL not found: ") + dlerror(); return false; }
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { err = "RCCL symbols missing"; lib = nullptr; return false; }
+    return true;
+  }
+};
+Rccl g_rccl;
+constexpr int kNcclDouble = 8, kNcclSum = 0;   // ncclFloat64, ncclSum (rccl.h)
+}  // namespace
+
+struct dsh_comm {
+  int nranks = 1, rank = 0;
+  void* comm = nullptr;      // ncclComm_t
+  dsh_ctx* ctx = nullptr;
+};
+
+namespace {
+
+// One rank of a shared-camera solve as the driver sees it.
+struct ScRank { dsh_ctx* c; };
+
+// The all-reduce of the exchange vectors: RCCL between processes (one local rank), or a summation kernel between the
+// contexts of an in-process group.
+struct ScReducer {
+  dsh_comm* comm = nullptr;            // RCCL
+  SftSc** d_ptrs = nullptr;            // in-process group: device array of the ranks' state pointers
+  int reduce(std::vector<ScRank>& R, std::string& err) {
+    if (comm) {
+      dsh_ctx* c = R[0].c;
+      const int rc = g_rccl.AllReduce(c->d_sc->send, c->d_sc->recv, SFT_SC_XCHG, kNcclDouble, kNcclSum, comm->comm, c->stream);
+      if (rc != 0) { err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return DSH_ERR_HIP; }
+      return DSH_OK;
+    }
+    for (auto& r : R)
+      if (hipStreamSynchronize(r.c->stream) != hipSuccess) { err = "stream synchronise failed"; return DSH_ERR_HIP; }
+    if (sft_sc_local_reduce(d_ptrs, (int)R.size(), R[0].c->stream) != hipSuccess || hipStreamSynchronize(R[0].c->stream) != hipSuccess) { err = "local reduce failed"; return DSH_ERR_HIP; }
+    return DSH_OK;
+  }
+};
+
+int sc_phase(std::vector<ScRank>& R, int phase, std::string& err) {
+  for (auto& r : R) {
+    dsh_ctx* c = r.c;
+    (void)hipSetDevice(c->device);
+    if (sft_sc_launch(c->d_probs, c->d_sc, 1, phase, c->max_kd, c->jl_doubles, &c->lds_configured_sc, c->stream) != hipSuccess) { err = "phase kernel launch failed"; return DSH_ERR_HIP; }
+  }
+  return DSH_OK;
+}
+
+// The Levenberg-Marquardt loop of the shared-camera mode: four phase kernels per damping trial, an all-reduce of SFT_SC_XCHG
+// doubles behind LIN, FAC and SOL (sft_kernels.hip: sft_sc_kernel).  Every rank reads the same all-reduced numbers and takes
+// the same decisions; the host only reads "again" / "done" of its first local rank.
+int sc_solve(std::vector<ScRank>& R, ScReducer& red, int rank0, int nranks, const dsh_sft_frame* frames, dsh_sft_result* results, std::string& err) {
+  const int G = (int)R.size();
+  for (int g = 0; g < G; g++) {
+    dsh_ctx* c = R[g].c;
+    if (c->host_only) { err = "host-only context, no GPU (there is no CPU fallback)"; return DSH_ERR_NO_DEVICE; }
+    if (frames[g].max_iters < 1) { err = "max_iters must be >= 1"; return DSH_ERR_ARG; }
+    (void)hipSetDevice(c->device);
+    c->force_waves = 8;
+    const int rc = dsh_sft_batch_upload(c, 1, &frames[g]);
+    c->force_waves = 0;
+    if (rc != DSH_OK) { err = c->err; return rc; }
+    if (c->packed[0].h.tile_mode != 1) { err = "the shared-camera mode needs a template with half-bandwidth <= 128 (register-window solver)"; return DSH_ERR_ARG; }
+    if (!c->d_sc && hipMalloc((void**)&c->d_sc, sizeof(SftSc)) != hipSuccess) { err = "out of device memory"; return DSH_ERR_HIP; }
+    SftSc init{};
+    init.rank = rank0 + g;
+    init.nranks = nranks;
+    init.send[0] = (double)c->packed[0].h.nA;     // the regulariser weights divide by the JOINT counts (DefOptimizer.cc:458,497)
+    init.send[1] = (double)c->packed[0].h.Es;
+    if (hipMemcpyAsync(c->d_sc, &init, sizeof(SftSc), hipMemcpyHostToDevice, c->stream) != hipSuccess) { err = "state upload failed"; return DSH_ERR_HIP; }
+  }
+  if (nranks > SFT_SC_XCHG - 13) { err = "too many ranks for the exchange vector"; return DSH_ERR_ARG; }
+  int rc = red.reduce(R, err);
+  if (rc != DSH_OK) return rc;
+  for (int g = 0; g < G; g++) {   // joint counts -> weights of every rank's problem record
+    dsh_ctx* c = R[g].c;
+    double tot[2];
+    if (hipMemcpyAsync(tot, c->d_sc->recv, sizeof(tot), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { err = "read-back failed"; return DSH_ERR_HIP; }
+    SftDev& h = c->h_probs[0];
+    h.w_curv = frames[g].reg_lap / tot[0];
+    h.w_str = tot[1] > 0 ? frames[g].reg_inex / tot[1] : 0.0;
+    if (hipMemcpyAsync(c->d_probs, &h, sizeof(SftDev), hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { err = "problem record upload failed"; return DSH_ERR_HIP; }
+  }
+  for (int guard = 0; guard < DSH_MAX_ITERS + 1; guard++) {
+    if ((rc = sc_phase(R, SFT_SC_LIN, err)) != DSH_OK || (rc = red.reduce(R, err)) != DSH_OK) return rc;
+    int again = 0, done = 0;
+    do {
+      if ((rc = sc_phase(R, SFT_SC_FAC, err)) != DSH_OK || (rc = red.reduce(R, err)) != DSH_OK) return rc;
+      if ((rc = sc_phase(R, SFT_SC_SOL, err)) != DSH_OK || (rc = red.reduce(R, err)) != DSH_OK) return rc;
+      if ((rc = sc_phase(R, SFT_SC_CTL, err)) != DSH_OK) return rc;
+      int32_t flags[2];
+      dsh_ctx* c = R[0].c;
+      if (hipMemcpyAsync(flags, &c->d_sc->again, sizeof(flags), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { err = "flag read-back failed"; return DSH_ERR_HIP; }
+      again = flags[0];
+      done = flags[1];
+    } while (again);
+    if (done) break;
+  }
+  for (int g = 0; g < G; g++) {
+    R[g].c->ran = true;
+    rc = dsh_sft_batch_download(R[g].c, 1, &results[g]);
+    if (rc != DSH_OK) { err = R[g].c->err; return rc; }
+  }
+  return DSH_OK;
+}
+
+}  // namespace
+
+int dsh_comm_unique_id(void* id) {
+  std::string err;
+  if (!id || !g_rccl.load(err)) return DSH_ERR_HIP;
+  return g_rccl.GetUniqueId(static_cast<RcclUniqueId*>(id)) == 0 ? DSH_OK : DSH_ERR_HIP;
+}
+
+int dsh_comm_create(dsh_ctx* c, int nranks, int rank, const void* id, dsh_comm** out) {
+  if (!c || !out || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, DSH_ERR_ARG, "dsh_comm_create: bad argument");
+  *out = nullptr;
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_comm_create: host-only context");
+  std::string err;
+  if (!g_rccl.load(err)) return fail(c, DSH_ERR_HIP, "dsh_comm_create: " + err);
+  (void)hipSetDevice(c->device);
+  RcclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  std::unique_ptr<dsh_comm> cm(new dsh_comm());
+  cm->nranks = nranks; cm->rank = rank; cm->ctx = c;
+  const int rc = g_rccl.CommInitRank(&cm->comm, nranks, uid, rank);
+  if (rc != 0) return fail(c, DSH_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  *out = cm.release();
+  return DSH_OK;
+}
+
+int dsh_comm_destroy(dsh_comm* cm) {
+  if (!cm) return DSH_ERR_ARG;
+  if (cm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm->comm);
+  delete cm;
+  return DSH_OK;
+}
+
+int dsh_sft_shared_solve(dsh_ctx* c, dsh_comm* cm, const dsh_sft_frame* frame, dsh_sft_result* result) {
+  if (!c || !cm || !frame || !result || cm->ctx != c) return fail(c, DSH_ERR_ARG, "dsh_sft_shared_solve: bad argument");
+  std::vector<ScRank> R{ScRank{c}};
+  ScReducer red;
+  red.comm = cm;
+  std::string err;
+  const int rc = sc_solve(R, red, cm->rank, cm->nranks, frame, result, err);
+  return rc == DSH_OK ? rc : fail(c, rc, "dsh_sft_shared_solve: " + err);
+}
+
+int dsh_sft_shared_solve_group(int G, dsh_ctx* const* ctxs, const dsh_sft_frame* frames, dsh_sft_result* results) {
+  if (G < 1 || !ctxs || !frames || !results) return DSH_ERR_ARG;
+  for (int g = 0; g < G; g++)
+    if (!ctxs[g]) return DSH_ERR_ARG;
+  dsh_ctx* c0 = ctxs[0];
+  std::vector<ScRank> R;
+  for (int g = 0; g < G; g++) R.push_back(ScRank{ctxs[g]});
+  for (int g = 0; g < G; g++) {   // the state blocks must exist before their addresses are collected
+    if (ctxs[g]->host_only) return fail(c0, DSH_ERR_NO_DEVICE, "dsh_sft_shared_solve_group: host-only context, no GPU (there is no CPU fallback)");
+    (void)hipSetDevice(ctxs[g]->device);
+    if (!ctxs[g]->d_sc && hipMalloc((void**)&ctxs[g]->d_sc, sizeof(SftSc)) != hipSuccess) return fail(c0, DSH_ERR_HIP, "dsh_sft_shared_solve_group: out of device memory");
+  }
+  std::vector<SftSc*> ptrs;
+  for (int g = 0; g < G; g++) ptrs.push_back(ctxs[g]->d_sc);
+  ScReducer red;
+  (void)hipSetDevice(c0->device);
+  if (hipMalloc((void**)&red.d_ptrs, sizeof(SftSc*) * G) != hipSuccess) return fail(c0, DSH_ERR_HIP, "dsh_sft_shared_solve_group: out of device memory");
+  int rc = DSH_OK;
+  std::string err;
+  if (hipMemcpy(red.d_ptrs, ptrs.data(), sizeof(SftSc*) * G, hipMemcpyHostToDevice) != hipSuccess) { rc = DSH_ERR_HIP; err = "pointer table upload failed"; }
+  if (rc == DSH_OK) rc = sc_solve(R, red, 0, G, frames, results, err);
+  (void)hipFree(red.d_ptrs);
+  return rc == DSH_OK ? rc : fail(c0, rc, "dsh_sft_shared_solve_group: " + err);
+}
+
 
 #ifdef DSH_LAB
 // ---- lab entry points (include/defslam_hip_debug.h): libdefslam_hip_lab.so only ----------------------------------------

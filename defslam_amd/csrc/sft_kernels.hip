@@ -1402,7 +1402,34 @@ __device__ __forceinline__ void flags_wait(lds_int* flags, int lo, int hi, int v
 
 // 8-wavefront specialisation (one ring row per wave): the same algorithm as factor_tiles_df<NW> below written without the
 // per-row loops -- the compiler allocates registers noticeably better for it (10.8 vs 12.0 ms per C2 problem).
-__device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double* ws) {
+// Cholesky of the 6x6 Schur complement of the camera (lower triangle of Cn, row 6 = right-hand side), forward solve of its
+// right-hand side, x_cam into P.x[Dnp ..]; one thread.
+__device__ __forceinline__ void corner_finish(const SftDev& P, Ctl* ctl, lds_double* Cn, int Dnp) {
+  bool bad = false;
+  for (int k = 0; k < 6; k++) {
+    double d = Cn[k * 7 + k];
+    for (int j = 0; j < k; j++) d -= Cn[k * 7 + j] * Cn[k * 7 + j];
+    if (!(d > 0.0)) bad = true;
+    const double piv = sqrt(d);
+    Cn[k * 7 + k] = piv;
+    for (int r = k + 1; r < 7; r++) {
+      double v = Cn[r * 7 + k];
+      for (int j = 0; j < k; j++) v -= Cn[r * 7 + j] * Cn[k * 7 + j];
+      Cn[r * 7 + k] = v / piv;
+    }
+  }
+  if (bad) ctl->fact_ok = 0;
+  if (ctl->fact_ok)
+    for (int k = 5; k >= 0; k--) {
+      double v = Cn[6 * 7 + k];
+      for (int r = k + 1; r < 6; r++) v -= Cn[r * 7 + k] * P.x[Dnp + r];
+      P.x[Dnp + k] = v / Cn[k * 7 + k];
+    }
+}
+
+// lam_corner: damping added to the 6x6 camera block (the shared-camera mode adds it on one rank only); finish_corner = false leaves the
+// 7x7 Schur complement of the camera (lower triangle + right-hand side row) in P.Lcorner instead of solving for the camera update.
+__device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double* ws, double lam_corner, bool finish_corner) {
   constexpr int NW = 8, NT = 64 * NW, BOFF = 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1457,7 +1484,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int r = crow + 4 * q;
-      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
+      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lam_corner : 0.0);
     }
   }
   for (int i = tid; i < 2 * (BT + 1) * TILE_LDS; i += NT) XpB[i] = 0.0;   // rows 7..15 of both border panel tiles stay zero
@@ -1678,33 +1705,14 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    bool bad = false;
-    for (int k = 0; k < 6; k++) {
-      double d = Cn[k * 7 + k];
-      for (int j = 0; j < k; j++) d -= Cn[k * 7 + j] * Cn[k * 7 + j];
-      if (!(d > 0.0)) bad = true;
-      const double piv = sqrt(d);
-      Cn[k * 7 + k] = piv;
-      for (int r = k + 1; r < 7; r++) {
-        double v = Cn[r * 7 + k];
-        for (int j = 0; j < k; j++) v -= Cn[r * 7 + j] * Cn[k * 7 + j];
-        Cn[r * 7 + k] = v / piv;
-      }
-    }
-    if (bad) ctl->fact_ok = 0;
-    if (ctl->fact_ok)
-      for (int k = 5; k >= 0; k--) {
-        double v = Cn[6 * 7 + k];
-        for (int r = k + 1; r < 6; r++) v -= Cn[r * 7 + k] * P.x[Dnp + r];
-        P.x[Dnp + k] = v / Cn[k * 7 + k];
-      }
+  if (!finish_corner) {   // shared-camera mode: the local Schur complement goes out for the all-reduce
+    if (tid < 49) P.Lcorner[tid] = Cn[tid];
+    __syncthreads();
+    return;
   }
+  if (tid == 0) corner_finish(P, ctl, Cn, Dnp);
   __syncthreads();
 }
-
-#undef WT_BEGIN
-#undef WT_END
 
 template <int NW>
 __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* ws) {
@@ -2149,31 +2157,12 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 // ------------------------------------------------------------------------------------------
 // The persistent per-problem kernel
 // ------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const SftDev* __restrict__ probs) {
-  constexpr int NT = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const SftDev& P = probs[blockIdx.x];
-  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
-  double* red = reinterpret_cast<double*>(smem + 512);   // 16*27 doubles
-  double* out = red + 16 * 27 + 5;                        // 27 doubles
-  double* panel = out + 32;
-  // One linearisation: residuals + assembly records, then the normal equations.  The records and the staging tiles alias the
-  // solver workspace (dead once H is assembled); their placement class is a template parameter (AsmRec).
-  auto linearise = [&](auto ph_residuals) -> double {
-    double chi = 0.0;
-    switch (P.lds_class) {
-      case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 2>(P, red, out, jp); break; }
-      case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 1>(P, red, out, jp); break; }
-      default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 0>(P, red, out, jp); break; }
-    }
-    return chi;
-  };
+// Initial state of a run (restored from the uploaded frame) and the zeroed system with its identity padding.
+template <int NT>
+__device__ __forceinline__ void init_state(const SftDev& P) {
   const int tid = threadIdx.x;
   const int Dn = P.Dn, ldh = P.ldh, kd = P.kd;
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
-
-  // ---- initial state, zeroed system with identity padding --------------------------------
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
   if (P.tile_mode) {
@@ -2197,16 +2186,99 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
   for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
   if (tid == 0) {
-    ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0;
     P.res->iters = 0; P.res->trials = 0; P.res->status = 0; P.res->inliers = 0;
     for (int i = 0; i < 96; i++) P.dbg[i] = 0.0;
   }
+}
+
+// One linearisation: residuals + assembly records, then the normal equations.  The records and the staging tiles alias the
+// solver workspace (dead once H is assembled); their placement class is a template parameter (AsmRec).
+template <int NW, class F>
+__device__ __forceinline__ double linearise(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, F ph_residuals) {
+  double chi = 0.0;
+  switch (P.lds_class) {
+    case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 2>(P, red, out, jp); break; }
+    case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 1>(P, red, out, jp); break; }
+    default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 0>(P, red, out, jp); break; }
+  }
+  return chi;
+}
+
+// Classification and statistics (DefOptimizer.cc:515-559), map-point write-back (DefMapPoint.cc:129-147), counters.
+//   outlier[m] = (float)chi2 > 5.991 with the chi2 of the observation's LAST evaluation (stale when the last damping
+//   trial was rejected: the reference reads e->chi2() without recomputing the error of inliers);
+//   repError = sum over the inliers, in index order, of the reprojection error norm at the final estimate, / count.
+template <int NT>
+__device__ __forceinline__ void classify(const SftDev& P, Ctl* ctl, double* panel, int iters, int total_trials) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { quat_to_R(P.pose + 3, ctl->R); ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2]; ctl->nbad = 0; ctl->chi_tmp = 0.0; }
+  __syncthreads();
+  {
+    constexpr int CHK = 2048;                 // observations per pass: their error norms wait in LDS for the ordered sum
+    lds_double* ers = to_lds(panel);
+    int nbad = 0;
+    for (int m0 = 0; m0 < P.M; m0 += CHK) {
+      const int mend = min(P.M, m0 + CHK);
+      for (int m = m0 + tid; m < mend; m += NT) {
+        const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
+        const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
+        double pw[3], pc[3];
+        for (int k = 0; k < 3; k++) pw[k] = (b0 * P.xyz[3 * n0 + k] + b1 * P.xyz[3 * n1 + k]) + b2 * P.xyz[3 * n2 + k];
+        for (int k = 0; k < 3; k++) pc[k] = (ctl->R[3 * k] * pw[0] + ctl->R[3 * k + 1] * pw[1] + ctl->R[3 * k + 2] * pw[2]) + ctl->t[k];
+        const double e0 = P.obs_uv[2 * m] - ((pc[0] / pc[2]) * P.fx + P.cx);
+        const double e1 = P.obs_uv[2 * m + 1] - ((pc[1] / pc[2]) * P.fy + P.cy);
+        const double er = sqrt(e0 * e0 + e1 * e1);
+        const bool bad = (double)(float)P.chi2_obs[m] > 5.991;
+        P.outlier[m] = bad ? 1 : 0;
+        nbad += bad ? 1 : 0;
+        ers[m - m0] = bad ? -1.0 : er;          // error norms are >= 0 (or NaN): a negative entry marks an outlier
+        // float32 world position, plain IEEE products and sums like the host code of the reference (no contraction)
+        for (int k = 0; k < 3; k++)
+          P.mappoint[3 * m + k] = (float)__dadd_rn(__dadd_rn(__dmul_rn(b0, P.xyz[3 * n0 + k]), __dmul_rn(b1, P.xyz[3 * n1 + k])), __dmul_rn(b2, P.xyz[3 * n2 + k]));
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double sum = ctl->chi_tmp;
+        const int cnt = mend - m0;
+#pragma unroll 8
+        for (int i = 0; i < cnt; i++) { const double v = ers[i]; if (!(v < 0.0)) sum += v; }
+        ctl->chi_tmp = sum;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nbad += __shfl_down(nbad, off, 64);
+    if ((tid & 63) == 0 && nbad) atomicAdd(&ctl->nbad, nbad);   // integer: order independent
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int inl = P.M - ctl->nbad;
+    P.res->iters = iters; P.res->trials = total_trials; P.res->inliers = inl;
+    P.res->rep_error = ctl->chi_tmp / (double)(unsigned)inl;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const SftDev* __restrict__ probs) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);   // 16*27 doubles
+  double* out = red + 16 * 27 + 5;                        // 27 doubles
+  double* panel = out + 32;
+  const int tid = threadIdx.x;
+  const int Dn = P.Dn;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+
+  init_state<NT>(P);
+  if (tid == 0) { ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0; }
   __syncthreads();
   PH_T0();
 
 #ifdef DSH_LAB
   if (P.mode == 1) {  // lab hook (dsh_lab_sft_system): one assembly at the initial state
-    const double chi = linearise([] {});
+    const double chi = linearise<NW>(P, ctl, red, out, panel, [] {});
     if (tid == 0) P.dbg[0] = chi;
     return;
   }
@@ -2214,7 +2286,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 
   int total_trials = 0, iters = 0;
   for (int it = 0; it < P.max_iters; it++) {
-    const double chi0 = linearise([&] { PH_ADD(1); });
+    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [&] { PH_ADD(1); });
     PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
@@ -2247,7 +2319,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 #endif
         {
           PH_RESET();
-          if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel);
+          if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel, ctl->lambda, true);
           else factor_tiles_df<NW>(P, ctl, panel);
           PH_ADD(5);
         }
@@ -2323,54 +2395,163 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
     __syncthreads();
     if (term) break;
   }
-  // ---- classification and statistics (DefOptimizer.cc:515-559), map-point write-back (DefMapPoint.cc:129-147) ----------
-  //   outlier[m] = (float)chi2 > 5.991 with the chi2 of the observation's LAST evaluation (stale when the last damping
-  //   trial was rejected: the reference reads e->chi2() without recomputing the error of inliers);
-  //   repError = sum over the inliers, in index order, of the reprojection error norm at the final estimate, / count.
-  if (tid == 0) { quat_to_R(P.pose + 3, ctl->R); ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2]; ctl->nbad = 0; ctl->chi_tmp = 0.0; }
-  __syncthreads();
-  {
-    constexpr int CHK = 2048;                 // observations per pass: their error norms wait in LDS for the ordered sum
-    lds_double* ers = to_lds(panel);
-    int nbad = 0;
-    for (int m0 = 0; m0 < P.M; m0 += CHK) {
-      const int mend = min(P.M, m0 + CHK);
-      for (int m = m0 + tid; m < mend; m += NT) {
-        const int n0 = P.obs_nodes[3 * m], n1 = P.obs_nodes[3 * m + 1], n2 = P.obs_nodes[3 * m + 2];
-        const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
-        double pw[3], pc[3];
-        for (int k = 0; k < 3; k++) pw[k] = (b0 * P.xyz[3 * n0 + k] + b1 * P.xyz[3 * n1 + k]) + b2 * P.xyz[3 * n2 + k];
-        for (int k = 0; k < 3; k++) pc[k] = (ctl->R[3 * k] * pw[0] + ctl->R[3 * k + 1] * pw[1] + ctl->R[3 * k + 2] * pw[2]) + ctl->t[k];
-        const double e0 = P.obs_uv[2 * m] - ((pc[0] / pc[2]) * P.fx + P.cx);
-        const double e1 = P.obs_uv[2 * m + 1] - ((pc[1] / pc[2]) * P.fy + P.cy);
-        const double er = sqrt(e0 * e0 + e1 * e1);
-        const bool bad = (double)(float)P.chi2_obs[m] > 5.991;
-        P.outlier[m] = bad ? 1 : 0;
-        nbad += bad ? 1 : 0;
-        ers[m - m0] = bad ? -1.0 : er;          // error norms are >= 0 (or NaN): a negative entry marks an outlier
-        // float32 world position, plain IEEE products and sums like the host code of the reference (no contraction)
-        for (int k = 0; k < 3; k++)
-          P.mappoint[3 * m + k] = (float)__dadd_rn(__dadd_rn(__dmul_rn(b0, P.xyz[3 * n0 + k]), __dmul_rn(b1, P.xyz[3 * n1 + k])), __dmul_rn(b2, P.xyz[3 * n2 + k]));
-      }
-      __syncthreads();
-      if (tid == 0) {
-        double sum = ctl->chi_tmp;
-        const int cnt = mend - m0;
-#pragma unroll 8
-        for (int i = 0; i < cnt; i++) { const double v = ers[i]; if (!(v < 0.0)) sum += v; }
-        ctl->chi_tmp = sum;
-      }
+  classify<NT>(P, ctl, panel, iters, total_trials);
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared-camera mode across GPUs (BASELINE.json north star / configs[3]: patches or keyframes sharded over the GPUs of a node,
+// "RCCL all-reduce of the shared camera-pose normal equations").  Every rank owns the nodes and observations of its own
+// patch; the only coupling is the 6-dof camera.  With the camera last (arrowhead) the local factorisation ends in the
+// rank's Schur complement of the camera S_g = H_cc,g - H_cn,g H_nn,g^-1 H_nc,g and its right-hand side: the ranks all-reduce
+// those 27 numbers (sum), every rank solves the same 6x6 system and back-substitutes its own nodes -- the exact solution of
+// the joint normal equations.  Levenberg-Marquardt control is replicated: it only reads all-reduced scalars, so every rank
+// takes the same decisions.  The persistent kernel is cut at the collectives into four phases sequenced by the host
+// (dsh_multi.cpp): LIN linearise, FAC factorise, SOL camera solve + back substitution + update + trial evaluation, CTL
+// accept / reject.  State between the phases lives in SftSc (global memory).
+// ------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_sc_kernel(const SftDev* __restrict__ probs, SftSc* __restrict__ scs, int phase) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  SftSc& S = scs[blockIdx.x];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);
+  double* out = red + 16 * 27 + 5;
+  double* panel = out + 32;
+  const int tid = threadIdx.x;
+  const int Dn = P.Dn;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  if (phase == SFT_SC_LIN) {
+    if (S.it == 0) {
+      init_state<NT>(P);
+      if (tid == 0) { S.lambda = -1.0; S.ni = 2.0; S.nbad = 0; S.iters = 0; S.trials = 0; S.done = 0; }
       __syncthreads();
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nbad += __shfl_down(nbad, off, 64);
-    if ((tid & 63) == 0 && nbad) atomicAdd(&ctl->nbad, nbad);   // integer: order independent
+    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+    double mx = 0.0;
+    for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
+    mx = block_max(mx, red);
+    if (tid == 0) {
+      // send: robust chi2, diagonal of the local H_cc, local b_c, the largest node diagonal in this rank's slot (a sum over
+      // the ranks then carries every rank's maximum: no second collective for the max of computeLambdaInit)
+      for (int i = 0; i < SFT_SC_XCHG; i++) S.send[i] = 0.0;
+      S.send[0] = chi0;
+      for (int k = 0; k < 6; k++) { S.send[1 + k] = P.Hcorner[k * 8]; S.send[7 + k] = P.Hcorner[42 + k]; }
+      S.send[13 + S.rank] = mx;
+      S.qmax = 0; S.rho = 0.0; S.accepted = 0; S.all_ok = 1;
+    }
+  } else if (phase == SFT_SC_FAC) {
+    if (tid == 0 && S.qmax == 0) {   // first trial of the iteration: take over the all-reduced linearisation
+      S.chi_cur = S.chi_ini = S.recv[0];
+      for (int k = 0; k < 6; k++) S.bc[k] = S.recv[7 + k];
+      if (S.it == 0) {
+        double mxa = 0.0;
+        for (int k = 0; k < 6; k++) mxa = fmax(mxa, fabs(S.recv[1 + k]));
+        for (int r = 0; r < S.nranks; r++) mxa = fmax(mxa, S.recv[13 + r]);
+        S.lambda = 1e-5 * mxa; S.ni = 2.0; S.nbad = 0;
+      }
+      S.lambda_start = S.lambda;
+    }
     __syncthreads();
-  }
-  if (tid == 0) {
-    const int inl = P.M - ctl->nbad;
-    P.res->iters = iters; P.res->trials = total_trials; P.res->inliers = inl;
-    P.res->rep_error = ctl->chi_tmp / (double)(unsigned)inl;
+    // push
+    for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];
+    if (tid < 7) S.pose_bak[tid] = P.pose[tid];
+    if (tid == 0) ctl->lambda = S.lambda;
+    __syncthreads();
+    if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel, S.rank == 0 ? S.lambda : 0.0, false);
+    if (tid == 0) {
+      for (int i = 0; i < SFT_SC_XCHG; i++) S.send[i] = 0.0;
+      int q = 0;
+      for (int r = 0; r < 7; r++)
+        for (int c = 0; c <= r && c < 6; c++) S.send[q++] = P.Lcorner[r * 7 + c];   // 21 + 6 entries: lower 6x6, then the right-hand side row
+      S.send[27] = ctl->fact_ok ? 0.0 : 1.0;
+    }
+  } else if (phase == SFT_SC_SOL) {
+    lds_double* Cn = to_lds(panel);
+    if (tid == 0) {
+      int q = 0;
+      for (int r = 0; r < 7; r++)
+        for (int c = 0; c <= r && c < 6; c++) Cn[r * 7 + c] = S.recv[q++];
+      ctl->fact_ok = S.recv[27] == 0.0 ? 1 : 0;
+      ctl->lambda = S.lambda;
+      corner_finish(P, ctl, Cn, Dnp);
+      S.fact_ok = ctl->fact_ok;
+    }
+    __syncthreads();
+    backsub_tiles<NW>(P, ctl, panel);
+    // update
+    for (int i = tid; i < 3 * P.n; i += NT) {
+      const int a = P.act[i / 3];
+      if (a >= 0) P.xyz[i] += P.x[3 * a + (i % 3)];
+    }
+    if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
+    double sc = 0.0;
+    const double lam = S.lambda;
+    for (int r = tid; r < Dn; r += NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
+    __syncthreads();
+    block_sum<1>(&sc, red, out);
+    const double scale_nodes = out[0];
+    __syncthreads();
+    const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+    if (tid == 0) {
+      for (int i = 0; i < SFT_SC_XCHG; i++) S.send[i] = 0.0;
+      S.send[0] = chi_new; S.send[1] = scale_nodes;
+    }
+  } else {   // SFT_SC_CTL
+    if (tid == 0) {
+      const int ok = S.fact_ok;
+      S.all_ok &= ok;
+      double scale = S.recv[1];   // node parts of every rank; the camera part once, from the all-reduced b_c
+      for (int k = 0; k < 6; k++) { const double xv = P.x[Dnp + k]; scale += xv * (S.lambda * xv + S.bc[k]); }
+      double tempChi = ok ? S.recv[0] : DBL_MAX;
+      double rho = (S.chi_cur - tempChi);
+      rho /= (scale + 1e-3);
+      S.rho = rho;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        const double sf = fmax(1. / 3., alpha);
+        S.lambda *= sf; S.ni = 2.0; S.chi_cur = tempChi; S.accepted = 1;
+        ctl->stop = 0;
+      } else {
+        S.lambda *= S.ni; S.ni *= 2.0;
+        ctl->stop = 1;
+      }
+      S.qmax++;
+    }
+    __syncthreads();
+    if (ctl->stop) {  // pop
+      for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
+      if (tid < 7) P.pose[tid] = S.pose_bak[tid];
+    }
+    __syncthreads();
+    const bool again = (S.rho < 0) && (S.qmax < 10);
+    bool finished = false;
+    if (!again) {   // the outer iteration is over: trace, termination tests (sparse_optimizer.cpp / DefOptimizer's stop rule)
+      if (tid == 0) {
+        S.trials += S.qmax;
+        S.iters++;
+        if (P.trace) {
+          double* t = P.trace + S.it * 8;
+          t[0] = S.chi_ini; t[1] = S.lambda_start; t[2] = S.qmax; t[3] = S.chi_cur; t[4] = S.lambda; t[5] = S.rho; t[6] = S.accepted; t[7] = S.all_ok;
+        }
+        if (!S.all_ok) P.res->status |= 1;
+        bool term = (S.qmax == 10) || (S.rho == 0);
+        if (!term) {
+          if ((S.chi_ini - S.chi_cur) * 1e3 < S.chi_ini) S.nbad++; else S.nbad = 0;
+          term = S.nbad >= 3;
+        }
+        S.it++;
+        if (S.it >= P.max_iters) term = true;
+        S.done = term ? 1 : 0;
+        ctl->qmax = term ? 1 : 0;
+      }
+      __syncthreads();
+      finished = ctl->qmax != 0;
+    }
+    if (tid == 0) S.again = again ? 1 : 0;
+    if (finished) classify<NT>(P, ctl, panel, S.iters, S.trials);
   }
 }
 
@@ -2430,6 +2611,30 @@ extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_
   return hipGetLastError();
 }
 #endif
+
+extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+  if (lds > *configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_sc_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    *configured = lds;
+  }
+  hipLaunchKernelGGL(sft_sc_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs, d_sc, phase);
+  return hipGetLastError();
+}
+
+// sum of G exchange vectors (the in-process stand-in of the all-reduce: dsh_comm_create_local)
+__global__ void sft_sc_local_reduce_kernel(SftSc* const* scs, int G) {
+  const int i = threadIdx.x;
+  if (i >= SFT_SC_XCHG) return;
+  double s = 0.0;
+  for (int g = 0; g < G; g++) s += scs[g]->send[i];
+  for (int g = 0; g < G; g++) scs[g]->recv[i] = s;
+}
+extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream) {
+  hipLaunchKernelGGL(sft_sc_local_reduce_kernel, dim3(1), dim3(64), 0, stream, d_ptrs, G);
+  return hipGetLastError();
+}
 
 // `configured` (two slots, owned by the calling context, i.e. per device): the dynamic LDS size the two kernels were last
 // enabled for on that device -- the function attribute is per device, a process-wide cache would skip the second GPU.

@@ -45,6 +45,20 @@ struct SftResHdr {
   double pad[5];
 };                                          // 128 bytes
 
+// State of the shared-camera mode between its phase kernels (sft_kernels.hip: sft_sc_kernel; host loop: dsh_multi.cpp).
+#define SFT_SC_XCHG 32          // doubles per exchange (all-reduce) vector
+#define SFT_SC_LIN 0
+#define SFT_SC_FAC 1
+#define SFT_SC_SOL 2
+#define SFT_SC_CTL 3
+struct SftSc {
+  double send[SFT_SC_XCHG], recv[SFT_SC_XCHG];   // local partials / their sum over the ranks
+  double lambda, ni, chi_cur, chi_ini, rho, lambda_start;
+  double bc[6];                 // all-reduced b_c of the current linearisation
+  double pose_bak[8];
+  int32_t it, qmax, nbad, accepted, again, done, all_ok, fact_ok, iters, trials, rank, nranks;
+};
+
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, noff, max_iters, mode;

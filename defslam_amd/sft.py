@@ -344,6 +344,86 @@ def DefPoseOptimizationBatch(ctx: Context, frames: Sequence[Frame], RegLap: floa
     return ctx.batch_download()
 
 
+# ---- shared-camera mode across GPUs (include/defslam_hip.h: dsh_comm_*, dsh_sft_shared_solve*) -------------------------
+def _result_buffers(f: Frame, max_iters: int):
+    M, n = f.obs_nodes.shape[0], f.nodes_xyz.shape[0]
+    b = dict(Tcw=np.zeros((4, 4), np.float32), pose7=np.zeros(7), xyz=np.zeros((n, 3)), chi2=np.zeros(M), outl=np.zeros(M, np.uint8),
+             mp=np.zeros((M, 3), np.float32), trace=np.zeros((max(max_iters, 1), _lib.DSH_TRACE_STRIDE)))
+    r = _lib.SftResultC()
+    r.Tcw = _ptr(b["Tcw"], C.c_float)
+    r.pose7 = _ptr(b["pose7"], C.c_double)
+    r.xyz = _ptr(b["xyz"], C.c_double)
+    r.chi2_obs = _ptr(b["chi2"], C.c_double)
+    r.outlier = _ptr(b["outl"], C.c_uint8)
+    r.mappoint_xyz = _ptr(b["mp"], C.c_float)
+    r.trace = _ptr(b["trace"], C.c_double)
+    return b, r
+
+
+def _write_back(f: Frame, b: dict, r) -> int:
+    f.Tcw, f.pose7, f.nodes_xyz, f.chi2_obs, f.mappoints = b["Tcw"], b["pose7"], b["xyz"], b["chi2"], b["mp"]
+    f.mvbOutlier = b["outl"].astype(bool)
+    f.repError = float(np.float32(r.rep_error))
+    f.rep_error_f64 = r.rep_error
+    f.iters, f.trials, f.dim, f.half_bandwidth, f.status = r.iters, r.trials, r.dim, r.half_bandwidth, r.status
+    f.trace = b["trace"][:r.iters].copy()
+    return int(r.inliers)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId: call on one rank and hand the bytes to every rank."""
+    buf = C.create_string_buffer(_lib.DSH_COMM_ID_BYTES)
+    if _lib.load().dsh_comm_unique_id(buf) != _lib.DSH_OK:
+        raise DshError("dsh_comm_unique_id failed (RCCL not available?)")
+    return buf.raw
+
+
+class Comm:
+    """An RCCL communicator on a context's GPU (collective over the ranks: one process per GPU)."""
+
+    def __init__(self, ctx: Context, nranks: int, rank: int, unique_id: bytes):
+        self._ctx = ctx
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), _lib.DSH_COMM_ID_BYTES)
+        ctx._check(ctx._L.dsh_comm_create(ctx._h, int(nranks), int(rank), buf, C.byref(h)), "dsh_comm_create")
+        self._h = h
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._ctx._L.dsh_comm_destroy(self._h)
+            self._h = None
+
+
+def SharedCameraPoseOptimization(ctx: Context, comm: Comm, pFrame: Frame, RegLap: float = 5000, RegInex: float = 5000, RegTemp: float = 0,
+                                 NeighboursLayers: int = 1, max_iters: int = 50) -> int:
+    """Collective over the communicator's ranks: every rank passes its own patch (template in `ctx`, observations in `pFrame`), all
+    patches are seen by one camera whose pose is estimated jointly (one all-reduce of the camera block per damping trial)."""
+    keep: list = []
+    fc = ctx._frame_c(pFrame, RegLap, RegInex, RegTemp, NeighboursLayers, max_iters, keep)
+    b, r = _result_buffers(pFrame, max_iters)
+    ctx._check(ctx._L.dsh_sft_shared_solve(ctx._h, comm._h, C.byref(fc), C.byref(r)), "dsh_sft_shared_solve")
+    return _write_back(pFrame, b, r)
+
+
+def SharedCameraPoseOptimizationGroup(ctxs: Sequence[Context], frames: Sequence[Frame], RegLap: float = 5000, RegInex: float = 5000, RegTemp: float = 0,
+                                      NeighboursLayers: int = 1, max_iters: int = 50) -> List[int]:
+    """The shared-camera protocol inside one process over len(ctxs) contexts (the all-reduce is a summation kernel)."""
+    G = len(ctxs)
+    keep: list = []
+    fcs = (_lib.SftFrameC * G)()
+    res = (_lib.SftResultC * G)()
+    bufs = []
+    for g in range(G):
+        fcs[g] = ctxs[g]._frame_c(frames[g], RegLap, RegInex, RegTemp, NeighboursLayers, max_iters, keep)
+        b, r = _result_buffers(frames[g], max_iters)
+        bufs.append(b)
+        res[g] = r
+    hs = (C.c_void_p * G)(*[c._h for c in ctxs])
+    ctxs[0]._check(ctxs[0]._L.dsh_sft_shared_solve_group(G, hs, fcs, res), "dsh_sft_shared_solve_group")
+    return [_write_back(frames[g], bufs[g], res[g]) for g in range(G)]
+
+
 def frame_from_synth(fr) -> Frame:
     return Frame(Tcw=fr.Tcw.copy(), K=fr.K.copy(), N=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary, obs_uv=fr.obs_uv,
                  obs_invsig2=fr.obs_invsig2, nodes_xyz=fr.xyz.copy())

@@ -125,6 +125,29 @@ int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
  * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload. */
 int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int32_t* counts);
 
+/* ---- shared-camera Shape-from-Template across GPUs ---------------------------------------------------------------------
+ * BASELINE north star: "the path shards naturally over independent keyframes / mesh patches ... with RCCL all-reduce of the
+ * shared camera-pose normal equations".  Every rank (one GPU, one context) holds one patch -- its own template, observations
+ * and vertices -- and all patches are seen by ONE camera whose pose is estimated jointly (the reference's graph with a single
+ * VertexSE3Expmap and the node vertices of every patch, DefOptimizer.cc:293-507).  The camera is the only coupling: each rank
+ * factorises its node block and reduces to its 6x6 Schur complement of the camera; the ranks all-reduce that block, its
+ * right-hand side and the scalars of the Levenberg-Marquardt control (32 doubles, three times per damping trial) and continue
+ * with identical decisions.  The result equals the single-GPU solve of the union of the patches (tested).  The default for
+ * independent problems stays dsh_sft_batch_*: no collective at all. */
+typedef struct dsh_comm dsh_comm;
+#define DSH_COMM_ID_BYTES 128
+/* ncclGetUniqueId: call on one rank, hand the bytes to every rank (RCCL is loaded at the first call, not at library load). */
+int dsh_comm_unique_id(void* id /* DSH_COMM_ID_BYTES */);
+/* ncclCommInitRank on the context's GPU; collective over the nranks processes. */
+int dsh_comm_create(dsh_ctx* ctx, int nranks, int rank, const void* id, dsh_comm** out);
+int dsh_comm_destroy(dsh_comm* comm);
+/* Collective: every rank passes its own patch (frame->Tcw, K, n_frame must agree); result as dsh_sft_solve, per patch, with
+ * the joint pose.  The regulariser weights use the joint counts (all optimised nodes / stretch edges of all patches). */
+int dsh_sft_shared_solve(dsh_ctx* ctx, dsh_comm* comm, const dsh_sft_frame* frame, dsh_sft_result* result);
+/* The same protocol inside one process over G contexts (normally on one GPU), the all-reduce done by a summation kernel:
+ * how the protocol is validated against the single-GPU solve where only one GPU is available. */
+int dsh_sft_shared_solve_group(int G, dsh_ctx* const* ctxs, const dsh_sft_frame* frames, dsh_sft_result* results);
+
 /* ---- NRSfM mapping side ----------------------------------------------------------------------- */
 /* Uniform bicubic B-spline (BBS::bbs_t, Thirdparty/BBS/bbs.h:41-50). */
 typedef struct dsh_bbs {

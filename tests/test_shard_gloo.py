@@ -70,3 +70,85 @@ def test_shard_range_partitions_everything_once():
                 seen += list(rr)
                 assert len(rr) in (n // world, n // world + 1)
             assert seen == list(range(n))
+
+
+# ---- the shared-camera exchange protocol between two real processes --------------------------------------------------------
+# Every rank owns one patch of the template (its nodes and observations); the camera is shared.  What crosses the process
+# boundary is what dsh_sft_shared_solve all-reduces over RCCL: the rank's 6x6 Schur complement of the camera and its right-hand
+# side.  Here the per-rank normal equations come from the oracle (no GPU in this container) and the all-reduce is gloo; the
+# result must be the solution of the JOINT system the oracle builds for the union of the patches.
+def _camera_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from defslam_amd import synth
+    from test_shared_camera_gpu import _split_template
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tmpl = synth.make_grid_template(8, 14)
+        fr = synth.make_frame(tmpl, 500, 6)
+        rng = np.random.default_rng(3)
+        fr.xyz = fr.xyz + rng.normal(scale=0.002, size=fr.xyz.shape)
+        facets, patches = _split_template(tmpl, [7])
+        on_patch = np.isin(np.sort(tmpl.facets[fr.obs_facet], axis=1).view([("", np.int32)] * 3).ravel(),
+                           np.sort(facets, axis=1).view([("", np.int32)] * 3).ravel())
+        for k in ["obs_facet", "obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+            setattr(fr, k, getattr(fr, k)[on_patch])
+        regs = np.array([synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP])
+        tcj = oracle.template_build(tmpl.xyz0, facets)
+        # this rank's patch; the regulariser weights divide by the JOINT counts and the joint median edge length: scale the
+        # patch's parameters so that its own normalisation gives the joint weights
+        ids, lf = patches[rank]
+        local = -np.ones(tmpl.n, np.int64)
+        local[ids] = np.arange(ids.size)
+        sel = np.all(local[fr.obs_nodes] >= 0, axis=1)
+        tcp = oracle.template_build(tmpl.xyz0[ids], lf)
+        counts = torch.tensor([float(ids.size), float(tcp.E)], dtype=torch.float64)   # every node of a patch is optimised here (all viewed or 1-ring)
+        tot = counts.clone()
+        dist.all_reduce(tot)
+        scale = np.array([counts[0] / tot[0], counts[1] / tot[1], (tcp.median_L / tcj.median_L) ** 2])
+        Hp, bp, chip = oracle.sft_system(tcp, fr.Tcw, fr.K, fr.n_frame, local[fr.obs_nodes[sel]].astype(np.int32), fr.obs_bary[sel], fr.obs_uv[sel],
+                                         fr.obs_invsig2[sel], fr.xyz[ids], *(regs * scale))
+        assert Hp.shape[0] == 6 + 3 * ids.size
+        lam = 1e-3 * np.abs(np.diag(Hp)).max()
+        lam_t = torch.tensor([lam], dtype=torch.float64)
+        dist.all_reduce(lam_t, op=dist.ReduceOp.MAX)
+        lam = float(lam_t.item())
+        Hnn = Hp[6:, 6:] + lam * np.eye(3 * ids.size)
+        Hcn = Hp[:6, 6:]
+        S = Hp[:6, :6] + (lam * np.eye(6) if rank == 0 else 0.0) - Hcn @ np.linalg.solve(Hnn, Hcn.T)
+        rhs = bp[:6] - Hcn @ np.linalg.solve(Hnn, bp[6:])
+        buf = torch.from_numpy(np.concatenate([S[np.tril_indices(6)], rhs, [chip]]))   # 21 + 6 + 1 = what the ranks exchange
+        dist.all_reduce(buf)
+        St = np.zeros((6, 6))
+        St[np.tril_indices(6)] = buf[:21].numpy()
+        St = St + np.tril(St, -1).T
+        xc = np.linalg.solve(St, buf[21:27].numpy())
+        xn = np.linalg.solve(Hnn, bp[6:] - Hcn.T @ xc)
+        # the joint system of the union of the patches (every rank builds it: the test's reference)
+        Hj, bj, chij = oracle.sft_system(tcj, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs)
+        xj = np.linalg.solve(Hj + lam * np.eye(Hj.shape[0]), bj)
+        rows = 6 + 3 * np.repeat(ids, 3) + np.tile(np.arange(3), ids.size)
+        q.put((rank, float(np.abs(xc - xj[:6]).max() / np.abs(xj[:6]).max()), float(np.abs(xn - xj[rows]).max() / np.abs(xj).max()),
+               float(abs(buf[27].item() - chij) / chij)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shared_camera_exchange_protocol_between_two_processes():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_camera_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1]
+    for _, err_cam, err_nodes, err_chi in got:
+        assert err_cam < 1e-9 and err_nodes < 1e-9 and err_chi < 1e-12
