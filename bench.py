@@ -68,6 +68,16 @@ def cpu_baseline(tmpl, m, budget_s):
             "lm_trials_per_s": trials / dt, "frames_per_s": probs / dt}
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator is created; flushed here it lands BEFORE the JSON line
+    (the last line of stdout is the result), not at interpreter exit."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -145,6 +155,7 @@ def shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch):
     if dist is not None:
         dist.broadcast(uid, 0)
     comm = sft.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+    flush_c_stdio()
     try:
         ts = []
         f = None
@@ -214,6 +225,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.dist_backend)
+        flush_c_stdio()
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -360,7 +372,8 @@ def main():
                 "library": "libdefslam_hip_lab.so (dsh_lab_sft_assemble_timed -> sft_assembly_kernel)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tmpl, m, args.cpu_seconds)
-        print(json.dumps(out))
+        flush_c_stdio()
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
