@@ -139,3 +139,131 @@ def test_def_pose_optimization_hip_mutates_frame_map_and_template_like_the_refer
     good = (kinds == 1) | (kinds == 3) | (kinds == 4)
     mI, mO = int((~outl[good]).sum()), int(outl[good].sum())
     assert open(tmp_path / "Matches.txt").read() == f"00037 {mI} {mO} 640\n"
+
+
+@pytest.mark.gpu
+def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow(gpu_ctx, tmp_path):
+    """SchwarpDatabaseHIP::add for three keyframes and ObtainK1K2HIP through the compiled shim (stand-in KeyFrame / MapPoint /
+    WarpDatabase classes) against the same sequence of C-ABI calls issued from Python with the reference's bookkeeping:
+    which matches are removed after the initial warp (including the residual-index quirk of DefORBmatcher.cc:167-175), which are
+    found through the warp, which DiffProp records are stored, the normals and covariances written back."""
+    from defslam_amd import nrsfm, synth
+    _build()
+    exe = os.path.join(INTEG, "build", "mapping_shim_test")
+    sc = synth.make_mapping_scene(seed=31)
+    P, nt = sc["kp0"].shape[0], sc["n_tracked"]
+    cam, lam = sc["cam"], 0.1
+    # a few gross mismatches among the tracked points so that the initial-warp test removes something
+    rng = np.random.default_rng(2)
+    levels = (1.2 ** (-2.0 * np.arange(8))).astype(np.float32)
+    octave = np.round(-np.log(sc["invsig"].astype(np.float64) ** 2) / (2 * np.log(1.2))).astype(int)
+    kfs = []
+    pix0 = sc["kp0"] * cam[:2] + cam[2:]
+    kfs.append(dict(N=P, pix=pix0.astype(np.float32), norm=sc["kp0"], desc=sc["desc0"], mp=np.arange(P), octave=octave))
+    for kf in sc["kfs"]:
+        N = kf["pix"].shape[0]
+        pix = kf["pix"].copy()
+        bad = kf["index_of_point"][rng.choice(nt, 6, replace=False)]
+        pix[bad] += rng.uniform(25, 40, size=(6, 2)).astype(np.float32)
+        mp = -np.ones(N, int)
+        mp[kf["index_of_point"][:nt]] = np.arange(nt)
+        kfs.append(dict(N=N, pix=pix, norm=((pix - cam[2:]) / cam[:2]).astype(np.float32), desc=kf["desc"], mp=mp, octave=rng.integers(0, 6, N)))
+    bb = sc["bbs2"]
+    with open(tmp_path / "in.txt", "w") as f:
+        f.write(f"{len(kfs)} {P} {bb[2]} {bb[5]} {lam!r} 8\n" + " ".join(repr(float(v)) for v in levels) + "\n")
+        for kf in kfs:
+            f.write(f"{kf['N']}\n{bb[0]!r} {bb[1]!r} {bb[3]!r} {bb[4]!r} {float(cam[0])!r} {float(cam[1])!r} {float(cam[2])!r} {float(cam[3])!r} 0 640 0 480\n")
+            for i in range(kf["N"]):
+                f.write(f"{float(kf['pix'][i, 0])!r} {float(kf['pix'][i, 1])!r} {int(kf['octave'][i])} {float(kf['norm'][i, 0])!r} {float(kf['norm'][i, 1])!r} {int(kf['mp'][i])} "
+                        + " ".join(str(int(b)) for b in kf["desc"][i]) + "\n")
+    r = subprocess.run([exe, str(tmp_path / "in.txt"), str(tmp_path / "out.txt"), "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tok = iter(open(tmp_path / "out.txt").read().split())
+    nrec = int(next(tok))
+    db = np.array([[float(next(tok)) for _ in range(22)] for _ in range(nrec)])
+    slots, related = [], []
+    for kf in kfs:
+        related.append(int(next(tok)))
+        slots.append(np.array([int(next(tok)) for _ in range(kf["N"])]))
+    solved = int(next(tok))
+    surf = []
+    for kf in kfs:
+        writes = int(next(tok))
+        surf.append((writes, np.array([[float(next(tok)) for _ in range(4)] for _ in range(kf["N"])])))
+    cov = np.array([[float(next(tok)) for _ in range(4)] for _ in range(P)])
+    pending = int(next(tok))
+
+    # ---- the reference's flow in Python, numeric steps through the same C ABI
+    b2 = nrsfm.Bbs(*bb)
+    fx, fy = float(cam[0]), float(cam[1])
+    kf_mp = [kf["mp"].copy() for kf in kfs]                      # KeyFrame::mvpMapPoints as ids
+    obs = [dict() for _ in range(P)]                             # MapPoint::mObservations: keyframe -> index
+    for k, kf in enumerate(kfs):
+        for i in np.nonzero(kf["mp"] >= 0)[0]:
+            obs[kf["mp"][i]][k] = int(i)
+    exp_db = []
+    for k in range(1, len(kfs)):
+        kf = kfs[k]
+        m = [(obs[p][0], i) for i, p in enumerate(kf_mp[k]) if p >= 0 and 0 in obs[p] and k in obs[p]]
+        assert len(m) >= 20
+        i1, i2 = np.array([a for a, _ in m]), np.array([b for _, b in m])
+        isg = np.sqrt(levels[kfs[0]["octave"][i1]])
+        ok, x = nrsfm.WarpInitialize(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], lam)
+        res, _ = nrsfm.schwarp_eval(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], isg, fx, fy, 0.0, x, want_jacobian=False)
+        err = res[2 * np.arange(len(m))] ** 2 + res[2 * np.arange(len(m)) + 1] ** 2
+        assert (err > 20).sum() >= 1                                # the scene makes the initial-warp test bite
+        for j in np.nonzero(err > 20)[0]:
+            kf_mp[k][i2[j]] = -1                                    # EraseMapPointMatch (the map point keeps its observation)
+        m = [mm for mm, e in zip(m, err) if not e > 20]
+        cand = [i for i in range(kfs[0]["N"]) if kf_mp[0][i] >= 0 and k not in obs[kf_mp[0][i]]]
+        mg = nrsfm.searchBySchwarp(gpu_ctx, b2, x, kfs[0]["norm"][cand], kfs[0]["desc"][cand], cam, np.array([0, 640, 0, 480], np.float32), kf["pix"], kf["desc"],
+                                   (kf_mp[k] >= 0).astype(np.uint8), radius=2.0)
+        new = [(cand[q], int(mg[q])) for q in range(len(cand)) if mg[q] >= 0]
+        assert len(new) > 20
+        for a, b in new:
+            obs[kf_mp[0][a]][k] = b
+            kf_mp[k][b] = kf_mp[0][a]
+        m = m + new
+        i1, i2 = np.array([a for a, _ in m]), np.array([b for _, b in m])
+        isg = np.sqrt(levels[kfs[0]["octave"][i1]])
+        xg, dg, drop, info, costs = nrsfm.calculateSchwarps(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], isg, fy, fx, lam, fx, fy, x, 3)
+        for j, (a, b) in enumerate(m):
+            p1, p2 = kf_mp[0][a], kf_mp[k][b]
+            if p1 < 0 or p2 < 0:
+                continue
+            if drop[j]:
+                obs[p2].pop(k, None)
+                kf_mp[k][b] = -1
+                continue
+            exp_db.append(np.r_[p1, k, a, b, dg[j].astype(np.float64)])
+    exp_db = np.array(exp_db)
+    # the database: same records (per map point in insertion order), float32 fields printed with 9 digits
+    order_g = np.lexsort((db[:, 1], db[:, 0]))
+    order_e = np.lexsort((exp_db[:, 1], exp_db[:, 0]))
+    np.testing.assert_array_equal(db[order_g][:, :4], exp_db[order_e][:, :4])
+    np.testing.assert_allclose(db[order_g][:, 4:], exp_db[order_e][:, 4:], rtol=2e-7, atol=1e-12)
+    for k in range(len(kfs)):
+        np.testing.assert_array_equal(slots[k], kf_mp[k])          # matches erased / registered exactly like the reference's bookkeeping
+    assert related == [0, 1, 1]
+    # ---- NormalEstimator: every point with records, reference keyframe 0, no previous normals
+    pts = sorted(set(exp_db[:, 0].astype(int)))
+    recs_by_pt = {p: exp_db[exp_db[:, 0] == p] for p in pts}
+    rec_ptr = np.r_[0, np.cumsum([len(recs_by_pt[p]) for p in pts])].astype(np.int32)
+    recs = np.concatenate([recs_by_pt[p][:, 4:] for p in pts]).astype(np.float32)
+    R = recs.shape[0]
+    ng = nrsfm.ObtainK1K2(gpu_ctx, rec_ptr, recs, np.ones(R, np.uint8), np.zeros((R, 2), np.float32), np.zeros(R, np.uint8), np.zeros((len(pts), 2), np.float32),
+                          np.zeros(len(pts), np.uint8), kfs[0]["norm"][pts])
+    assert solved == int((ng.status == 0).sum()) and pending == 0
+    w0, s0 = surf[0]
+    assert w0 == solved
+    for q, p in enumerate(pts):
+        if ng.status[q] == 0:
+            assert s0[p, 0] == 1
+            np.testing.assert_allclose(s0[p, 1:], ng.normal_ref[q], rtol=2e-7)
+            np.testing.assert_allclose(cov[p], ng.cov[q].ravel(), rtol=1e-12)
+    allrec = np.concatenate([recs_by_pt[p] for p in pts])
+    for k in range(1, len(kfs)):
+        wk, sk = surf[k]
+        sel = (allrec[:, 1] == k) & (ng.rec_written == 1)
+        assert wk == int(sel.sum())
+        np.testing.assert_allclose(sk[allrec[sel, 3].astype(int), 1:], ng.normal_rec[sel], rtol=2e-7)
