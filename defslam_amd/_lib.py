@@ -62,10 +62,18 @@ class SftResultC(C.Structure):
     ]
 
 
+class SchwarpProblemC(C.Structure):
+    pass
+
+
 class BbsC(C.Structure):
     _fields_ = [("umin", C.c_double), ("umax", C.c_double), ("nptsu", C.c_int32), ("vmin", C.c_double), ("vmax", C.c_double),
                 ("nptsv", C.c_int32), ("valdim", C.c_int32)]
 
+
+SchwarpProblemC._fields_ = [("bbs", BbsC), ("P", C.c_int32), ("kp1", c_float_p), ("kp2", c_float_p), ("invsig", c_float_p), ("fx_slot", C.c_double),
+                            ("fy_slot", C.c_double), ("lam", C.c_double), ("fx", C.c_float), ("fy", C.c_float), ("max_iters", C.c_int32), ("x", c_double_p),
+                            ("diff", c_float_p), ("drop", c_u8_p), ("info", C.c_int32 * 2), ("costs", C.c_double * 2)]
 
 DIFFPROP_FIELDS = ["I1u", "I1v", "I2u", "I2v", "J12a", "J12b", "J12c", "J12d", "J21a", "J21b", "J21c", "J21d",
                    "H12uux", "H12uuy", "H12uvx", "H12uvy", "H12vvx", "H12vvy"]
@@ -77,7 +85,7 @@ EXPORTED_SYMBOLS = [
     "dsh_template_build", "dsh_template_set", "dsh_template_dims", "dsh_template_get", "dsh_template_embed",
     "dsh_sft_solve", "dsh_sft_batch_upload", "dsh_sft_batch_run", "dsh_sft_batch_download",
     "dsh_sft_batch_counts", "dsh_sft_batch_problem_info",
-    "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit",
+    "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit", "dsh_schwarp_fit_batch",
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
     "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
     "dsh_comm_unique_id", "dsh_comm_create", "dsh_comm_destroy", "dsh_sft_shared_solve", "dsh_sft_shared_solve_group",
@@ -141,6 +149,7 @@ def _bind(path: str, lab: bool) -> C.CDLL:
                                    c_double_p, c_double_p]
     L.dsh_schwarp_fit.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_float_p, c_float_p, c_float_p, C.c_double, C.c_double, C.c_double, C.c_float,
                                   C.c_float, C.c_int, c_double_p, c_float_p, c_u8_p, c_i32_p, c_double_p]
+    L.dsh_schwarp_fit_batch.argtypes = [vp, C.c_int, C.POINTER(SchwarpProblemC)]
     L.dsh_sfn_estimate.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_double_p, c_double_p, c_float_p, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_float_p, c_i32_p]
     L.dsh_bbs_bending.argtypes = [C.POINTER(BbsC), C.c_double, c_double_p]

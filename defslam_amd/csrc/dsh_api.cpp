@@ -296,6 +296,8 @@ int dsh_destroy(dsh_ctx* c) {
   c->results.release();
   if (c->d_tmpl) (void)hipFree(c->d_tmpl);
   c->scratch.release();
+  c->pin_in.release();
+  c->pin_out.release();
   if (c->d_batch) (void)hipFree(c->d_batch);
   if (c->d_sc) (void)hipFree(c->d_sc);
   delete c;

@@ -46,8 +46,25 @@ struct dsh_scratch {
   }
 };
 
+// Page-locked host buffer for the one-copy-in / one-copy-out calls (grow-only; plain memory for a host-only context).
+struct dsh_pinned {
+  char* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    const size_t want = bytes + bytes / 4 + 4096;
+    const hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct dsh_ctx_base {
   dsh_scratch scratch;
+  dsh_pinned pin_in, pin_out;
   int device = 0;
   bool host_only = false;   // device == -1: template + packer only (CPU tests of the host logic)
   hipStream_t stream = nullptr;

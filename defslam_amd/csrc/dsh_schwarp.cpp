@@ -3,6 +3,7 @@
 // residuals, Jacobian, normal equations, the 2N x 2N Cholesky solve and the DiffProp extraction run on the GPU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -19,6 +20,10 @@ extern "C" hipError_t nrsfm_swp_colscale(int, const double*, double*, hipStream_
 extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, int, int, hipStream_t);
 extern "C" int nrsfm_swp_solve_np(int);
 extern "C" hipError_t nrsfm_swp_step(int, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
+extern "C" size_t nrsfm_swp_fit_bytes();
+extern "C" void nrsfm_swp_fit_fill(void*, double, double, int, double, double, int, int, double, double, double, float, float, int, const float*, const float*, const float*,
+                                   double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, float*, uint8_t*, int32_t*, double*);
+extern "C" hipError_t nrsfm_swp_fit_batch(void*, int, int, int, int, hipStream_t);
 extern "C" hipError_t nrsfm_swp_diffprop(double, double, int, double, double, int, int, const float*, const float*, const double*, float, float, float*,
                                          uint8_t*, hipStream_t);
 
@@ -107,79 +112,106 @@ int dsh_schwarp_eval(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, 
   return DSH_OK;
 }
 
+// The batched fit: every problem's inputs go up in ONE copy, the fits advance together through a fixed sequence of launches
+// with the trust-region control on the device (nrsfm_kernels.hip: nrsfm_swp_fit_batch), every result comes back in ONE copy.
+int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
+  dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
+  if (!c) return DSH_ERR_ARG;
+  if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_schwarp_fit_batch: host-only context, no GPU (there is no CPU fallback)");
+  if (B <= 0 || !probs) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: bad argument");
+  int maxP = 0, maxN = 0, max_it = 0;
+  for (int b = 0; b < B; b++) {
+    const dsh_schwarp_problem& q = probs[b];
+    if (!args_ok(&q.bbs, q.P, q.kp1, q.kp2, q.invsig, q.x) || q.max_iters < 0 || q.max_iters > 1000) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: bad argument in problem " + std::to_string(b));
+    if (q.bbs.nptsu * q.bbs.nptsv > 256)
+      return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit: more than 256 control points (the one-workgroup solve handles 2N <= 512 unknowns; the reference uses 13 x 15 = 195)");
+    if ((q.diff == nullptr) != (q.drop == nullptr)) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: diff and drop go together");
+    maxP = std::max(maxP, q.P); maxN = std::max(maxN, q.bbs.nptsu * q.bbs.nptsv); max_it = std::max(max_it, q.max_iters);
+  }
+  (void)hipSetDevice(c->device);
+  hipStream_t st = c->stream;
+  c->scratch.reset();
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // ---- layout of the input block (host-staged) and of the output block
+  const size_t fit_bytes = nrsfm_swp_fit_bytes();
+  size_t in_bytes = al(fit_bytes * (size_t)B), out_bytes = 0;
+  struct Off { size_t kp1, kp2, isg, x0, cs, xo, diff, drop, info, costs; };
+  std::vector<Off> off(B);
+  for (int b = 0; b < B; b++) {
+    const dsh_schwarp_problem& q = probs[b];
+    const size_t n2 = 2 * (size_t)q.bbs.nptsu * q.bbs.nptsv;
+    Off& o = off[b];
+    o.kp1 = in_bytes; in_bytes += al(8 * (size_t)q.P);
+    o.kp2 = in_bytes; in_bytes += al(8 * (size_t)q.P);
+    o.isg = in_bytes; in_bytes += al(4 * (size_t)q.P);
+    o.cs = in_bytes; in_bytes += al(8 * n2);
+    o.xo = out_bytes; out_bytes += al(8 * n2);                  // x lives in the output block (in/out): its start value is copied there
+    o.diff = out_bytes; out_bytes += al(q.diff ? 72 * (size_t)q.P : 0);
+    o.drop = out_bytes; out_bytes += al(q.drop ? (size_t)q.P : 0);
+    o.info = out_bytes; out_bytes += 256;
+    o.costs = out_bytes; out_bytes += 256;
+  }
+  DevBuf din, dout;
+  HIPCHK(c, din.alloc(c, in_bytes)); HIPCHK(c, dout.alloc(c, out_bytes));
+  HIPCHK(c, c->pin_in.ensure(in_bytes + out_bytes)); HIPCHK(c, c->pin_out.ensure(out_bytes));
+  char* hin = c->pin_in.p;
+  char* hx = c->pin_in.p + in_bytes;   // start values of x, laid out like the output block
+  std::memset(hx, 0, out_bytes);
+  char* dib = din.as<char>();
+  char* dob = dout.as<char>();
+  for (int b = 0; b < B; b++) {
+    const dsh_schwarp_problem& q = probs[b];
+    const Off& o = off[b];
+    const int N = q.bbs.nptsu * q.bbs.nptsv, n2 = 2 * N, m = 2 * q.P + 4 * N;
+    std::memcpy(hin + o.kp1, q.kp1, 8 * (size_t)q.P); std::memcpy(hin + o.kp2, q.kp2, 8 * (size_t)q.P); std::memcpy(hin + o.isg, q.invsig, 4 * (size_t)q.P);
+    double* cs = reinterpret_cast<double*>(hin + o.cs);
+    for (int j = 0; j < n2; j++) cs[j] = 1.0;
+    std::memcpy(hx + o.xo, q.x, 8 * (size_t)n2);
+    DevBuf xn, g, dx, r, J, A, M, W, scal;
+    const size_t np = (size_t)nrsfm_swp_solve_np(n2);
+    HIPCHK(c, xn.alloc(c, 8 * (size_t)n2)); HIPCHK(c, g.alloc(c, 8 * (size_t)n2)); HIPCHK(c, dx.alloc(c, 8 * (size_t)n2)); HIPCHK(c, r.alloc(c, 8 * (size_t)m));
+    HIPCHK(c, J.alloc(c, 8 * (size_t)m * n2)); HIPCHK(c, A.alloc(c, 8 * (size_t)n2 * n2)); HIPCHK(c, M.alloc(c, 8 * np * np)); HIPCHK(c, W.alloc(c, 8 * np * 16));
+    HIPCHK(c, scal.alloc(c, 128));
+    HIPCHK(c, hipMemsetAsync(scal.p, 0, 128, st));
+    HIPCHK(c, hipMemsetAsync(dx.p, 0, 8 * (size_t)n2, st));
+    nrsfm_swp_fit_fill(hin + fit_bytes * (size_t)b, q.bbs.umin, q.bbs.umax, q.bbs.nptsu, q.bbs.vmin, q.bbs.vmax, q.bbs.nptsv, q.P, q.fx_slot, q.fy_slot, q.lambda, q.fx, q.fy,
+                       q.max_iters, reinterpret_cast<const float*>(dib + o.kp1), reinterpret_cast<const float*>(dib + o.kp2), reinterpret_cast<const float*>(dib + o.isg),
+                       reinterpret_cast<double*>(dob + o.xo), xn.as<double>(), reinterpret_cast<double*>(dib + o.cs), g.as<double>(), dx.as<double>(), r.as<double>(),
+                       J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal.as<double>(), q.diff ? reinterpret_cast<float*>(dob + o.diff) : nullptr,
+                       q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr, reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs));
+  }
+  HIPCHK(c, hipMemcpyAsync(dib, hin, in_bytes, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dob, hx, out_bytes, hipMemcpyHostToDevice, st));
+  HIPCHK(c, nrsfm_swp_fit_batch(dib, B, maxP, maxN, max_it, st));
+  HIPCHK(c, hipMemcpyAsync(c->pin_out.p, dob, out_bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const char* ho = c->pin_out.p;
+  for (int b = 0; b < B; b++) {
+    dsh_schwarp_problem& q = probs[b];
+    const Off& o = off[b];
+    const size_t n2 = 2 * (size_t)q.bbs.nptsu * q.bbs.nptsv;
+    std::memcpy(q.x, ho + o.xo, 8 * n2);
+    if (q.diff) { std::memcpy(q.diff, ho + o.diff, 72 * (size_t)q.P); std::memcpy(q.drop, ho + o.drop, (size_t)q.P); }
+    std::memcpy(q.info, ho + o.info, sizeof q.info);
+    std::memcpy(q.costs, ho + o.costs, sizeof q.costs);
+  }
+  return DSH_OK;
+}
+
 int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, const float* invsig, double fx_slot, double fy_slot,
                     double lambda, float fx, float fy, int max_iters, double* x, dsh_diffprop* diff, uint8_t* drop, int32_t* info, double* costs) {
   dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
   if (!c) return DSH_ERR_ARG;
   if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_schwarp_fit: host-only context, no GPU (there is no CPU fallback)");
   if (!args_ok(bbs, P, kp1, kp2, invsig, x) || max_iters < 0) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit: bad argument");
-  if (bbs->nptsu * bbs->nptsv > 256) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit: more than 256 control points (the one-workgroup solve handles 2N <= 512 unknowns; the reference uses 13 x 15 = 195)");
-  (void)hipSetDevice(c->device);
-  Fit f;
-  int rc = setup(f, c, bbs, P, kp1, kp2, invsig, fx_slot, fy_slot, lambda, x);
+  dsh_schwarp_problem q{};
+  q.bbs = *bbs; q.P = P; q.kp1 = kp1; q.kp2 = kp2; q.invsig = invsig; q.fx_slot = fx_slot; q.fy_slot = fy_slot; q.lambda = lambda; q.fx = fx; q.fy = fy;
+  q.max_iters = max_iters; q.x = x;
+  q.diff = (diff && drop) ? diff : nullptr; q.drop = (diff && drop) ? drop : nullptr;
+  const int rc = dsh_schwarp_fit_batch(ctx, 1, &q);
   if (rc != DSH_OK) return rc;
-  // scal: [0] cost, [1] sqrt(rho'), [2] solve ok, [3] model cost change, [4] |step|, [5] |x|, [6] max |g|
-  double s[8];
-  double* scal = f.scal.as<double>();
-  // Jacobi scaling from the initial Jacobian (cs = 1 first), then the scaled linearisation of the start
-  if ((rc = f.eval(f.x.as<double>(), true)) != DSH_OK) return rc;
-  HIPCHK(c, nrsfm_swp_colscale(f.n2, f.A.as<double>(), f.cs.as<double>(), f.st));
-  if ((rc = f.eval(f.x.as<double>(), true)) != DSH_OK) return rc;
-  HIPCHK(c, nrsfm_swp_step(f.n2, f.x.as<double>(), f.dx.as<double>(), f.cs.as<double>(), f.g.as<double>(), f.xn.as<double>(), scal + 2, f.st));
-  if ((rc = f.scalars(s)) != DSH_OK) return rc;
-  double cost = s[0];
-  const double cost0 = cost;
-  const double ftol = 1e-6, gtol = 1e-10, ptol = 1e-8, min_rel_dec = 1e-3;
-  double radius = 1e4, nu = 2.0;
-  int it = 0, good = 0, invalid = 0;
-  // One host round trip per iteration: the trial point is evaluated speculatively right behind the solve (a failed solve or a
-  // vanishing step only wastes that evaluation), and the gradient test of an accepted step -- `max |g| <= gtol` after the new
-  // linearisation -- is read with the scalars of the next iteration (whose speculative work is dropped if it fires).
-  bool pending_gtol = false;     // an accepted step was linearised; its max |g| has not been looked at yet
-  if (s[6] > gtol)
-    while (it < max_iters) {
-      it++;
-      HIPCHK(c, nrsfm_swp_solve(f.n2, f.A.as<double>(), f.g.as<double>(), radius, f.M.as<double>(), f.W.as<double>(), f.dx.as<double>(), scal + 2, 1, 2 * (3 * bbs->nptsv + 3) + 1, f.st));
-      HIPCHK(c, nrsfm_swp_step(f.n2, f.x.as<double>(), f.dx.as<double>(), f.cs.as<double>(), f.g.as<double>(), f.xn.as<double>(), scal + 2, f.st));
-      if ((rc = f.eval(f.xn.as<double>(), false)) != DSH_OK) return rc;   // residuals only: J, A, g still belong to x
-      if ((rc = f.scalars(s)) != DSH_OK) return rc;
-      if (pending_gtol && s[6] <= gtol) { it--; break; }                  // the previous iteration had already converged
-      pending_gtol = false;
-      const bool ok = s[2] != 0.0;
-      const double model = s[3];
-      if (!ok) { if (++invalid >= 5) break; radius *= 0.5; continue; }
-      invalid = 0;
-      if (s[4] <= ptol * (s[5] + ptol)) break;
-      const double cost_new = s[0];
-      const double rel = (cost - cost_new) / model;
-      if (rel > min_rel_dec) {
-        const double change = cost - cost_new, old = cost;
-        HIPCHK(c, hipMemcpyAsync(f.x.p, f.xn.p, 8 * (size_t)f.n2, hipMemcpyDeviceToDevice, f.st));
-        radius = std::fmin(1e16, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
-        nu = 2.0;
-        good++;
-        if ((rc = f.eval(f.x.as<double>(), true)) != DSH_OK) return rc;   // same residuals as the trial evaluation: cost == cost_new
-        cost = cost_new;
-        pending_gtol = true;
-        if (std::fabs(change) <= ftol * old) break;
-      } else {
-        radius /= nu; nu *= 2.0;
-        if (radius < 1e-32) break;
-      }
-    }
-  if (info) { info[0] = it; info[1] = good; }
-  if (costs) { costs[0] = cost0; costs[1] = cost; }
-  HIPCHK(c, hipMemcpyAsync(x, f.x.p, 8 * (size_t)f.n2, hipMemcpyDeviceToHost, f.st));
-  if (diff && drop) {
-    DevBuf dd, dr;
-    HIPCHK(c, dd.alloc(c, 72 * (size_t)P)); HIPCHK(c, dr.alloc(c, P));
-    HIPCHK(c, nrsfm_swp_diffprop(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, P, f.kp1.as<float>(), f.kp2.as<float>(), f.x.as<double>(), fx,
-                                 fy, dd.as<float>(), dr.as<uint8_t>(), f.st));
-    HIPCHK(c, hipMemcpyAsync(diff, dd.p, 72 * (size_t)P, hipMemcpyDeviceToHost, f.st));
-    HIPCHK(c, hipMemcpyAsync(drop, dr.p, P, hipMemcpyDeviceToHost, f.st));
-    HIPCHK(c, hipStreamSynchronize(f.st));
-  }
-  HIPCHK(c, hipStreamSynchronize(f.st));
+  if (info) { info[0] = q.info[0]; info[1] = q.info[1]; }
+  if (costs) { costs[0] = q.costs[0]; costs[1] = q.costs[1]; }
   return DSH_OK;
 }
 

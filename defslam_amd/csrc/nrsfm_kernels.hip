@@ -12,6 +12,7 @@
 // All kernels are embarrassingly parallel and bandwidth-trivial; records are stored SoA so neighbouring
 // threads read neighbouring addresses.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "tile_chol.h"
 #include <math.h>
 #include <stdint.h>
@@ -313,6 +314,7 @@ __global__ void normals_propagate_kernel(int R, const float* __restrict__ recs, 
 // Schwarzian-regularised warp fit: Schwarp.cc:38-97,235-543, SchwarpDatabase.cc:145-349
 // Parameter layout x[0..N) first coordinate, x[N..2N) second; dense row-major Jacobian (2P+4N) x 2N.
 // ------------------------------------------------------------------------------------------------
+typedef double v2d_t __attribute__((ext_vector_type(2)));
 struct SwpPar { double umin, umax, vmin, vmax, fxs, fys, lambda; int nu, nv, N, P; };
 
 __device__ __forceinline__ void swp_eval16(const SwpPar& p, const double* x, double u, double v, int du, int dv, double& ox, double& oy) {
@@ -358,7 +360,7 @@ __device__ __forceinline__ bool swp_taps(const SwpPar& p, double u, double v, in
 }
 
 template <bool WITH_J>
-__global__ void swp_eval_kernel(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const float* __restrict__ invsig,
+__device__ __forceinline__ void swp_eval_body(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const float* __restrict__ invsig,
                                 const double* __restrict__ x, double* __restrict__ r, double* __restrict__ J) {
   const int n2 = 2 * p.N;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,7 +436,7 @@ __device__ double swp_block_sum256(double v, double* red) {
 }
 
 // scal[0] = cost = 1/2 (rho(|r_warp|^2) + |r_schw|^2), scal[1] = sqrt(rho'); one 256-thread workgroup.
-__global__ __launch_bounds__(256) void swp_loss_kernel(int P2, int m, const double* __restrict__ r, double* __restrict__ scal) {
+__device__ __forceinline__ void swp_loss_body(int P2, int m, const double* __restrict__ r, double* __restrict__ scal) {
   __shared__ double red[256];
   const int t = threadIdx.x;
   const double a = 5.77;   // HuberLoss(5.77), SchwarpDatabase.cc:208
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void swp_loss_kernel(int P2, int m, const doub
   }
 }
 
-__global__ void swp_scale_kernel(int P2, int n2, const double* __restrict__ scal, double* __restrict__ r, double* __restrict__ J) {
+__device__ __forceinline__ void swp_scale_body(int P2, int n2, const double* __restrict__ scal, double* __restrict__ r, double* __restrict__ J) {
   const double sc = scal[1];
   const size_t tot = (size_t)P2 * n2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) J[i] *= sc;
@@ -467,7 +469,7 @@ __global__ void swp_scale_kernel(int P2, int n2, const double* __restrict__ scal
 // of 4 rows per MFMA), four accumulators in flight; the four wavefronts of a workgroup split the rows of J (split-K) and
 // their partial tiles are added in a fixed order (bit-reproducible run to run).  The column scaling S = diag(cs) is
 // applied to the finished tile.  Tiles of block column 0 also accumulate g on the vector ALU.
-__global__ __launch_bounds__(256) void swp_normal_kernel(int m, int n2, int nt, const double* __restrict__ J, const double* __restrict__ r,
+__device__ __forceinline__ void swp_normal_body(int m, int n2, int nt, const double* __restrict__ J, const double* __restrict__ r,
                                                          const double* __restrict__ cs, double* __restrict__ A, double* __restrict__ g) {
   __shared__ double part[3][4][64];
   __shared__ double gpart[3][16];
@@ -554,7 +556,7 @@ __device__ __forceinline__ size_t swp_mi(int np, int r, int c) {
 // interleaved (x0, y0, x1, y1, ...): control points couple within a 4 x 4 patch of the grid, so the interleaved normal matrix is
 // banded (half-bandwidth 2 (3 nptsv + 3) + 1) and the factorisation only visits the tiles of the band.
 __device__ __forceinline__ int swp_perm(int n, int il, int i) { return (il && i < n) ? ((i < n / 2) ? 2 * i : 2 * (i - n / 2) + 1) : i; }
-__global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, int il, const double* __restrict__ A, double radius, double* __restrict__ M) {
+__device__ __forceinline__ void swp_damp_body(int n, int np, int il, const double* __restrict__ A, double radius, double* __restrict__ M) {
   const int cc = blockIdx.x * 256 + threadIdx.x, rr = blockIdx.y;
   if (cc >= np) return;
   double v = (rr == cc) ? 1.0 : 0.0;
@@ -569,7 +571,7 @@ __device__ __forceinline__ double swp_row16_sum(double v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
 }
-__global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, int il, int bwt, const double* __restrict__ A, const double* __restrict__ g, double radius,
+__device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, const double* __restrict__ A, const double* __restrict__ g, double radius,
                                                         double* __restrict__ M, double* __restrict__ Winv, double* __restrict__ dx, double* __restrict__ out) {
   // il: interleaved unknown ordering (swp_perm); bwt: sub-diagonal tiles of the band (NT - 1: dense)
   extern __shared__ double sws[];
@@ -991,7 +993,7 @@ __global__ void sfn_points_kernel(BbsPar p, const double* __restrict__ ctrl, int
 }
 
 // xn = x + dx*cs; out[2] = |step|, out[3] = |x|, out[4] = max |g|; one 256-thread workgroup
-__global__ __launch_bounds__(256) void swp_step_kernel(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
+__device__ __forceinline__ void swp_step_body(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
                                                        const double* __restrict__ g, double* __restrict__ xn, double* __restrict__ out) {
   __shared__ double red[256];
   const int t = threadIdx.x;
@@ -1014,13 +1016,13 @@ __global__ __launch_bounds__(256) void swp_step_kernel(int n, const double* __re
   if (t == 0) { out[2] = sqrt(snt); out[3] = sqrt(xt); out[4] = red[0]; }
 }
 
-__global__ void swp_colscale_kernel(int n, const double* __restrict__ A, double* __restrict__ cs) {
+__device__ __forceinline__ void swp_colscale_body(int n, const double* __restrict__ A, double* __restrict__ cs) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) cs[j] = 1.0 / (1.0 + sqrt(A[(size_t)j * n + j]));
 }
 
 // DiffProp records of the fitted warp (SchwarpDatabase.cc:243-345): six evaluations -> float32 key points
-__global__ void swp_diffprop_kernel(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const double* __restrict__ x,
+__device__ __forceinline__ void swp_diffprop_body(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const double* __restrict__ x,
                                     float fx_true, float fy_true, float* __restrict__ diff, uint8_t* __restrict__ drop) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.P) return;
@@ -1042,6 +1044,168 @@ __global__ void swp_diffprop_kernel(SwpPar p, const float* __restrict__ kp1, con
   const float det = dqu[0] * dqv[1] - dqv[0] * dqu[1];
   d[8] = d[7] / det; d[9] = -d[6] / det; d[10] = -d[5] / det; d[11] = d[4] / det;
   d[12] = dquu[0]; d[13] = dquu[1]; d[14] = dquv[0]; d[15] = dquv[1]; d[16] = dqvv[0]; d[17] = dqvv[1];
+}
+
+// ---- thin kernels over the bodies above (one fit per launch: dsh_schwarp_eval, Shape from Normals, warp initialisation) ----------
+template <bool WITH_J>
+__global__ void swp_eval_kernel(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const float* __restrict__ invsig,
+                                const double* __restrict__ x, double* __restrict__ r, double* __restrict__ J) { swp_eval_body<WITH_J>(p, kp1, kp2, invsig, x, r, J); }
+__global__ __launch_bounds__(256) void swp_loss_kernel(int P2, int m, const double* __restrict__ r, double* __restrict__ scal) { swp_loss_body(P2, m, r, scal); }
+__global__ void swp_scale_kernel(int P2, int n2, const double* __restrict__ scal, double* __restrict__ r, double* __restrict__ J) { swp_scale_body(P2, n2, scal, r, J); }
+__global__ __launch_bounds__(256) void swp_normal_kernel(int m, int n2, int nt, const double* __restrict__ J, const double* __restrict__ r,
+                                                         const double* __restrict__ cs, double* __restrict__ A, double* __restrict__ g) { swp_normal_body(m, n2, nt, J, r, cs, A, g); }
+__global__ __launch_bounds__(256) void swp_damp_kernel(int n, int np, int il, const double* __restrict__ A, double radius, double* __restrict__ M) { swp_damp_body(n, np, il, A, radius, M); }
+__global__ __launch_bounds__(512) void swp_solve_kernel(int n, int np, int il, int bwt, const double* __restrict__ A, const double* __restrict__ g, double radius,
+                                                        double* __restrict__ M, double* __restrict__ Winv, double* __restrict__ dx, double* __restrict__ out) { swp_solve_body(n, np, il, bwt, A, g, radius, M, Winv, dx, out); }
+__global__ __launch_bounds__(256) void swp_step_kernel(int n, const double* __restrict__ x, const double* __restrict__ dx, const double* __restrict__ cs,
+                                                       const double* __restrict__ g, double* __restrict__ xn, double* __restrict__ out) { swp_step_body(n, x, dx, cs, g, xn, out); }
+__global__ void swp_colscale_kernel(int n, const double* __restrict__ A, double* __restrict__ cs) { swp_colscale_body(n, A, cs); }
+__global__ void swp_diffprop_kernel(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const double* __restrict__ x,
+                                    float fx_true, float fy_true, float* __restrict__ diff, uint8_t* __restrict__ drop) { swp_diffprop_body(p, kp1, kp2, x, fx_true, fy_true, diff, drop); }
+
+// ------------------------------------------------------------------------------------------------
+// Batched Schwarp fit (SchwarpDatabase::add fits one warp per anchor keyframe, SchwarpDatabase.cc:50-128): B fits advance
+// together, one launch per stage with the fit in blockIdx.y (blockIdx.z for the 2D damp grid); each kernel reads its arguments
+// from the fit's descriptor.  The trust-region control of the reference's Ceres run (dsh_schwarp.cpp restated it on the host
+// with one round trip per iteration) runs in swp_ctl_kernel on the device: the whole batch is a fixed sequence of launches
+// without a single host synchronisation, and a finished fit skips its stages by a flag.
+// ------------------------------------------------------------------------------------------------
+struct SwpFit {
+  SwpPar p;                      // domain, grid, P, N, slots, lambda
+  float fx, fy;                  // true focal lengths (DiffProp drop test)
+  int n2, m, np, il, bwt, max_iters;
+  const float *kp1, *kp2, *isg;
+  double *x, *xn, *cs, *g, *dx, *r, *J, *A, *M, *W, *scal;   // scal: [0] cost [1] sqrt(rho') [2] solve ok [3] model change [4] |step| [5] |x| [6] max |g|
+  float* diff;
+  uint8_t* drop;
+  int32_t* info;                 // [0] iterations [1] accepted steps
+  double* costs;                 // [0] initial [1] final
+  // trust-region state (Ceres LM as restated in dsh_schwarp.cpp / oracle/schwarp_oracle.c)
+  double radius, nu, cost, cost0, change, old;
+  int it, good, invalid, done, accepted, pending;   // pending: an accepted step was re-linearised, its max |g| has not been tested yet
+};
+#define SWP_STAGE_ALWAYS 0      // setup stages: run for every fit
+#define SWP_STAGE_ACTIVE 1      // stages of an iteration: skipped once the fit is done
+#define SWP_STAGE_ACCEPTED 2    // re-linearisation: only after an accepted step
+
+__device__ __forceinline__ bool swp_on(const SwpFit& f, int stage) {
+  return stage == SWP_STAGE_ALWAYS || (stage == SWP_STAGE_ACTIVE && !f.done) || (stage == SWP_STAGE_ACCEPTED && f.accepted);
+}
+
+template <bool WITH_J>
+__global__ void swpb_eval_kernel(const SwpFit* fits, int stage, int at_xn) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_eval_body<WITH_J>(f.p, f.kp1, f.kp2, f.isg, at_xn ? f.xn : f.x, f.r, f.J);
+}
+__global__ void swpb_zero_j_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  const size_t tot = (size_t)f.m * f.n2 / 2;
+  v2d_t* J2 = reinterpret_cast<v2d_t*>(f.J);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) J2[i] = (v2d_t){0.0, 0.0};
+}
+__global__ __launch_bounds__(256) void swpb_loss_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_loss_body(2 * f.p.P, f.m, f.r, f.scal);
+}
+__global__ void swpb_scale_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_scale_body(2 * f.p.P, f.n2, f.scal, f.r, f.J);
+}
+__global__ __launch_bounds__(256) void swpb_normal_kernel(const SwpFit* fits, int stage, int nt) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_normal_body(f.m, f.n2, nt, f.J, f.r, f.cs, f.A, f.g);
+}
+__global__ void swpb_colscale_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_colscale_body(f.n2, f.A, f.cs);
+}
+__global__ __launch_bounds__(256) void swpb_damp_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.z];
+  if (!swp_on(f, stage) || (int)blockIdx.y >= f.np) return;
+  swp_damp_body(f.n2, f.np, f.il, f.A, f.radius, f.M);
+}
+__global__ __launch_bounds__(512) void swpb_solve_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_solve_body(f.n2, f.np, f.il, f.bwt, f.A, f.g, f.radius, f.M, f.W, f.dx, f.scal + 2);
+}
+__global__ __launch_bounds__(256) void swpb_step_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_step_body(f.n2, f.x, f.dx, f.cs, f.g, f.xn, f.scal + 2);
+}
+__global__ void swpb_diffprop_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.diff || !f.drop) return;
+  swp_diffprop_body(f.p, f.kp1, f.kp2, f.x, f.fx, f.fy, f.diff, f.drop);
+}
+// x <- xn after an accepted step
+__global__ void swpb_accept_kernel(SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.accepted) return;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < f.n2; j += gridDim.x * blockDim.x) f.x[j] = f.xn[j];
+}
+
+// The trust-region controller, one thread per fit.  phase 0: after the scaled linearisation of the start (and a zero step that
+// measures max |g|); 1: top of an iteration; 5: behind solve + step -- the gradient test of the previous accepted step (the step
+// kernel measures max |g| of the current linearisation); 2: after the trial evaluation (accept / reject, radius update);
+// 3: after the re-linearisation of an accepted step (function tolerance); 4: results.  Same decisions, in the same order, as
+// the host loop this replaces (oracle/schwarp_oracle.c is the restatement both are tested against).
+__global__ void swpb_ctl_kernel(SwpFit* fits, int B, int phase) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  SwpFit& f = fits[b];
+  const double ftol = 1e-6, gtol = 1e-10, ptol = 1e-8, min_rel_dec = 1e-3;
+  double* s = f.scal;
+  if (phase == 0) {
+    f.cost = s[0]; f.cost0 = s[0];
+    f.radius = 1e4; f.nu = 2.0;
+    f.it = 0; f.good = 0; f.invalid = 0; f.accepted = 0; f.pending = 0;
+    f.done = !(s[6] > gtol) || f.max_iters <= 0;
+  } else if (phase == 1) {
+    f.accepted = 0;
+    if (!f.done) {
+      if (f.it >= f.max_iters) f.done = 1;
+      else f.it++;
+    }
+  } else if (phase == 5) {
+    if (!f.done && f.pending && s[6] <= gtol) { f.it--; f.done = 1; }   // the previous iteration had already converged
+    f.pending = 0;
+  } else if (phase == 2) {
+    f.accepted = 0;
+    if (f.done) return;
+    const bool ok = s[2] != 0.0;
+    const double model = s[3];
+    if (!ok) { if (++f.invalid >= 5) f.done = 1; f.radius *= 0.5; return; }
+    f.invalid = 0;
+    if (s[4] <= ptol * (s[5] + ptol)) { f.done = 1; return; }
+    const double cost_new = s[0];
+    const double rel = (f.cost - cost_new) / model;
+    if (rel > min_rel_dec) {
+      f.change = f.cost - cost_new; f.old = f.cost;
+      f.radius = fmin(1e16, f.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
+      f.nu = 2.0;
+      f.good++;
+      f.cost = cost_new;
+      f.accepted = 1;
+    } else {
+      f.radius /= f.nu; f.nu *= 2.0;
+      if (f.radius < 1e-32) f.done = 1;
+    }
+  } else if (phase == 3) {
+    if (!f.accepted) return;
+    f.pending = 1;
+    if (fabs(f.change) <= ftol * f.old) f.done = 1;   // function tolerance, tested behind the re-linearisation like on the host
+  } else {
+    if (f.info) { f.info[0] = f.it; f.info[1] = f.good; }
+    if (f.costs) { f.costs[0] = f.cost0; f.costs[1] = f.cost; }
+  }
 }
 
 }  // namespace
@@ -1138,6 +1302,69 @@ extern "C" hipError_t nrsfm_swp_diffprop(double umin, double umax, int nu, doubl
                                          const double* x, float fx_true, float fy_true, float* diff, uint8_t* drop, hipStream_t st) {
   SwpPar p = {umin, umax, vmin, vmax, 0.0, 0.0, 0.0, nu, nv, nu * nv, P};
   hipLaunchKernelGGL(swp_diffprop_kernel, dim3((P + 127) / 128), dim3(128), 0, st, p, kp1, kp2, x, fx_true, fy_true, diff, drop);
+  return hipGetLastError();
+}
+
+// The batched Schwarp fit: a fixed sequence of launches over B fit descriptors (device array), no host synchronisation inside.
+// maxP / maxN / maxn2 / maxnp: the largest sizes in the batch (grid extents); max_iters: the largest iteration limit.
+extern "C" size_t nrsfm_swp_fit_bytes() { return sizeof(SwpFit); }
+extern "C" void nrsfm_swp_fit_fill(void* host_slot, double umin, double umax, int nu, double vmin, double vmax, int nv, int P, double fxs, double fys, double lambda,
+                                   float fx, float fy, int max_iters, const float* kp1, const float* kp2, const float* isg, double* x, double* xn, double* cs,
+                                   double* g, double* dx, double* r, double* J, double* A, double* M, double* W, double* scal, float* diff, uint8_t* drop,
+                                   int32_t* info, double* costs) {
+  SwpFit f{};
+  f.p = SwpPar{umin, umax, vmin, vmax, fxs, fys, lambda, nu, nv, nu * nv, P};
+  f.fx = fx; f.fy = fy;
+  f.n2 = 2 * nu * nv; f.m = 2 * P + 4 * nu * nv; f.np = nrsfm_swp_solve_np(f.n2); f.il = 1;
+  f.bwt = min(f.np / 16 - 1, (2 * (3 * nv + 3) + 1 + 15) / 16);
+  f.max_iters = max_iters;
+  f.kp1 = kp1; f.kp2 = kp2; f.isg = isg; f.x = x; f.xn = xn; f.cs = cs; f.g = g; f.dx = dx; f.r = r; f.J = J; f.A = A; f.M = M; f.W = W; f.scal = scal;
+  f.diff = diff; f.drop = drop; f.info = info; f.costs = costs;
+  memcpy(host_slot, &f, sizeof f);
+}
+extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int maxN, int max_iters, hipStream_t st) {
+  SwpFit* fits = static_cast<SwpFit*>(d_fits_v);
+  const int maxn2 = 2 * maxN, maxnp = nrsfm_swp_solve_np(maxn2), NT = maxnp / 16;
+  const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + maxnp + 16);
+  if (lds > 150 * 1024 || maxnp > 512) return hipErrorInvalidValue;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swpb_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  const int nt = (maxn2 + 15) / 16, tiles = nt * (nt + 1) / 2;
+  const dim3 g_eval((maxP + maxN + 127) / 128, B), g_one(1, B);
+  auto linearise = [&](int stage) {   // residuals + Jacobian at x, loss, Huber row scaling, normal equations
+    hipLaunchKernelGGL(swpb_zero_j_kernel, dim3(64, B), dim3(256), 0, st, fits, stage);
+    hipLaunchKernelGGL(swpb_eval_kernel<true>, g_eval, dim3(128), 0, st, fits, stage, 0);
+    hipLaunchKernelGGL(swpb_loss_kernel, g_one, dim3(256), 0, st, fits, stage);
+    hipLaunchKernelGGL(swpb_scale_kernel, dim3(64, B), dim3(256), 0, st, fits, stage);
+    hipLaunchKernelGGL(swpb_normal_kernel, dim3(tiles, B), dim3(256), 0, st, fits, stage, nt);
+  };
+  const dim3 g_ctl((B + 63) / 64);
+  // Jacobi scaling from the initial Jacobian (cs = 1 first), then the scaled linearisation of the start; a zero step measures |x|, max |g|
+  linearise(SWP_STAGE_ALWAYS);
+  hipLaunchKernelGGL(swpb_colscale_kernel, dim3((maxn2 + 127) / 128, B), dim3(128), 0, st, fits, SWP_STAGE_ALWAYS);
+  linearise(SWP_STAGE_ALWAYS);
+  hipLaunchKernelGGL(swpb_step_kernel, g_one, dim3(256), 0, st, fits, SWP_STAGE_ALWAYS);
+  hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 0);
+  for (int it = 0; it <= max_iters; it++) {   // the last round only lets phase 1 retire the fits that used every iteration
+    hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 1);
+    if (it == max_iters) break;
+    hipLaunchKernelGGL(swpb_damp_kernel, dim3((maxnp + 255) / 256, maxnp, B), dim3(256), 0, st, fits, SWP_STAGE_ACTIVE);
+    hipLaunchKernelGGL(swpb_solve_kernel, g_one, dim3(512), lds, st, fits, SWP_STAGE_ACTIVE);
+    hipLaunchKernelGGL(swpb_step_kernel, g_one, dim3(256), 0, st, fits, SWP_STAGE_ACTIVE);
+    hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 5);
+    hipLaunchKernelGGL(swpb_eval_kernel<false>, g_eval, dim3(128), 0, st, fits, SWP_STAGE_ACTIVE, 1);   // residuals at the trial point
+    hipLaunchKernelGGL(swpb_loss_kernel, g_one, dim3(256), 0, st, fits, SWP_STAGE_ACTIVE);
+    hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 2);
+    hipLaunchKernelGGL(swpb_accept_kernel, dim3(2, B), dim3(256), 0, st, fits);
+    linearise(SWP_STAGE_ACCEPTED);
+    hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 3);
+  }
+  hipLaunchKernelGGL(swpb_diffprop_kernel, dim3((maxP + 127) / 128, B), dim3(128), 0, st, fits);
+  hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 4);
   return hipGetLastError();
 }
 

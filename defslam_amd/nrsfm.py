@@ -126,6 +126,32 @@ def calculateSchwarps(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot
     return x, diff, drop.astype(bool), info, costs
 
 
+def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3):
+    """B fits in one call (dsh_schwarp_fit_batch).  problems: dicts with bbs (Bbs), kp1, kp2, invsig, fx_slot, fy_slot, lam, fx, fy, x0.
+    Returns a list of (x, diffprops, drop, info, costs) like calculateSchwarps."""
+    B = len(problems)
+    arr = (_lib.SchwarpProblemC * B)()
+    keep = []
+    for b, q in enumerate(problems):
+        kp1 = np.ascontiguousarray(q["kp1"], np.float32).reshape(-1, 2)
+        kp2 = np.ascontiguousarray(q["kp2"], np.float32).reshape(-1, 2)
+        isg = np.ascontiguousarray(q["invsig"], np.float32)
+        x = np.array(q["x0"], np.float64, copy=True)
+        P = kp1.shape[0]
+        diff = np.zeros((P, 18), np.float32)
+        drop = np.zeros(P, np.uint8)
+        keep.append((kp1, kp2, isg, x, diff, drop))
+        a = arr[b]
+        a.bbs = q["bbs"].c()
+        a.P = P
+        a.kp1, a.kp2, a.invsig = _ptr(kp1, C.c_float), _ptr(kp2, C.c_float), _ptr(isg, C.c_float)
+        a.fx_slot, a.fy_slot, a.lam, a.fx, a.fy = float(q["fx_slot"]), float(q["fy_slot"]), float(q["lam"]), float(q["fx"]), float(q["fy"])
+        a.max_iters = int(q.get("max_iters", max_iters))
+        a.x, a.diff, a.drop = _ptr(x, C.c_double), _ptr(diff, C.c_float), _ptr(drop, C.c_uint8)
+    ctx._check(ctx._L.dsh_schwarp_fit_batch(ctx._h, B, arr), "dsh_schwarp_fit_batch")
+    return [(keep[b][3], keep[b][4], keep[b][5].astype(bool), np.array(arr[b].info[:], np.int32), np.array(arr[b].costs[:])) for b in range(B)]
+
+
 def bbs_bending(bbs: Bbs, lam: float) -> np.ndarray:
     """BBS::BendingEigen as a dense symmetric N x N matrix (host side of the library)."""
     L = _lib.load()

@@ -210,6 +210,26 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
                     double fy_slot, double lambda, float fx, float fy, int max_iters, double* x, dsh_diffprop* diff, uint8_t* drop,
                     int32_t* info, double* costs);
 
+/* The same fit for B keyframe pairs at once (SchwarpDatabase::add fits one warp per anchor keyframe of the new keyframe,
+ * SchwarpDatabase.cc:50-128): one copy up, a fixed sequence of launches in which all fits advance together with the
+ * trust-region control on the device (no host round trip), one copy back.  Same results as B calls of dsh_schwarp_fit. */
+typedef struct dsh_schwarp_problem {
+  dsh_bbs bbs;
+  int32_t P;
+  const float* kp1;            /* P x 2 */
+  const float* kp2;            /* P x 2 */
+  const float* invsig;         /* P */
+  double fx_slot, fy_slot, lambda;
+  float fx, fy;
+  int32_t max_iters;
+  double* x;                   /* in/out, 2 N */
+  dsh_diffprop* diff;          /* P, may be NULL together with drop */
+  uint8_t* drop;               /* P */
+  int32_t info[2];             /* out: iterations, accepted steps */
+  double costs[2];             /* out: initial, final cost */
+} dsh_schwarp_problem;
+int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* problems);
+
 /* ---- Shape from Normals -------------------------------------------------------------------------
  * ShapeFromNormals::ShapeFromNormals + ::estimate (Modules/Mapping/ShapeFromNormals.cc:38-171, obtainM :178-260): the
  * depth B-spline (valdim 1, bbs->valdim is ignored) of a keyframe from the normals of its map points.

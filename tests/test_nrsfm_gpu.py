@@ -146,6 +146,33 @@ def test_schwarp_fit_matches_oracle(gpu_ctx, oracle_mod, P, seed, lam, outl, ite
     np.testing.assert_allclose(dg[good, 11], (a / det)[good], rtol=1e-5)
 
 
+def test_schwarp_fit_batch_equals_single_fits_and_the_oracle(gpu_ctx, oracle_mod):
+    """dsh_schwarp_fit_batch (one warp per anchor keyframe of a new keyframe, SchwarpDatabase.cc:50-128): fits of different sizes,
+    regularisation, iteration limits and outlier rates advance together with the trust-region control on the device; every
+    result is bit-identical to the single call and follows the oracle's accept / reject sequence."""
+    from defslam_amd import nrsfm, synth
+    cases = [(300, 3, 0.1, 0.0, 3), (150, 5, 1.0, 0.0, 12), (40, 9, 0.5, 0.1, 3), (500, 21, 1e-2, 0.05, 3), (80, 22, 1e-2, 0.0, 0), (300, 3, 1.0, 0.05, 3)]
+    probs, prs = [], []
+    for P, seed, lam, outl, iters in cases:
+        pr = synth.make_warp_problem(P, seed, outliers=outl)
+        prs.append(pr)
+        probs.append(dict(bbs=nrsfm.Bbs(*pr["bbs"]), kp1=pr["kp1"], kp2=pr["kp2"], invsig=pr["invsig"], fx_slot=pr["fy"], fy_slot=pr["fx"], lam=lam, fx=pr["fx"], fy=pr["fy"],
+                          x0=pr["x0"], max_iters=iters))
+    res = nrsfm.calculateSchwarpsBatch(gpu_ctx, probs)
+    for (P, seed, lam, outl, iters), pr, q, (xb, db, drb, ib, cb) in zip(cases, prs, probs, res):
+        xs, ds, drs, is_, cs = nrsfm.calculateSchwarps(gpu_ctx, q["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, pr["fx"], pr["fy"], pr["x0"], iters)
+        np.testing.assert_array_equal(xb, xs)
+        np.testing.assert_array_equal(db.view(np.uint32), ds.view(np.uint32))
+        np.testing.assert_array_equal(drb, drs)
+        np.testing.assert_array_equal(ib, is_)
+        np.testing.assert_array_equal(cb, cs)
+        xo, do, dro, io, co = oracle_mod.schwarp_fit(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, pr["fx"], pr["fy"], pr["x0"], iters)
+        np.testing.assert_array_equal(ib, io)
+        np.testing.assert_allclose(cb, co, rtol=1e-10)
+        np.testing.assert_allclose(xb, xo, rtol=0, atol=1e-9 * max(1.0, np.abs(xo).max()))
+        np.testing.assert_array_equal(drb, dro)
+
+
 @pytest.mark.parametrize("n,seed,lam", [(600, 4, 1e-3), (150, 7, 0.05), (2500, 9, 1e-4)])
 def test_shape_from_normals_matches_oracle(gpu_ctx, oracle_mod, n, seed, lam):
     """ShapeFromNormals::estimate (SURVEY 8f rank 1): the device solves the stacked least squares by corrected semi-normal

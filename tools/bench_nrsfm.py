@@ -77,6 +77,15 @@ def main():
         dtc = timeit(lambda: oracle.schwarp_fit(wp["bbs"], wp["kp1"], wp["kp2"], wp["invsig"], wp["fy"], wp["fx"], 1e-2, wp["fx"], wp["fy"], wp["x0"], 3), 1)
         rec["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "fits/s", "cores": 1, "kind": "port", "sample": "same problem, oracle/schwarp_oracle.c (dense normal equations, 1 thread; parity unpinned)"}
     out.append(rec)
+    # ---- the same fit for B keyframe pairs per call (SchwarpDatabase::add: one warp per anchor keyframe) ----
+    for B in (8, 64):
+        probs = []
+        for b in range(B):
+            q = synth.make_warp_problem(n_matches=args.matches, seed=100 + b)
+            probs.append(dict(bbs=nrsfm.Bbs(*q["bbs"]), kp1=q["kp1"], kp2=q["kp2"], invsig=q["invsig"], fx_slot=q["fy"], fy_slot=q["fx"], lam=1e-2, fx=q["fx"], fy=q["fy"], x0=q["x0"]))
+        dtb = timeit(lambda: nrsfm.calculateSchwarpsBatch(ctx, probs, 3), max(2, args.reps // 4))
+        out.append({"metric": "Schwarp fit keyframe pairs/s, batched (13x15 grid, 3 LM iterations, host buffers in/out)", "value": B / dtb, "unit": "fits/s", "pairs_per_call": B,
+                    "matches": args.matches, "ms_per_call": 1e3 * dtb})
     for r in out:
         print(json.dumps(r))
     ctx.close()
