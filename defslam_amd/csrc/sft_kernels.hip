@@ -2052,8 +2052,12 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
 }
 
 // Back substitution in tile mode: x_J = Linv_J^T (y_J - sum_{I>J} X_{I,J}^T x_I - Lcn_J^T x_cam).
-// Wave w forms the partial products of tiles (J+d, J), d = w+1+NW*t; wave 0 finishes the block.  The tiles of block J-1
-// are prefetched while block J is processed (LDS-only barriers keep the loads in flight).
+// Roles: the product of tile (J+d, J) with x_{J+d} belongs to wave (d-1) mod NW; wave 1 also forms the camera term; wave 0
+// finishes the block.  Only the d = 1 product needs the block that was finished last, and it belongs to wave 0 itself -- so the
+// chain x_{J+1} -> X_{J+1,J}^T x_{J+1} -> sum -> Linv_J^T -> x_J stays inside wave 0, and everything else of block J (d >= 2, the
+// camera term) only needs x_{J+2} and older: the other products run one block AHEAD of wave 0.  One LDS barrier per block, none
+// on the chain (the version before: two barriers and a partial-sum hand-over on the chain of every block).
+// The L tiles of the next PF blocks are in flight in a register ring (LDS-only barriers keep the loads in flight).
 template <int NW>
 __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws) {
   constexpr int RPW = BT / NW;
@@ -2063,7 +2067,7 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   const int Dnp = ((uni(P.Dn) + NB - 1) / NB) * NB;
   const int nT = Dnp / TS;
   lds_double* xw = to_lds(ws);                // ring of BT x-tiles
-  lds_double* part = xw + TS * BT;     // (BT+1) partial vectors
+  lds_double* part = xw + TS * BT;            // 2 x (BT+1) partial vectors, double buffered by block parity
   const int crow = lane >> 4, ccol = lane & 15;
   const double xc = (lane < 6) ? P.x[Dnp + lane] : 0.0;
   double xcr[6];
@@ -2082,7 +2086,7 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
     for (int t = 0; t < RPW; t++) p.t[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 6; r++) p.aux[r] = 0.0;
-    if (J < 0) return p;
+    if (J < 0 || J >= nT) return p;
 #pragma unroll
     for (int t = 0; t < RPW; t++) {
       const int d = wave + 1 + NW * t;
@@ -2099,52 +2103,62 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
     }
     return p;
   };
-  // Tiles of the next PF blocks are in flight (register ring, the block loop is unrolled PF times): under load the
-  // L tiles come from HBM, one block of look-ahead does not cover that latency.
+  // product of the wave's tile t of block J with x_{J+d}: 16 partial sums (replicated in the four 16-lane groups after the shuffles)
+  auto product = [&](const Pre& e, int t, int J) -> double {
+    const int d = wave + 1 + NW * t, I = J + d;
+    double p = 0.0;
+    if (I < nT) {
+      const lds_double* xi = xw + (I & (BT - 1)) * TS + crow;
+#pragma unroll
+      for (int q = 0; q < 4; q++) p = fma(e.t[t][q], xi[4 * q], p);
+      p = sum_rows(p);
+    }
+    return p;
+  };
+  // Slot s (s = nT ... 0): wave 0 finishes block s (its own d = 1 product + the partials the others wrote in slot s+1);
+  // every wave writes its d >= 2 products (wave 1: + the camera term) of block s-1.  Ring position j holds block (base - j) and
+  // is refilled with block (base - j - PF) as soon as it has been taken: PF blocks of look-ahead all the time.
   constexpr int PF = 6;
   Pre ring[PF];
 #pragma unroll
-  for (int j = 0; j < PF; j++) ring[j] = fetch(nT - 1 - j);
+  for (int j = 0; j < PF; j++) ring[j] = fetch(nT - j);
 #pragma unroll 1
-  for (int base = nT - 1; base >= 0; base -= PF) {
+  for (int base = nT; base >= 0; base -= PF) {
 #pragma unroll
     for (int j = 0; j < PF; j++) {
-      const int J = base - j;
-      if (J < 0) break;
-      const Pre cur = ring[j];
-      ring[j] = fetch(J - PF);
+      const int s = base - j;
+      if (s < 0) break;
+      const Pre cur = ring[j];            // block s
+      ring[j] = fetch(s - PF);
+      const Pre& nxt = ring[(j + 1) % PF];   // block s - 1 (position 0 was refilled with block base - PF at the start of this chunk)
+      lds_double* part_s = part + (s & 1) * (BT + 1) * TS;
+      lds_double* part_n = part + ((s - 1) & 1) * (BT + 1) * TS;
+      // ---- ahead of wave 0: block s-1, tiles at distance >= 2 and the camera term (x_{s+1} and older are final)
+      if (s >= 1) {
 #pragma unroll
-      for (int t = 0; t < RPW; t++) {
-        const int d = wave + 1 + NW * t;
-        const int I = J + d;
-        double p = 0.0;
-        if (I < nT) {
-          const lds_double* xi = xw + (I & (BT - 1)) * TS + crow;
-#pragma unroll
-          for (int q = 0; q < 4; q++) p = fma(cur.t[t][q], xi[4 * q], p);
-          p += __shfl_xor(p, 16, 64);
-          p += __shfl_xor(p, 32, 64);
+        for (int t = 0; t < RPW; t++) {
+          const int d = wave + 1 + NW * t;
+          if (d >= 2) { const double p = product(nxt, t, s - 1); if (lane < TS) part_n[d * TS + lane] = p; }
         }
-        if (lane < TS) part[d * TS + lane] = p;
-      }
-      if (wave == 1 && lane < TS) {
-        double p = 0.0;
+        if (wave == 1 && lane < TS) {
+          double p = 0.0;
 #pragma unroll
-        for (int r = 0; r < 6; r++) p = fma(cur.aux[r], xcr[r], p);
-        part[lane] = p;
+          for (int r = 0; r < 6; r++) p = fma(nxt.aux[r], xcr[r], p);
+          part_n[lane] = p;
+        }
       }
-      lds_barrier();
-      if (wave == 0) {
-        double v = cur.aux[4];
+      // ---- wave 0: block s
+      if (wave == 0 && s < nT) {
+        double v = cur.aux[4] - product(cur, 0, s);      // y_s - X_{s+1,s}^T x_{s+1}
+        v -= part_s[ccol];                               // camera term
 #pragma unroll
-        for (int i = 0; i <= BT; i++) v -= part[i * TS + ccol];
+        for (int i = 2; i <= BT; i++) v -= part_s[i * TS + ccol];
         // x[c] = sum_r Linv[r][c] v[r]   (v is replicated in every 16-lane group)
         double p = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 32, 64);
-        if (lane < TS) { xw[(J & (BT - 1)) * TS + lane] = p; xg[TS * J + lane] = p; }
+        p = sum_rows(p);
+        if (lane < TS) { xw[(s & (BT - 1)) * TS + lane] = p; xg[TS * s + lane] = p; }
       }
       lds_barrier();
     }

@@ -352,8 +352,7 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, Ctl* ctl, double* ws)
           const lds_double* xi = xw + (I & (RING - 1)) * TS + crow;
 #pragma unroll
           for (int q = 0; q < 4; q++) p = fma(cur.t[t][q], xi[4 * q], p);
-          p += __shfl_xor(p, 16, 64);
-          p += __shfl_xor(p, 32, 64);
+          p = sum_rows(p);
         }
         if (lane < TS && d <= wb) part[d * TS + lane] = p;
       }
@@ -371,8 +370,7 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, Ctl* ctl, double* ws)
         double p = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 32, 64);
+        p = sum_rows(p);
         if (lane < TS) { xw[(J & (RING - 1)) * TS + lane] = p; xg[TS * J + lane] = p; }
       }
       lds_barrier();

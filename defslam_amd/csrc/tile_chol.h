@@ -15,6 +15,21 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Sum over the four 16-lane rows of a wavefront (lanes c, c+16, c+32, c+48), result (p[c] + p[c+16]) + (p[c+32] + p[c+48]) in every
+// lane: the gfx950 lane swaps v_permlane16_swap / v_permlane32_swap on the vector ALU instead of two round trips through the LDS
+// crossbar (ds_bpermute) -- same association as `p += shfl_xor(p, 16); p += shfl_xor(p, 32)` (tools/probes/permlane_probe.hip).
+__device__ __forceinline__ double sum_rows(double p) {
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(p), hi = __double2hiint(p);
+  v2u_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  v2u_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double q = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(q); hi = __double2hiint(q);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
 // 1/sqrt(d) to double precision: v_rsq_f64 seed (~2^-26 relative) + one coupled Goldschmidt/Newton step
 // (quadratic: ~2^-52) + one residual correction of the square root.
 __device__ __forceinline__ void rsqrt_sqrt(double d, double& inv, double& s) {
