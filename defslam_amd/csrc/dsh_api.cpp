@@ -25,6 +25,7 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
 #ifdef DSH_LAB
@@ -117,13 +118,20 @@ struct dsh_ctx : dsh_ctx_base {
   int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
   size_t lds_configured[2] = {0, 0};   // dynamic LDS size the two launch shapes were last enabled for on THIS device
   size_t lds_configured_sc = 0;        // the same for the phase kernel of the shared-camera mode
+  size_t lds_configured_spec = 0;      // and for the speculative-trial kernel
+  // latency mode: K workgroups per problem run the next K damping trials of an iteration side by side (sft_kernels.hip: sft_spec_kernel)
+  int spec_k = 1;
+  int max_iters_batch = 0;
+  SftSpec* d_spec = nullptr;           // K*B controller states, inside d_batch
+  size_t spec_bytes = 0;
+  HostBuf spec_done;                   // page-locked: lane 0's SftSpec of every problem (the done flag)
   SftSc* d_sc = nullptr;               // shared-camera mode: LM state between the phase kernels
   int force_waves = 0;                 // set while the shared-camera mode packs its problem (always the 8-wavefront shape)
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int asm_direct = 0; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int asm_direct = 0; int speculate = 0; } opt;
 };
 
 namespace {
@@ -248,6 +256,35 @@ int pack_problem(dsh_ctx* c, const dsh_sft_frame& f, bool wide_off, Packed& P, s
   const float deltaMono = (float)std::sqrt(5.991);             // :286
   h.hub_delta = (double)deltaMono;
   h.hub_dsqr = h.hub_delta * h.hub_delta;
+  return DSH_OK;
+}
+
+// One solve of the uploaded batch.  K == 1: the persistent kernel, one launch, asynchronous.  K > 1 (latency mode): one launch
+// per round of K damping trials; an iteration that accepts one of its first K trials takes one launch, so max_iters + 1 launches
+// finish the typical frame; the done flags are read back behind them and further rounds are launched only while needed.
+int run_once(dsh_ctx* c) {
+  if (c->spec_k <= 1) {
+    HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
+    return DSH_OK;
+  }
+  const int K = c->spec_k, B = c->B;
+  HIPCHK(c, hipMemsetAsync(c->d_spec, 0, c->spec_bytes, c->stream));
+  const int rounds_per_iter = (10 + K - 1) / K;
+  const int worst = c->max_iters_batch * rounds_per_iter + 1;
+  int launched = 0, group = std::min(worst, c->max_iters_batch + 1);
+  HIPCHK(c, c->spec_done.ensure(sizeof(SftSpec) * (size_t)B, true));
+  while (launched < worst) {
+    for (int i = 0; i < group && launched < worst; i++, launched++)
+      HIPCHK(c, sft_spec_launch(c->d_probs, c->d_spec, B, K, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream));
+    if (launched >= worst) break;
+    HIPCHK(c, hipMemcpyAsync(c->spec_done.p, c->d_spec, sizeof(SftSpec) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const SftSpec* sp = reinterpret_cast<const SftSpec*>(c->spec_done.p);
+    bool all_done = true;
+    for (int b = 0; b < B; b++) all_done = all_done && sp[b].done;
+    if (all_done) break;
+    group = 3;
+  }
   return DSH_OK;
 }
 
@@ -426,6 +463,13 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
     if (c->force_waves == 8) nw = 8;
   }
+  // Latency mode: while CUs would idle anyway, every problem gets K of them and tries K dampings per iteration at once.
+  int K = 1;
+  if (nw == 8 && !c->force_waves && !c->host_only) {
+    K = (4 * B <= c->num_cus) ? 4 : ((2 * B <= c->num_cus) ? 2 : 1);
+    if (c->opt.speculate >= 1 && c->opt.speculate <= SFT_SPEC_MAXK) K = c->opt.speculate;   // lab builds only
+    for (int b = 0; b < B; b++) if (c->packed[b].f.max_iters < 1) K = 1;
+  }
   // LDS of the assembly (it aliases the solver workspace): one staged tile row of H per wavefront, then the records a gather
   // touches most often, as far as the budget goes (4 wavefronts: two problems share a CU's 160 KB)
   size_t jl_doubles = 0;
@@ -454,7 +498,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   }
   // ---- layout: [SftDev table][per-frame read-only arrays of every problem] | [result region: B headers, bodies] | [workspace]
   Arena a;
-  const size_t o_tab = a.take(sizeof(SftDev) * B);
+  const size_t o_tab = a.take(sizeof(SftDev) * B * K);   // lane-major: lane 0 of every problem first
   struct Offs { size_t obs_nodes, obs_bary, obs_uv, obs_w, ob_ptr, ob_m, ob_c, viewed, xyz_init, pose_init; };
   std::vector<Offs> ro(B);
   for (int b = 0; b < B; b++) {
@@ -478,13 +522,18 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     r.mp = a.take(4 * 3 * (size_t)h.M) - c->res_off; r.outl = a.take((size_t)h.M) - c->res_off;
   }
   c->res_bytes = a.size - c->res_off;
-  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg; };
-  std::vector<WOffs> wo(B);
+  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; };
+  std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
-  for (int b = 0; b < B; b++) {
+  const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
+  for (int e = 0; e < B * K; e++) {
+    const int b = e % B, lane = e / B;
     const SftDev& h = c->packed[b].h;
     const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
-    WOffs& w = wo[b];
+    WOffs& w = wo[e];
+    w.sx0 = a.take(K > 1 ? 8 * 3 * (size_t)h.n : 0); w.sx1 = a.take(K > 1 ? 8 * 3 * (size_t)h.n : 0);
+    // lanes > 0 keep their state, errors and pose in the workspace: only lane 0 owns a slot of the result region
+    w.shadow_xyz = a.take(lane ? 8 * 3 * (size_t)h.n : 0); w.shadow_chi2 = a.take(lane ? 8 * (size_t)h.M : 0); w.shadow_hdr = a.take(lane ? sizeof(SftResHdr) : 0);
     w.bak = a.take(8 * 3 * (size_t)h.n);
     w.camrec = a.take(8 * (size_t)h.M * SFT_CAM_STRIDE);
     w.wtv = a.take(h.lds_class >= 1 ? 0 : 8 * ((size_t)h.M + 1)); w.Jstar = a.take(h.lds_class >= 1 ? 0 : 8 * 4 * (size_t)h.S);
@@ -514,19 +563,24 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   HIPCHK(c, c->stage.ensure(c->ro_bytes, true));
   char* st = c->stage.p;
   char* base = c->d_batch;
-  c->h_probs.resize(B);
+  c->h_probs.resize((size_t)B * K);
   SftResHdr* d_hdr = (SftResHdr*)(base + c->res_off);
-  for (int b = 0; b < B; b++) {
+  int max_iters = 0;
+  for (int e = 0; e < B * K; e++) {
+    const int b = e % B, lane = e / B;
     Packed& P = c->packed[b];
     const dsh::SftFramePack& F = P.f;
     const dsh::SftGraph& g = *P.g;
     const Offs& o = ro[b];
-    put(st, o.obs_nodes, F.obs_nodes); put(st, o.obs_bary, F.obs_bary); put(st, o.obs_uv, F.obs_uv); put(st, o.obs_w, F.obs_w);
-    put(st, o.ob_ptr, F.ob_ptr); put(st, o.ob_m, F.ob_m); put(st, o.ob_c, F.ob_c); put(st, o.viewed, F.viewed); put(st, o.xyz_init, F.xyz_init);
-    std::memcpy(st + o.pose_init, F.pose_init, 7 * sizeof(double));
+    if (lane == 0) {
+      put(st, o.obs_nodes, F.obs_nodes); put(st, o.obs_bary, F.obs_bary); put(st, o.obs_uv, F.obs_uv); put(st, o.obs_w, F.obs_w);
+      put(st, o.ob_ptr, F.ob_ptr); put(st, o.ob_m, F.ob_m); put(st, o.ob_c, F.ob_c); put(st, o.viewed, F.viewed); put(st, o.xyz_init, F.xyz_init);
+      std::memcpy(st + o.pose_init, F.pose_init, 7 * sizeof(double));
+    }
     SftDev h = P.h;
-    const WOffs& w = wo[b];
+    const WOffs& w = wo[e];
     const dsh_ctx::ResOffs& r = c->res_offs[b];
+    max_iters = std::max(max_iters, F.max_iters);
     char* rbase = base + c->res_off;
     const char* gb = g.d_base;
     h.xyz0 = c->dt.xyz0; h.nbr_ptr = c->dt.nbr_ptr; h.nbr_idx = c->dt.nbr_idx; h.nbr_w = c->dt.nbr_w; h.nbr_sumw = c->dt.nbr_sumw; h.k0 = c->dt.k0;
@@ -549,9 +603,15 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc); h.Linv = (double*)(base + w.Linv);
     h.Lt = (double*)(base + w.Lt); h.LbT = (double*)(base + w.LbT);
     h.x = (double*)(base + w.x); h.dbg = (double*)(base + w.dbg);
-    c->h_probs[b] = h;
+    h.spec_xyz[0] = (double*)(base + w.sx0); h.spec_xyz[1] = (double*)(base + w.sx1);
+    if (lane) {
+      h.xyz = (double*)(base + w.shadow_xyz); h.chi2_obs = (double*)(base + w.shadow_chi2);
+      h.res = (SftResHdr*)(base + w.shadow_hdr); h.pose = ((SftResHdr*)(base + w.shadow_hdr))->pose;
+      h.trace = nullptr; h.mappoint = nullptr; h.outlier = nullptr;
+    }
+    c->h_probs[e] = h;
   }
-  std::memcpy(st + o_tab, c->h_probs.data(), sizeof(SftDev) * B);
+  std::memcpy(st + o_tab, c->h_probs.data(), sizeof(SftDev) * B * K);
   HIPCHK(c, hipMemcpyAsync(base, st, c->ro_bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->stage_free, c->stream));
   c->stage_busy = true;
@@ -562,6 +622,10 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   if (fresh_arena) HIPCHK(c, hipMemsetAsync(base + ws_off, 0, a.size - ws_off, c->stream));
   HIPCHK(c, hipMemsetAsync(base + c->res_off, 0, c->res_bytes, c->stream));
   c->d_probs = (SftDev*)(base + o_tab);
+  c->d_spec = (SftSpec*)(base + o_spec);
+  c->spec_bytes = sizeof(SftSpec) * (size_t)B * K;
+  c->spec_k = K;
+  c->max_iters_batch = max_iters;
   c->B = B;
   c->max_kd = max_kd;
   c->jl_doubles = jl_doubles;
@@ -574,7 +638,8 @@ int dsh_sft_batch_run(dsh_ctx* c) {
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_sft_batch_run: host-only context, no GPU (there is no CPU fallback)");
   if (c->B <= 0) return fail(c, DSH_ERR_STATE, "dsh_sft_batch_run: nothing uploaded");
   (void)hipSetDevice(c->device);
-  HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
+  const int rc = run_once(c);
+  if (rc != DSH_OK) return rc;
   c->ran = true;
   return DSH_OK;
 }
@@ -869,6 +934,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   if (k == "waves") { if (value != 0 && value != 4 && value != 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: waves is 0 (automatic), 4 or 8"); c->opt.waves = value; }
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
+  else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else if (k == "asm_direct") c->opt.asm_direct = value != 0;
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;
@@ -882,7 +948,7 @@ int dsh_lab_sft_run_timed(dsh_ctx* c, int launches, double* total_ms) {
   EventPair ev;
   HIPCHK(c, ev.create());
   HIPCHK(c, hipEventRecord(ev.e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
+  for (int i = 0; i < launches; i++) { const int rc = run_once(c); if (rc != DSH_OK) return rc; }
   HIPCHK(c, hipEventRecord(ev.e1, c->stream));
   HIPCHK(c, hipEventSynchronize(ev.e1));
   float ms = 0.f;

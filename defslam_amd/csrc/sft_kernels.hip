@@ -2168,6 +2168,63 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 
 #include "sft_wide.h"
 
+// One damping trial at ctl->lambda from the current state: factorisation of H + lambda I, back substitution, state update
+// (sparse_optimizer.cpp:477-491), scale = sum_j x_j (lambda x_j + b_j) (optimization_algorithm_levenberg.cpp:166-176) and the robust
+// chi2 at the trial state.  The caller has pushed the state and pops it on rejection.
+template <int NW>
+__device__ __forceinline__ double damping_trial(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, int& ok, double& scale) {
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x;
+  const int Dn = P.Dn;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  PH_T0();
+  if (P.tile_mode == 2) {
+    if constexpr (NW == 8) {   // wide band: always the 512-thread kernel
+      factor_wide(P, ctl, panel);
+      PH_ADD(5);
+      backsub_wide(P, ctl, panel);
+      PH_ADD(6);
+    }
+  } else if (P.tile_mode) {
+#ifdef DSH_LAB
+    if (!(P.mode & 2)) factor_tiles<NW>(P, ctl, panel);
+    else
+#endif
+    {
+      PH_RESET();
+      if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel, ctl->lambda, true);
+      else factor_tiles_df<NW>(P, ctl, panel);
+      PH_ADD(5);
+    }
+    PH_RESET();
+    backsub_tiles<NW>(P, ctl, panel);
+    PH_ADD(6);
+  } else {
+    if constexpr (NW == 8) factor_and_solve(P, ctl, panel, red);   // band mode always runs the 512-thread kernel
+  }
+  PH_RESET();
+  ok = ctl->fact_ok;
+  // update
+  for (int i = tid; i < 3 * P.n; i += NT) {
+    const int a = P.act[i / 3];
+    if (a >= 0) P.xyz[i] += P.x[3 * a + (i % 3)];
+  }
+  if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
+  // scale = sum_j x_j (lambda x_j + b_j)
+  double sc = 0.0;
+  const double lam = ctl->lambda;
+  for (int r = tid; r < Dn; r += NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
+  if (tid < 6) { const double xv = P.x[Dnp + tid]; sc += xv * (lam * xv + P.Hcorner[42 + tid]); }
+  __syncthreads();
+  block_sum<1>(&sc, red, out);
+  scale = out[0];
+  __syncthreads();
+  PH_ADD(7);
+  const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+  PH_ADD(1);
+  return chi_new;
+}
+
 // ------------------------------------------------------------------------------------------
 // The persistent per-problem kernel
 // ------------------------------------------------------------------------------------------
@@ -2283,7 +2340,6 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
   double* panel = out + 32;
   const int tid = threadIdx.x;
   const int Dn = P.Dn;
-  const int Dnp = ((Dn + NB - 1) / NB) * NB;
 
   init_state<NT>(P);
   if (tid == 0) { ctl->lambda = -1.0; ctl->ni = 2.0; ctl->nbad = 0; ctl->stop = 0; ctl->it = 0; }
@@ -2319,51 +2375,11 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
       for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];
       double pose_bak = (tid < 7) ? P.pose[tid] : 0.0;
       PH_ADD(7);
-      if (P.tile_mode == 2) {
-        if constexpr (NW == 8) {   // wide band: always the 512-thread kernel
-          factor_wide(P, ctl, panel);
-          PH_ADD(5);
-          backsub_wide(P, ctl, panel);
-          PH_ADD(6);
-        }
-      } else if (P.tile_mode) {
-#ifdef DSH_LAB
-        if (!(P.mode & 2)) factor_tiles<NW>(P, ctl, panel);
-        else
-#endif
-        {
-          PH_RESET();
-          if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel, ctl->lambda, true);
-          else factor_tiles_df<NW>(P, ctl, panel);
-          PH_ADD(5);
-        }
-        PH_RESET();
-        backsub_tiles<NW>(P, ctl, panel);
-        PH_ADD(6);
-      } else {
-        if constexpr (NW == 8) factor_and_solve(P, ctl, panel, red);   // band mode always runs the 512-thread kernel
-      }
+      int ok;
+      double scale;
+      const double chi_new = damping_trial<NW>(P, ctl, red, out, panel, ok, scale);
       PH_RESET();
-      const int ok = ctl->fact_ok;
       all_ok &= ok;
-      // update
-      for (int i = tid; i < 3 * P.n; i += NT) {
-        const int a = P.act[i / 3];
-        if (a >= 0) P.xyz[i] += P.x[3 * a + (i % 3)];
-      }
-      if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
-      // scale = sum_j x_j (lambda x_j + b_j)
-      double sc = 0.0;
-      const double lam = ctl->lambda;
-      for (int r = tid; r < Dn; r += NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
-      if (tid < 6) { const double xv = P.x[Dnp + tid]; sc += xv * (lam * xv + P.Hcorner[42 + tid]); }
-      __syncthreads();
-      block_sum<1>(&sc, red, out);
-      const double scale = out[0];
-      __syncthreads();
-      PH_ADD(7);
-      const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
-      PH_ADD(1);
       if (tid == 0) {
         double tempChi = ok ? chi_new : DBL_MAX;
         double rho = (ctl->chi_cur - tempChi);
@@ -2410,6 +2426,155 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
     if (term) break;
   }
   classify<NT>(P, ctl, panel, iters, total_trials);
+}
+
+// ------------------------------------------------------------------------------------------
+// Latency mode: speculative damping trials.  One tracked frame is ONE problem and 255 of the 256 CUs idle; a Levenberg-Marquardt
+// iteration, however, usually needs two or three damping trials (after an accepted step the damping shrinks to a third, the next
+// first trial is too bold, is rejected, and lambda nu is accepted: golden traces 1,3,1,3,2,2,2...), and the dampings of the
+// rejection chain are known in advance: lambda, lambda nu, lambda nu (2 nu), ...  K workgroups ("lanes", on K CUs) linearise the
+// same state redundantly -- identical arithmetic, so identical H -- and lane j runs trial j of the chain; the next launch reads the
+// K results and replays the controller in trial order: the first accepted trial wins, exactly the sequence the one-workgroup
+// kernel would have walked through, at one trial per iteration instead of two.  The kernel boundary is the only synchronisation
+// (no device-scope fences, no flags); results, state and decisions are bit-identical to sft_lm_kernel.
+// ------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int B = gridDim.x / K, b = blockIdx.x / K, j = blockIdx.x % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
+  const SftDev& P = probs[(size_t)j * B + b];
+  SftSpec& S = specs[(size_t)j * B + b];
+  auto peer = [&](int jj) -> const SftSpec& { return specs[(size_t)jj * B + b]; };
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);
+  double* out = red + 16 * 27 + 5;
+  double* panel = out + 32;
+  const int tid = threadIdx.x;
+  const int Dn = P.Dn;
+  if (S.done) return;
+  const int L = S.launches, par = L & 1, prev = par ^ 1;
+  if (L == 0) {
+    init_state<NT>(P);
+    if (tid == 0) { S.lambda = -1.0; S.ni = 2.0; S.nbad = 0; S.it = 0; S.qbase = 0; S.iters = 0; S.trials = 0; S.need_lin = 1; S.last_lane = 0; S.all_ok = 1; }
+    __syncthreads();
+  } else {
+    // ---- the controller over the K trials of the previous launch, in trial order (optimization_algorithm_levenberg.cpp:102-164)
+    if (tid == 0) {
+      double lam = S.lambda, ni = S.ni, chi_cur = S.chi_cur, rho = 0.0;
+      int q = S.qbase, accepted = 0, winner = -1, ended = 0, last = 0, all_ok = S.all_ok;
+      for (int jj = 0; jj < K && !ended; jj++) {
+        const SftSpecRes& R = peer(jj).res[prev];
+        if (!R.valid) break;
+        q++;
+        last = jj;
+        all_ok &= R.ok;
+        const double tempChi = R.ok ? R.chi_new : DBL_MAX;
+        rho = (chi_cur - tempChi);
+        rho /= (R.scale + 1e-3);
+        if (rho > 0 && isfinite(tempChi)) {
+          double alpha = 1. - pow((2 * rho - 1), 3);
+          alpha = fmin(alpha, 2. / 3.);
+          const double sf = fmax(1. / 3., alpha);
+          lam = R.lambda * sf; ni = 2.0; chi_cur = tempChi; accepted = 1; winner = jj; ended = 1;
+        } else {
+          lam = R.lambda * R.ni; ni = R.ni * 2.0;
+          if (!(rho < 0) || q >= 10) ended = 1;
+        }
+      }
+      S.lambda = lam; S.ni = ni; S.chi_cur = chi_cur; S.rho = rho; S.all_ok = all_ok; S.last_lane = last;
+      if (accepted) S.accepted = 1;
+      ctl->accepted = accepted; ctl->qmax = q; ctl->it = winner; ctl->stop = ended;
+    }
+    __syncthreads();
+    const int accepted = ctl->accepted, qmax = ctl->qmax, winner = ctl->it, ended = ctl->stop;
+    if (accepted) {   // every lane continues from the winner's state
+      const auto src = probs[(size_t)winner * B + b].spec_xyz[prev];
+      for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = src[i];
+      if (tid < 7) P.pose[tid] = peer(winner).res[prev].pose[tid];
+    } else {          // pop the lane's own trial
+      for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
+      if (tid < 7) P.pose[tid] = S.pose_bak[tid];
+    }
+    __syncthreads();
+    if (ended) {      // the outer iteration is over (sparse_optimizer.cpp:403-475 + the reference's stop rule)
+      if (tid == 0) {
+        S.trials += qmax;
+        S.iters++;
+        if (j == 0 && P.trace) {
+          double* t = P.trace + S.it * 8;
+          t[0] = S.chi_ini; t[1] = S.lambda_start; t[2] = qmax; t[3] = S.chi_cur; t[4] = S.lambda; t[5] = S.rho; t[6] = S.accepted; t[7] = S.all_ok;
+        }
+        if (j == 0 && !S.all_ok) P.res->status |= 1;
+        bool term = (qmax == 10) || (S.rho == 0);
+        if (!term) {
+          if ((S.chi_ini - S.chi_cur) * 1e3 < S.chi_ini) S.nbad++; else S.nbad = 0;
+          term = S.nbad >= 3;
+        }
+        S.it++;
+        if (S.it >= P.max_iters) term = true;
+        S.need_lin = 1; S.qbase = 0;
+        ctl->nbad = term ? 1 : 0;
+      }
+      __syncthreads();
+      if (ctl->nbad) {   // finished: lane 0 owns the results
+        if (j == 0) {
+          const int last = S.last_lane;
+          if (last != 0) {   // the errors of the LAST evaluated trial are what the classification reads (DefOptimizer.cc:515-537)
+            const auto src = probs[(size_t)last * B + b].chi2_obs;
+            for (int m = tid; m < P.M; m += NT) P.chi2_obs[m] = src[m];
+            __syncthreads();
+          }
+          classify<NT>(P, ctl, panel, S.iters, S.trials);
+        }
+        __syncthreads();
+        if (tid == 0) S.done = 1;
+        return;
+      }
+    } else if (tid == 0) {
+      S.qbase = qmax; S.need_lin = 0;
+    }
+    __syncthreads();
+  }
+  // ---- this launch's work: (new iteration: linearise) + the lane's trial of the rejection chain
+  if (S.need_lin) {
+    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+    if (S.it == 0) {
+      double mx = 0.0;
+      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
+      if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+      mx = block_max(mx, red);
+      if (tid == 0) { S.lambda = 1e-5 * mx; S.ni = 2.0; S.nbad = 0; }
+    }
+    if (tid == 0) { S.chi_cur = chi0; S.chi_ini = chi0; S.rho = 0.0; S.accepted = 0; S.all_ok = 1; }
+    __syncthreads();
+    if (tid == 0) S.lambda_start = S.lambda;
+  }
+  __syncthreads();
+  double lam = S.lambda, ni = S.ni;
+  for (int t = 0; t < j; t++) { lam *= ni; ni *= 2.0; }   // trial j of the chain: the damping after j rejections
+  const bool in_range = S.qbase + j < 10;                 // the reference stops after ten trials
+  if (in_range) {
+    for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];   // push
+    if (tid < 7) S.pose_bak[tid] = P.pose[tid];
+    if (tid == 0) ctl->lambda = lam;
+    __syncthreads();
+    int ok;
+    double scale;
+    const double chi_new = damping_trial<NW>(P, ctl, red, out, panel, ok, scale);
+    const auto dst = P.spec_xyz[par];
+    for (int i = tid; i < 3 * P.n; i += NT) dst[i] = P.xyz[i];
+    if (tid == 0) {
+      SftSpecRes& R = S.res[par];
+      R.chi_new = chi_new; R.scale = scale; R.lambda = lam; R.ni = ni; R.ok = ok; R.valid = 1;
+      for (int k = 0; k < 7; k++) R.pose[k] = P.pose[k];
+    }
+  } else if (tid == 0) {
+    S.res[par].valid = 0;
+    for (int k = 0; k < 7; k++) S.pose_bak[k] = P.pose[k];
+  }
+  if (!in_range) for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];
+  if (tid == 0) S.launches = L + 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2634,6 +2799,17 @@ extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, i
     *configured = lds;
   }
   hipLaunchKernelGGL(sft_sc_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs, d_sc, phase);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+  if (lds > *configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_spec_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    *configured = lds;
+  }
+  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K), dim3(512), lds, stream, d_probs, d_spec, K);
   return hipGetLastError();
 }
 

@@ -59,6 +59,18 @@ struct SftSc {
   int32_t it, qmax, nbad, accepted, again, done, all_ok, fact_ok, iters, trials, rank, nranks;
 };
 
+// Speculative damping trials (latency mode, sft_kernels.hip: sft_spec_kernel): K workgroups ("lanes") per problem try the next K
+// dampings lambda, lambda nu, lambda nu 2nu, ... of the Levenberg-Marquardt rejection chain at the same time.  Every lane keeps
+// the controller state (identical by construction) and publishes its trial, double buffered by launch parity.
+#define SFT_SPEC_MAXK 4
+struct SftSpecRes { double chi_new, scale, lambda, ni, pose[8]; int32_t ok, valid; };
+struct SftSpec {
+  double lambda, ni, chi_cur, chi_ini, lambda_start, rho;
+  double pose_bak[8];
+  int32_t it, qbase, nbad, accepted, all_ok, iters, trials, done, launches, need_lin, last_lane, pad;
+  SftSpecRes res[2];
+};
+
 struct SftDev {
   // sizes
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, noff, max_iters, mode;
@@ -136,4 +148,5 @@ struct SftDev {
   SFT_G uint8_t* outlier;         // M  (float)chi2 > 5.991 (DefOptimizer.cc:515-537)
   SFT_G float* mappoint;          // M*3 DefMapPoint::RecalculatePosition of every observation's point (DefMapPoint.cc:129-147)
   SFT_G double* dbg;              // lab builds: [0] robust chi2 of dsh_lab_sft_system, phase timers, step stamps
+  SFT_G double* spec_xyz[2];      // speculative trials: n*3 each, the lane's state after its trial (by launch parity)
 };

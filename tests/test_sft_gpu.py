@@ -448,3 +448,41 @@ def test_assembly_only_launches_leave_the_batch_intact(lab_ctx):
         assert (f.iters, f.trials) == (it, tr)
         np.testing.assert_array_equal(f.nodes_xyz, x)
         np.testing.assert_array_equal(f.pose7, q)
+
+
+@pytest.mark.parametrize("cfg,pids,iters", [("smoke", (0, 1, 2, 3, 4, 5), 10), ("C2", (0, 5), 10), ("W16", (0, 1), 6), ("B272", (0,), 5), ("C5", (0,), 4), ("smoke", (7,), 1)])
+def test_speculative_damping_trials_are_bit_identical(lab_ctx, cfg, pids, iters):
+    """Latency mode (sft_spec_kernel): K workgroups per problem run K consecutive dampings of the rejection chain side by side
+    and the next launch replays the Levenberg-Marquardt controller over them in trial order.  Same arithmetic on the same
+    state: vertices, pose, per-observation errors, classification and the whole iteration trace equal the one-workgroup
+    kernel bit for bit, for every lane count, tile mode (banded MFMA tiles, wide tiles) and for several problems per launch."""
+    from defslam_amd import sft, synth
+    ctx = lab_ctx
+    runs = {}
+    try:
+        for K in (1, 2, 3, 4):
+            ctx.set_option("speculate", K)
+            frames = []
+            for pid in pids:
+                tmpl, fr = synth.make_problem(cfg, pid)
+                if not frames:
+                    ctx.template_build(tmpl.xyz0, tmpl.facets)
+                frames.append(sft.frame_from_synth(fr))
+            inl = sft.DefPoseOptimizationBatch(ctx, frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, max_iters=iters)
+            runs[K] = (frames, inl)
+    finally:
+        ctx.set_option("speculate", 0)
+    f1, i1 = runs[1]
+    assert sum(f.trials for f in f1) > sum(f.iters for f in f1) or iters == 1   # the cases do reject trials
+    for K in (2, 3, 4):
+        fk, ik = runs[K]
+        assert ik == i1
+        for a, b in zip(fk, f1):
+            assert (a.iters, a.trials, a.status) == (b.iters, b.trials, b.status)
+            np.testing.assert_array_equal(a.trace, b.trace)
+            np.testing.assert_array_equal(a.nodes_xyz, b.nodes_xyz)
+            np.testing.assert_array_equal(a.pose7, b.pose7)
+            np.testing.assert_array_equal(a.chi2_obs, b.chi2_obs)
+            np.testing.assert_array_equal(a.mvbOutlier, b.mvbOutlier)
+            np.testing.assert_array_equal(a.mappoints, b.mappoints)
+            assert a.rep_error_f64 == b.rep_error_f64
