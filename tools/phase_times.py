@@ -6,6 +6,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 WAVES = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 ctx.set_option("waves", WAVES)
+if len(sys.argv) > 4:
+    ctx.set_option("speculate", int(sys.argv[4]))   # 1 = the one-workgroup kernel also for small batches
 rows, cols, m = synth.CONFIGS[cfg]
 tmpl = synth.make_grid_template(rows, cols)
 ctx.template_build(tmpl.xyz0, tmpl.facets)
