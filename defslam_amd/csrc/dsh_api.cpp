@@ -131,7 +131,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int asm_direct = 0; int speculate = 0; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; } opt;
 };
 
 namespace {
@@ -216,10 +216,12 @@ int graph_for(dsh_ctx* c, const std::vector<uint8_t>& opt, dsh::SftGraph** out, 
     o.act = reserve(a, g->act); o.actnode = reserve(a, g->actnode); o.star_node = reserve(a, g->star_node); o.star_sL = reserve(a, g->star_sL);
     o.str_nodes = reserve(a, g->str_nodes); o.str_L0 = reserve(a, g->str_L0); o.off_ptr = reserve(a, g->off_ptr); o.off_rc = reserve(a, g->off_rc);
     o.sh_ptr = reserve(a, g->sh_ptr); o.sh_rec = reserve(a, g->sh_rec); o.sh_cf = reserve(a, g->sh_cf); o.tmask = reserve(a, g->tmask);
+    o.hgather = reserve(a, g->hgather);
     std::vector<char> st(a.size, 0);
     put(st.data(), o.act, g->act); put(st.data(), o.actnode, g->actnode); put(st.data(), o.star_node, g->star_node); put(st.data(), o.star_sL, g->star_sL);
     put(st.data(), o.str_nodes, g->str_nodes); put(st.data(), o.str_L0, g->str_L0); put(st.data(), o.off_ptr, g->off_ptr); put(st.data(), o.off_rc, g->off_rc);
     put(st.data(), o.sh_ptr, g->sh_ptr); put(st.data(), o.sh_rec, g->sh_rec); put(st.data(), o.sh_cf, g->sh_cf); put(st.data(), o.tmask, g->tmask);
+    put(st.data(), o.hgather, g->hgather);
     if (hipMalloc((void**)&g->d_base, a.size) != hipSuccess) { err = "out of device memory (graph)"; return DSH_ERR_HIP; }
     g->d_bytes = a.size;
     if (hipMemcpy(g->d_base, st.data(), a.size, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g->d_base); err = "graph upload failed"; return DSH_ERR_HIP; }
@@ -477,11 +479,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   const size_t lds_budget = ((nw == 4 ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
   for (int b = 0; b < B; b++) {
     SftDev& hh = c->packed[b].h;
-    const dsh::SftGraph& g = *c->packed[b].g;
     hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);   // the barrier version of the factor steps exists in lab builds only
     size_t used = 0;
-    hh.asm_slots = 0;
-    if (hh.tile_mode == 1 && !c->opt.asm_direct && (size_t)nw * g.max_slots * (kTS * kTS) <= lds_budget) { hh.asm_slots = g.max_slots; used = (size_t)nw * g.max_slots * (kTS * kTS); }
     // placement class of the records (sft_kernels.hip: AsmRec): 1 = observation weights + curvature records, 2 = + node matrices + stretch records
     const size_t need1 = (((size_t)hh.M + 1) & ~(size_t)1) + 4 * (size_t)hh.S, need2 = need1 + 6 * (size_t)hh.nA + 4 * (size_t)hh.Es;
     hh.lds_class = (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
@@ -522,7 +521,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     r.mp = a.take(4 * 3 * (size_t)h.M) - c->res_off; r.outl = a.take((size_t)h.M) - c->res_off;
   }
   c->res_bytes = a.size - c->res_off;
-  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hb, Hbord, Hc, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; };
+  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hc, Hb, Hbord, Hcn, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; };
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
@@ -542,7 +541,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     // factorisation load every tile of its sliding window unconditionally (SFT_H_PAD_* in sft_problem.h)
     const size_t band_elems = h.tile_mode ? (Dnp / kTS + SFT_H_PAD_TILE_ROWS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;
     const size_t bord_elems = (SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER;
-    w.Hb = a.take(8 * band_elems); w.Hbord = a.take(8 * bord_elems); w.Hc = a.take(8 * 56);
+    w.Hc = a.take(h.tile_mode == 1 ? 8 * c->packed[b].g->hc_elems() : 0);
+    w.Hb = a.take(h.tile_mode == 1 ? 0 : 8 * band_elems); w.Hbord = a.take(8 * bord_elems); w.Hcn = a.take(8 * 56);
     w.Lb = a.take(8 * band_elems); w.Lbord = a.take(8 * bord_elems); w.Lc = a.take(8 * 56);
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.Lt = a.take(h.tile_mode == 2 ? 8 * band_elems : 0); w.LbT = a.take(h.tile_mode == 2 ? 8 * (Dnp / kTS) * (size_t)kTS * kTS : 0);
@@ -588,6 +588,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.star_sL = (const double*)(gb + g.o.star_sL); h.str_nodes = (const int32_t*)(gb + g.o.str_nodes); h.str_L0 = (const double*)(gb + g.o.str_L0);
     h.off_ptr = (const int32_t*)(gb + g.o.off_ptr); h.off_rc = (const int32_t*)(gb + g.o.off_rc); h.sh_ptr = (const int32_t*)(gb + g.o.sh_ptr);
     h.sh_rec = (const uint32_t*)(gb + g.o.sh_rec); h.sh_cf = (const double*)(gb + g.o.sh_cf); h.tmask = (const int32_t*)(gb + g.o.tmask);
+    h.hgather = (const uint32_t*)(gb + g.o.hgather);
     h.obs_nodes = (const int32_t*)(base + o.obs_nodes); h.obs_bary = (const double*)(base + o.obs_bary);
     h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w);
     h.ob_ptr = (const int32_t*)(base + o.ob_ptr); h.ob_m = (const int32_t*)(base + o.ob_m); h.ob_c = (const double*)(base + o.ob_c);
@@ -599,7 +600,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.xyz_bak = (double*)(base + w.bak);
     h.camrec = (double*)(base + w.camrec); h.wtv = (double*)(base + w.wtv); h.Anode = (double*)(base + w.Anode);
     h.Jstar = (double*)(base + w.Jstar); h.Jstr = (double*)(base + w.Jstr);
-    h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hc);
+    h.Hc = (double*)(base + w.Hc); h.Hb = (double*)(base + w.Hb); h.Hbord = (double*)(base + w.Hbord); h.Hcorner = (double*)(base + w.Hcn);
     h.Lb = (double*)(base + w.Lb); h.Lbord = (double*)(base + w.Lbord); h.Lcorner = (double*)(base + w.Lc); h.Linv = (double*)(base + w.Linv);
     h.Lt = (double*)(base + w.Lt); h.LbT = (double*)(base + w.LbT);
     h.x = (double*)(base + w.x); h.dbg = (double*)(base + w.dbg);
@@ -935,7 +936,6 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
-  else if (k == "asm_direct") c->opt.asm_direct = value != 0;
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;
 }
@@ -1029,14 +1029,29 @@ int dsh_lab_sft_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, do
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
   const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;
-  std::vector<double> Hb(band_elems), Hbord(SFT_BORDER * Dnp), Hc(56);
+  std::vector<double> Hb(h.tile_mode == 1 ? 0 : band_elems), Hbord(SFT_BORDER * Dnp), Hc(56);
   auto hidx = [&](int r, int cc) -> size_t {
     const size_t tb = ((size_t)(r >> 4) * h.tpr + ((r >> 4) - (cc >> 4))) * (kTS * kTS);
     if (h.tile_mode == 1) return tb + ((((r & 15) & 3) << 4) + (cc & 15)) * 4 + ((r & 15) >> 2);
     if (h.tile_mode == 2) return tb + ((((cc & 15) & 3) << 4) + (r & 15)) * 4 + ((cc & 15) >> 2);   // wide mode keeps the tiles transposed
     return (size_t)r * h.ldh + (cc - r + h.kd);
   };
-  HIPCHK(c, hipMemcpy(Hb.data(), h.Hb, 8 * Hb.size(), hipMemcpyDeviceToHost));
+  // tile mode 1: H is kept as compact 3x3 blocks; it is read here the way the factorisation reads it, through the gather lists
+  const dsh::SftGraph& g = *c->packed[b].g;
+  std::vector<double> Hcomp;
+  if (h.tile_mode == 1) {
+    Hcomp.resize(g.hc_elems());
+    HIPCHK(c, hipMemcpy(Hcomp.data(), h.Hc, 8 * Hcomp.size(), hipMemcpyDeviceToHost));
+  } else {
+    HIPCHK(c, hipMemcpy(Hb.data(), h.Hb, 8 * Hb.size(), hipMemcpyDeviceToHost));
+  }
+  auto hval = [&](int r, int cc) -> double {
+    if (h.tile_mode != 1) return Hb[hidx(r, cc)];
+    const int I = r >> 4, d = I - (cc >> 4);
+    if (d > kBT) return 0.0;
+    const int lane = (((r & 15) & 3) << 4) + (cc & 15), q = (r & 15) >> 2;
+    return Hcomp[g.hgather[(((size_t)I * (kBT + 1) + d) * 64 + lane) * 4 + q] / 8];
+  };
   HIPCHK(c, hipMemcpy(Hbord.data(), h.Hbord, 8 * Hbord.size(), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(Hc.data(), h.Hcorner, 8 * 49, hipMemcpyDeviceToHost));
   if (chi2) HIPCHK(c, hipMemcpy(chi2, h.dbg, 8, hipMemcpyDeviceToHost));
@@ -1047,7 +1062,7 @@ int dsh_lab_sft_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, do
       for (int k = 0; k <= h.kd; k++) {
         const int cidx = r - h.kd + k;
         if (cidx < 0) continue;
-        const double v = Hb[hidx(r, cidx)];
+        const double v = hval(r, cidx);
         H[(size_t)(6 + r) + (size_t)(6 + cidx) * D] = v;
         H[(size_t)(6 + cidx) + (size_t)(6 + r) * D] = v;
       }

@@ -87,6 +87,12 @@ __device__ __forceinline__ size_t h_index(const PT& P, int r, int c) {
   if (P.tile_mode == 2) return ((size_t)(r >> 4) * P.tpr + ((r >> 4) - (c >> 4))) * (TS * TS) + tile_elem(c & 15, r & 15);   // wide mode: tiles hold H(I,J)^T
   return (size_t)r * P.ldh + (c - r + P.kd);
 }
+// diagonal element r of H (tile mode 1: from the compact 3x3 blocks)
+template <class PT>
+__device__ __forceinline__ double h_diag(const PT& P, int r) {
+  if (P.tile_mode == 1) { const int a = r / 3, e = r - 3 * a; return P.Hc[9 * (size_t)(a + P.off_ptr[a]) + 4 * e]; }
+  return P.Hb[h_index(P, r, r)];
+}
 
 struct Ctl {       // LDS-resident control block, written by thread 0
   double R[9], t[3];
@@ -236,7 +242,6 @@ __device__ __forceinline__ lds_double* to_lds(double* p) { return (lds_double*)p
 //              depth (sft_types.h:176-205), so J_node(m, s) = b_ms A_node -- the Jacobian of an observation with respect to a node
 //              depends on the observation only through its barycentric coordinate.  H_ij(obs) = (sum_m wt_m b_mi b_mj) A_i^T A_j.
 //   star[4 s]  unit vector u and residual r of curvature star s;  str[4 e]  gradient g and residual of stretch edge e
-//   tiles      tile mode 1: one tile row of H per wavefront (P.asm_slots tiles of 2 KB), flushed to HBM as whole tiles
 // Placement class of the records (P.lds_class, chosen by the host packer from the LDS budget of the launch shape):
 //   0: everything in the workspace (global memory)   1: observation weights + curvature records in LDS
 //   2: all four arrays in LDS
@@ -247,7 +252,7 @@ using gdouble = SFT_G double;
 template <int CLS>
 struct AsmRec {
   static constexpr bool WT_L = CLS >= 1, STAR_L = CLS >= 1, A_L = CLS >= 2, STR_L = CLS >= 2;
-  lds_double *wt_l, *A_l, *star_l, *str_l, *tiles;
+  lds_double *wt_l, *A_l, *star_l, *str_l;
   gdouble *wt_g, *A_g, *star_g, *str_g;
   __device__ __forceinline__ double wt(int m) const { if constexpr (WT_L) return wt_l[m]; else return wt_g[m]; }
   __device__ __forceinline__ void set_wt(int m, double v) const { if constexpr (WT_L) wt_l[m] = v; else wt_g[m] = v; }
@@ -279,8 +284,7 @@ template <int NW, int CLS>
 __device__ __forceinline__ AsmRec<CLS> asm_records(const SftDev& P, double* lds) {
   AsmRec<CLS> r;
   lds_double* base = to_lds(lds);
-  size_t off = (size_t)NW * P.asm_slots * (TS * TS);
-  r.tiles = base;
+  size_t off = 0;
   r.wt_l = base + off; if (AsmRec<CLS>::WT_L) off += (size_t)(P.M + 1) & ~(size_t)1;
   r.star_l = base + off; if (AsmRec<CLS>::STAR_L) off += 4 * (size_t)P.S;
   r.A_l = base + off; if (AsmRec<CLS>::A_L) off += 6 * (size_t)P.nA;
@@ -446,12 +450,12 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
   // The pointers and scalars the gathers use, read once: wave-uniform values stay in scalar registers instead of being re-read
   // from the problem record (a scalar load + a wait that also drains the LDS counter) inside the loops.
   struct {
-    int Dn, nA, M, tile_mode, tpr, kd, ldh, asm_slots;
+    int Dn, nA, M, tile_mode, tpr, kd, ldh;
     double w_ref, w_curv, w_str;
     decltype(P_.camrec) camrec; decltype(P_.ob_ptr) ob_ptr, sh_ptr, ob_m, off_ptr, off_rc, tmask, actnode; decltype(P_.ob_c) ob_c, sh_cf, xyz0;
-    decltype(P_.sh_rec) sh_rec; decltype(P_.viewed) viewed; decltype(P_.Hb) Hb, Hbord, Hcorner, xyz, dbg;
-  } P{P_.Dn, P_.nA, P_.M, P_.tile_mode, P_.tpr, P_.kd, P_.ldh, P_.asm_slots, P_.w_ref, P_.w_curv, P_.w_str, P_.camrec, P_.ob_ptr, P_.sh_ptr, P_.ob_m, P_.off_ptr,
-      P_.off_rc, P_.tmask, P_.actnode, P_.ob_c, P_.sh_cf, P_.xyz0, P_.sh_rec, P_.viewed, P_.Hb, P_.Hbord, P_.Hcorner, P_.xyz, P_.dbg};
+    decltype(P_.sh_rec) sh_rec; decltype(P_.viewed) viewed; decltype(P_.Hb) Hb, Hc, Hbord, Hcorner, xyz, dbg;
+  } P{P_.Dn, P_.nA, P_.M, P_.tile_mode, P_.tpr, P_.kd, P_.ldh, P_.w_ref, P_.w_curv, P_.w_str, P_.camrec, P_.ob_ptr, P_.sh_ptr, P_.ob_m, P_.off_ptr,
+      P_.off_rc, P_.tmask, P_.actnode, P_.ob_c, P_.sh_cf, P_.xyz0, P_.sh_rec, P_.viewed, P_.Hb, P_.Hc, P_.Hbord, P_.Hcorner, P_.xyz, P_.dbg};
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -485,27 +489,27 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
     __syncthreads();
   }
   AS_ADD(32);
-  const bool staged = P.tile_mode == 1 && P.asm_slots > 0;
-  const int slots = P.asm_slots;
-  lds_double* mytiles = ar.tiles + (size_t)wave * slots * (TS * TS);
-  const int ngroups = staged ? (P.Dn + TS - 1) / TS : (P.nA + 4) / 5;
+  // Tile mode 1 keeps H as compact 3x3 blocks (P.Hc; the factorisation gathers its tiles from them): a lane that finishes a
+  // block stores its nine doubles, nothing is padded to tiles.  The other modes store into their band / tile layout element by element.
+  const bool compact = P.tile_mode == 1;
+  constexpr int GN = 7;                      // block rows (nodes) per round of a wavefront: 8 lanes each for the diagonal blocks
+  const int ngroups = (P.nA + GN - 1) / GN;
   const auto Hg = P.Hb;
-  if (staged)
-    for (int i = lane; i < slots * (TS * TS) / 2; i += 64) reinterpret_cast<__attribute__((address_space(3))) v2d*>(mytiles)[i] = (v2d){0.0, 0.0};
+  const auto Hc = P.Hc;
   // node range of group I and the headers of a lane's first off-diagonal block: fetched one group ahead
   auto group_nodes = [&](int I, int& a_lo, int& a_hi) {
-    a_lo = staged ? (TS * I) / 3 : 5 * I;
-    a_hi = min(staged ? (TS * I + TS - 1) / 3 : 5 * I + 4, P.nA - 1);
+    a_lo = GN * I;
+    a_hi = min(GN * I + GN - 1, P.nA - 1);
   };
-  struct Hdr { int q, qe, bi, bj, ob0, ob1, sh0, sh1, dob0, dob1, dsh0, dsh1; };
+  struct Hdr { int q, qe, bi, bj, ob0, ob1, sh0, sh1, dob0, dob1, dsh0, dsh1, doff; };
   auto load_hdr = [&](int I) -> Hdr {
-    Hdr h{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Hdr h{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (I >= ngroups) return h;
     int a_lo, a_hi;
     group_nodes(I, a_lo, a_hi);
     {   // list bounds of the lane's diagonal block
       const int a = a_lo + (lane >> 3);
-      if ((lane >> 3) < 7 && a <= a_hi) { h.dob0 = P.ob_ptr[a]; h.dob1 = P.ob_ptr[a + 1]; h.dsh0 = P.sh_ptr[a]; h.dsh1 = P.sh_ptr[a + 1]; }
+      if ((lane >> 3) < GN && a <= a_hi) { h.dob0 = P.ob_ptr[a]; h.dob1 = P.ob_ptr[a + 1]; h.dsh0 = P.sh_ptr[a]; h.dsh1 = P.sh_ptr[a + 1]; h.doff = P.off_ptr[a]; }
     }
     const int qb = P.off_ptr[a_lo];
     h.qe = P.off_ptr[a_hi + 1];
@@ -521,34 +525,24 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
 
 #pragma unroll 1
   for (int I = wave; I < ngroups; I += NW) {
-    const int row_lo = staged ? TS * I : 0, row_hi = staged ? TS * I + TS - 1 : 0x7fffffff;
     int a_lo, a_hi;
     group_nodes(I, a_lo, a_hi);
-    const int mask = staged ? P.tmask[I] : 0;
     Hdr cur = nxt;
     nxt = load_hdr(I + NW);
-    // element (r, c), c <= r, of H (and its mirror inside a diagonal tile, which is stored symmetric)
+    // element (r, c), c <= r, of H in the band / wide-tile layouts (and its mirror inside a diagonal tile, which is stored symmetric)
     auto put = [&](int r, int c, double v) {
-      if (staged) {
-        if (r < row_lo || r > row_hi) return;
-        const int d = I - (c >> 4);
-        lds_double* tl = mytiles + __builtin_popcount(mask & ((1 << d) - 1)) * (TS * TS);
-        tl[tile_elem(r & 15, c & 15)] = v;
-        if (d == 0 && c < r) tl[tile_elem(c & 15, r & 15)] = v;
-      } else {
-        const size_t idx = h_index(P, r, c);
-        Hg[idx] = v;
-        if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) {
-          const int e1 = tile_elem(r & 15, c & 15), e2 = tile_elem(c & 15, r & 15);
-          Hg[idx + (P.tile_mode == 2 ? e1 - e2 : e2 - e1)] = v;
-        }
+      const size_t idx = h_index(P, r, c);
+      Hg[idx] = v;
+      if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) {
+        const int e1 = tile_elem(r & 15, c & 15), e2 = tile_elem(c & 15, r & 15);
+        Hg[idx + (P.tile_mode == 2 ? e1 - e2 : e2 - e1)] = v;
       }
     };
     // ---- diagonal blocks: 8 lanes per node, contributions dealt round-robin, partial sums combined by a fixed xor butterfly.
     // Every level of the gather (list entries -> records) is issued for up to DCH contributions at once.
     {
       const int sub = lane & 7, a = a_lo + (lane >> 3);
-      const bool on = (lane >> 3) < 7 && a <= a_hi;
+      const bool on = (lane >> 3) < GN && a <= a_hi;
       double sii = 0.0, G0[5], G1[5], g0 = 0.0, g1 = 0.0, Hs[6], bn[3];
 #pragma unroll
       for (int k = 0; k < 5; k++) { G0[k] = 0.0; G1[k] = 0.0; }
@@ -634,13 +628,17 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       if (on && sub == 0) {
         const double wr = vw ? P.w_ref : 0.0;
         // lower triangle of the 3x3 block: observations (s_ii A^T A), curvature + stretching, reference edge (J = I)
-        put(3 * a, 3 * a, (sii * (A[0] * A[0] + A[3] * A[3]) + Hs[0]) + wr);
-        put(3 * a + 1, 3 * a, sii * (A[1] * A[0] + A[4] * A[3]) + Hs[1]);
-        put(3 * a + 1, 3 * a + 1, (sii * (A[1] * A[1] + A[4] * A[4]) + Hs[2]) + wr);
-        put(3 * a + 2, 3 * a, sii * (A[2] * A[0] + A[5] * A[3]) + Hs[3]);
-        put(3 * a + 2, 3 * a + 1, sii * (A[2] * A[1] + A[5] * A[4]) + Hs[4]);
-        put(3 * a + 2, 3 * a + 2, (sii * (A[2] * A[2] + A[5] * A[5]) + Hs[5]) + wr);
-        if (3 * a >= row_lo) {   // camera x node block and b of the node: once (with the tile row that holds the node's first row)
+        const double h00 = (sii * (A[0] * A[0] + A[3] * A[3]) + Hs[0]) + wr, h10 = sii * (A[1] * A[0] + A[4] * A[3]) + Hs[1];
+        const double h11 = (sii * (A[1] * A[1] + A[4] * A[4]) + Hs[2]) + wr, h20 = sii * (A[2] * A[0] + A[5] * A[3]) + Hs[3];
+        const double h21 = sii * (A[2] * A[1] + A[5] * A[4]) + Hs[4], h22 = (sii * (A[2] * A[2] + A[5] * A[5]) + Hs[5]) + wr;
+        if (compact) {
+          const auto dst = Hc + 9 * (size_t)(a + cur.doff);
+          dst[0] = h00; dst[1] = h10; dst[2] = h20; dst[3] = h10; dst[4] = h11; dst[5] = h21; dst[6] = h20; dst[7] = h21; dst[8] = h22;
+        } else {
+          put(3 * a, 3 * a, h00); put(3 * a + 1, 3 * a, h10); put(3 * a + 1, 3 * a + 1, h11);
+          put(3 * a + 2, 3 * a, h20); put(3 * a + 2, 3 * a + 1, h21); put(3 * a + 2, 3 * a + 2, h22);
+        }
+        {   // camera x node block and b of the node
           const double G0f[6] = {G0[0], G0[1], G0[2], G0[3], 0.0, G0[4]};
           const double G1f[6] = {G1[0], G1[1], G1[2], 0.0, G1[3], G1[4]};
 #pragma unroll
@@ -718,42 +716,22 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
           add_shared(rcv, P.sh_cf[2 * p], r1);
         }
       }
+      if (compact) {
+        const auto dst = Hc + 9 * (size_t)(bi + 1 + q);
 #pragma unroll
-      for (int a = 0; a < 3; a++)
+        for (int e = 0; e < 9; e++) dst[e] = H[e];
+      } else {
 #pragma unroll
-        for (int b = 0; b < 3; b++) put(3 * bi + a, 3 * bj + b, H[3 * a + b]);
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) put(3 * bi + a, 3 * bj + b, H[3 * a + b]);
+      }
     }
     AS_ADD(35);
-    // ---- the wavefront's tile row leaves as whole tiles (accumulator order, 32 bytes per lane); the LDS copy is cleared
-    if (staged) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wavefront's own LDS stores have landed (no other wave touches these tiles)
-      const int crow = lane >> 4, ccol = lane & 15;
-      using lds_v4d = __attribute__((address_space(3))) v4d;
-      lds_v4d* tl = reinterpret_cast<lds_v4d*>(mytiles + 4 * lane);
-      v4d x[BT + 1];
-#pragma unroll
-      for (int sl = 0; sl <= BT; sl++)
-        if (sl < slots) x[sl] = tl[sl * (TS * TS / 4)];
-      int dd[BT + 1];   // tile distance of slot sl: the sl-th set bit of the mask
-      {
-        int mm = mask;
-#pragma unroll
-        for (int sl = 0; sl <= BT; sl++) { dd[sl] = mm ? __builtin_ctz(mm) : -1; mm &= mm - 1; }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++)   // identity padding behind the last unknown (rows >= Dn of the last diagonal tile; slot 0 is d = 0)
-        if (crow + 4 * q == ccol && TS * I + ccol >= P.Dn) x[0][q] = 1.0;
-#pragma unroll
-      for (int sl = 0; sl <= BT; sl++)
-        if (sl < slots && dd[sl] >= 0) {
-          // streaming store: 1.1 MB of tiles per problem and pass must not evict the records and gather lists the other wavefronts
-          // (and the problem sharing the CU) are reading through the same L2
-          __builtin_nontemporal_store(x[sl], reinterpret_cast<SFT_G v4d*>(Hg + tile_off(I, dd[sl]) + 4 * lane));
-          tl[sl * (TS * TS / 4)] = (v4d){0.0, 0.0, 0.0, 0.0};
-        }
-    }
     AS_ADD(36);
+#if defined(SFT_PHASE_TIMERS) && defined(DSH_LAB)
     if (threadIdx.x == 0) P.dbg[37] += 1.0;
+#endif
   }
   __syncthreads();
 }
@@ -1041,7 +1019,6 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   lds_double* Cn = Abord + SFT_BORDER * TS;      // 7 x 7 corner (written once at the end)
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;   // accumulator layout: rows crow + 4q, column ccol
-  const auto Hg = uni(P.Hb);
   const auto Hbord = uni(P.Hbord);
   const auto Lg = uni(P.Lb);
   const auto Lbord = uni(P.Lbord);
@@ -1057,15 +1034,26 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   v4d bacc[RPW];                        // border tiles of ring columns (wave + NW*t + BOFF) mod BT: never on the wave that factors that column
   constexpr int BOFF = 2;
 
-  // Raw tile (I, I-d) of H in accumulator layout.  The storage is zero-padded (SFT_H_PAD_*), so every tile the sliding
-  // window can ask for exists: loads are unconditional and nothing touches the loaded registers before the MFMAs do.
-  // Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) are read from the first padding tile row --
-  // one shared 2 KB zero tile that stays in cache -- instead of from their own place in HBM; the load itself stays
-  // unconditional (exact wait counts).  mrow: the mask word of tile row I (P.tmask).
+  // Raw tile (I, I-d) of H in accumulator layout, gathered from the compact 3x3 blocks through the graph's element list: loads
+  // are unconditional (exact wait counts).  Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) take the
+  // all-zero list row, which stays in cache.  mrow: the mask word of tile row I (P.tmask).
   const auto tmask = uni(P.tmask);
-  const size_t zero_tile = tile_off(nT, 0);
-  auto fresh_tile = [&](int I, int d, int mrow) -> v4d {
-    return *reinterpret_cast<const v4d*>(Hg + (((mrow >> d) & 1) ? tile_off(I, d) : zero_tile) + 4 * lane);
+  const auto hgl = uni(P.hgather);
+  const auto Hc = uni(P.Hc);
+  // two phases so that no wait sits between the tiles of a row: first the byte offsets of every tile (16 bytes per lane; the all-zero
+  // list row nT, which stays in cache, for structurally zero tiles), then the elements of the tiles the mask has (wave-uniform branch)
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  auto fresh_idx = [&](int I, int d, int mrow) -> v4u_t {
+    return *reinterpret_cast<const SFT_G v4u_t*>(hgl + (((size_t)(((mrow >> d) & 1) ? I : nT) * (BT + 1) + d) * 64 + lane) * 4);
+  };
+  auto fresh_data = [&](const v4u_t& ix, int d, int mrow) -> v4d {
+    v4d v = {0.0, 0.0, 0.0, 0.0};
+    if ((mrow >> d) & 1) {
+      const auto Hb8 = reinterpret_cast<const SFT_G char*>(Hc);
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const SFT_G double*>(Hb8 + ix[q]);
+    }
+    return v;
   };
   // border block of tile column J: rows crow, crow+4 of the 8-row border (row 7 is zero), accumulator layout
   auto fresh_border = [&](int J) -> v4d {
@@ -1078,8 +1066,11 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
   for (int t = 0; t < RPW; t++) {       // rows 0..BT-1
     const int I = wave + NW * t;
     const int m0 = uni(tmask[I]);
+    { v4u_t ix[BT];
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1), m0);
+      for (int b = 0; b < BT; b++) ix[b] = fresh_idx(I, (I - b) & (BT - 1), m0);
+#pragma unroll
+      for (int b = 0; b < BT; b++) acc[t][b] = fresh_data(ix[b], (I - b) & (BT - 1), m0); }
     bacc[t] = fresh_border((I + BOFF) & (BT - 1));
   }
   v4d cacc = {0.0, 0.0, 0.0, 0.0};      // wave 0: corner
@@ -1116,10 +1107,10 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
           const int I = k + BT;
           const int mI = uni(tmask[I]);
 #pragma unroll
-          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(I, (I - b) & (BT - 1), mI);
+          for (int b = 0; b < BT; b++) acc[t][b] = fresh_data(fresh_idx(I, (I - b) & (BT - 1), mI), (I - b) & (BT - 1), mI);
         }
       }
-    if (memwave) fr8 = fresh_tile(kc + BT, BT, uni(tmask[kc + BT]));
+    if (memwave) fr8 = fresh_data(fresh_idx(kc + BT, BT, uni(tmask[kc + BT])), BT, uni(tmask[kc + BT]));
     if (k >= 0) {
 #pragma unroll
       for (int t = 0; t < RPW; t++)   // the holder of ring column k mod BT (consumed by now) fetches the border block of column k+BT
@@ -1445,7 +1436,6 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
   lds_int* wflag = F, *bflag = F + 1, *dflag = F + 24;
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;
-  const auto Hg = uni(P.Hb);
   const auto Hbord = uni(P.Hbord);
   const auto Lg = uni(P.Lb);
   const auto Lbord = uni(P.Lbord);
@@ -1461,13 +1451,25 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #define WT_BEGIN() do {} while (0)
 #define WT_END(e) do {} while (0)
 #endif
-  // Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) are read from the first padding tile row --
-  // one shared 2 KB zero tile that stays in cache -- instead of from their own place in HBM; the load itself stays
-  // unconditional (exact wait counts).  mrow: the mask word of tile row I (P.tmask).
+  // Tiles of H are gathered from the compact 3x3 blocks (unconditional loads, exact wait counts); structurally zero tiles (30 % of
+  // the C2 band) take the all-zero list row, which stays in cache.  mrow: the mask word of tile row I (P.tmask).
   const auto tmask = uni(P.tmask);
-  const size_t zero_tile = tile_off(nT, 0);
-  auto fresh_tile = [&](int I, int d, int mrow) -> v4d {
-    return *reinterpret_cast<const v4d*>(Hg + (((mrow >> d) & 1) ? tile_off(I, d) : zero_tile) + 4 * lane);
+  const auto hgl = uni(P.hgather);
+  const auto Hc = uni(P.Hc);
+  // two phases so that no wait sits between the tiles of a row: first the byte offsets of every tile (16 bytes per lane; the all-zero
+  // list row nT, which stays in cache, for structurally zero tiles), then the elements of the tiles the mask has (wave-uniform branch)
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  auto fresh_idx = [&](int I, int d, int mrow) -> v4u_t {
+    return *reinterpret_cast<const SFT_G v4u_t*>(hgl + (((size_t)(((mrow >> d) & 1) ? I : nT) * (BT + 1) + d) * 64 + lane) * 4);
+  };
+  auto fresh_data = [&](const v4u_t& ix, int d, int mrow) -> v4d {
+    v4d v = {0.0, 0.0, 0.0, 0.0};
+    if ((mrow >> d) & 1) {
+      const auto Hb8 = reinterpret_cast<const SFT_G char*>(Hc);
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const SFT_G double*>(Hb8 + ix[q]);
+    }
+    return v;
   };
   auto fresh_border = [&](int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
@@ -1477,7 +1479,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
   };
   const int m0 = uni(tmask[wave]);
 #pragma unroll
-  for (int b = 0; b < BT; b++) acc[b] = fresh_tile(wave, (wave - b) & (BT - 1), m0);
+  for (int b = 0; b < BT; b++) acc[b] = fresh_data(fresh_idx(wave, (wave - b) & (BT - 1), m0), (wave - b) & (BT - 1), m0);
   bacc = fresh_border((wave + BOFF) & (BT - 1));
   v4d cacc = {0.0, 0.0, 0.0, 0.0};
   if (wave == 0) {
@@ -1504,9 +1506,13 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
     if (k >= 0) {
       if (memwave) {                                 // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
         const int mk = uni(tmask[k + BT]);
+        v4u_t ix[BT + 1];
+        ix[BT] = fresh_idx(k + BT, BT, mk);
 #pragma unroll
-        for (int b = 0; b < BT; b++) acc[b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1), mk);
-        araw = fresh_tile(k + BT, BT, mk);
+        for (int b = 0; b < BT; b++) ix[b] = fresh_idx(k + BT, (k + BT - b) & (BT - 1), mk);
+        araw = fresh_data(ix[BT], BT, mk);           // first: the TRSM of this step waits for it
+#pragma unroll
+        for (int b = 0; b < BT; b++) acc[b] = fresh_data(ix[b], (k + BT - b) & (BT - 1), mk);
       }
       if (((wave + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc = fresh_border(k + BT);
       // nobody may still be reading the buffers of step k-2 (same parity)
@@ -1735,7 +1741,6 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   lds_int* wflag = F, *bflag = F + 1, *dflag = F + 24;
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;
-  const auto Hg = uni(P.Hb);
   const auto Hbord = uni(P.Hbord);
   const auto Lg = uni(P.Lb);
   const auto Lbord = uni(P.Lbord);
@@ -1751,13 +1756,25 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
 #define WT_BEGIN() do {} while (0)
 #define WT_END(e) do {} while (0)
 #endif
-  // Structurally zero tiles (no 3x3 block touches them: 30 % of the C2 band) are read from the first padding tile row --
-  // one shared 2 KB zero tile that stays in cache -- instead of from their own place in HBM; the load itself stays
-  // unconditional (exact wait counts).  mrow: the mask word of tile row I (P.tmask).
+  // Tiles of H are gathered from the compact 3x3 blocks (unconditional loads, exact wait counts); structurally zero tiles (30 % of
+  // the C2 band) take the all-zero list row, which stays in cache.  mrow: the mask word of tile row I (P.tmask).
   const auto tmask = uni(P.tmask);
-  const size_t zero_tile = tile_off(nT, 0);
-  auto fresh_tile = [&](int I, int d, int mrow) -> v4d {
-    return *reinterpret_cast<const v4d*>(Hg + (((mrow >> d) & 1) ? tile_off(I, d) : zero_tile) + 4 * lane);
+  const auto hgl = uni(P.hgather);
+  const auto Hc = uni(P.Hc);
+  // two phases so that no wait sits between the tiles of a row: first the byte offsets of every tile (16 bytes per lane; the all-zero
+  // list row nT, which stays in cache, for structurally zero tiles), then the elements of the tiles the mask has (wave-uniform branch)
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  auto fresh_idx = [&](int I, int d, int mrow) -> v4u_t {
+    return *reinterpret_cast<const SFT_G v4u_t*>(hgl + (((size_t)(((mrow >> d) & 1) ? I : nT) * (BT + 1) + d) * 64 + lane) * 4);
+  };
+  auto fresh_data = [&](const v4u_t& ix, int d, int mrow) -> v4d {
+    v4d v = {0.0, 0.0, 0.0, 0.0};
+    if ((mrow >> d) & 1) {
+      const auto Hb8 = reinterpret_cast<const SFT_G char*>(Hc);
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const SFT_G double*>(Hb8 + ix[q]);
+    }
+    return v;
   };
   auto fresh_border = [&](int J) -> v4d {
     v4d v = {0.0, 0.0, 0.0, 0.0};
@@ -1769,7 +1786,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   for (int t = 0; t < RPW; t++) {
     const int a = wave + NW * t;
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(a, (a - b) & (BT - 1), uni(tmask[a]));
+    for (int b = 0; b < BT; b++) acc[t][b] = fresh_data(fresh_idx(a, (a - b) & (BT - 1), uni(tmask[a])), (a - b) & (BT - 1), uni(tmask[a]));
     bacc[t] = fresh_border((a + BOFF) & (BT - 1));
   }
   v4d cacc = {0.0, 0.0, 0.0, 0.0};
@@ -1803,9 +1820,13 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
         if (wave + NW * t == (k & (BT - 1))) {        // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
           const int mk = uni(tmask[k + BT]);
           memwave = true;
+          v4u_t ix[BT + 1];
+          ix[BT] = fresh_idx(k + BT, BT, mk);
 #pragma unroll
-          for (int b = 0; b < BT; b++) acc[t][b] = fresh_tile(k + BT, (k + BT - b) & (BT - 1), mk);
-          araw = fresh_tile(k + BT, BT, mk);
+          for (int b = 0; b < BT; b++) ix[b] = fresh_idx(k + BT, (k + BT - b) & (BT - 1), mk);
+          araw = fresh_data(ix[BT], BT, mk);          // first: the TRSM of this step waits for it
+#pragma unroll
+          for (int b = 0; b < BT; b++) acc[t][b] = fresh_data(ix[b], (k + BT - b) & (BT - 1), mk);
         }
         if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
       }
@@ -2236,18 +2257,20 @@ __device__ __forceinline__ void init_state(const SftDev& P) {
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
   for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_init[i];
   if (tid < 7) P.pose[tid] = P.pose_init[tid];
-  if (P.tile_mode) {
-    // zero tiles + identity padding; tile mode 1 keeps the compile-time tile-row length (no integer divisions by a runtime value)
-    auto zero_tiles = [&](const int tpr) {
-      const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
-      for (size_t i = tid; i < nel; i += NT) {
-        const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % tpr), I = (int)(i / ((size_t)tpr * TS * TS));
-        const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
-        const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn && I < Dnp / TS;
-        P.Hb[i] = pad_diag ? 1.0 : 0.0;
-      }
-    };
-    if (P.tile_mode == 1) zero_tiles(BT + 1); else zero_tiles(P.tpr);
+  if (P.tile_mode == 1) {
+    // compact blocks: the assembly rewrites every block of every linearisation; behind them the 0.0 and the 1.0 the gather lists point
+    // structurally empty elements and the identity padding at
+    if (tid == 0) { const size_t z = 9 * (size_t)(P.nA + P.noff); P.Hc[z] = 0.0; P.Hc[z + 1] = 1.0; }
+  } else if (P.tile_mode) {
+    // zero tiles + identity padding
+    const int tpr = P.tpr;
+    const size_t nel = (size_t)(Dnp / TS + SFT_H_PAD_TILE_ROWS) * tpr * TS * TS;   // incl. the zero tile rows below the matrix
+    for (size_t i = tid; i < nel; i += NT) {
+      const int e = (int)(i % (TS * TS)), td = (int)((i / (TS * TS)) % tpr), I = (int)(i / ((size_t)tpr * TS * TS));
+      const int el = e >> 2, erow = (el >> 4) + 4 * (e & 3), ecol = el & 15;   // native tile order: lane, register
+      const bool pad_diag = td == 0 && erow == ecol && TS * I + ecol >= Dn && I < Dnp / TS;
+      P.Hb[i] = pad_diag ? 1.0 : 0.0;
+    }
   } else {
     for (size_t i = tid; i < (size_t)Dnp * ldh; i += NT) {
       const int k = (int)(i % ldh), r = (int)(i / ldh);
@@ -2360,7 +2383,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
     PH_ADD(2);
     if (it == 0) {
       double mx = 0.0;
-      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
+      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
       if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
       mx = block_max(mx, red);
       if (tid == 0) { ctl->lambda = 1e-5 * mx; ctl->ni = 2.0; ctl->nbad = 0; }
@@ -2541,7 +2564,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
     if (S.it == 0) {
       double mx = 0.0;
-      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
+      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
       if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
       mx = block_max(mx, red);
       if (tid == 0) { S.lambda = 1e-5 * mx; S.ni = 2.0; S.nbad = 0; }
@@ -2609,7 +2632,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_sc_kernel(const
     }
     const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
     double mx = 0.0;
-    for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(P.Hb[h_index(P, r, r)]));
+    for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
     mx = block_max(mx, red);
     if (tid == 0) {
       // send: robust chi2, diagonal of the local H_cc, local b_c, the largest node diagonal in this rank's slot (a sum over

@@ -209,6 +209,34 @@ int build_graph(const TemplateHost& t, const std::vector<uint8_t>& opt, SftGraph
     for (int q = 0; q < noff; q++) mark(g.off_rc[2 * q], g.off_rc[2 * q + 1]);
     g.max_slots = 0;
     for (int I = 0; I < nT_; I++) g.max_slots = std::max(g.max_slots, __builtin_popcount((unsigned)g.tmask[I]));
+    g.hgather.clear();
+    if (g.kd <= kTS * 8) {   // register-window solver: the gather lists of its tiles (sft_pack.h)
+      if (9 * (size_t)(nA + noff) + 2 >= (1u << 28)) { err = "template too large for the 32-bit gather offsets"; return DSH_ERR_ARG; }
+      const uint32_t ZERO = (uint32_t)(8 * 9 * (size_t)(nA + noff)), ONE = ZERO + 8;   // byte offsets into Hc
+      g.hgather.assign((size_t)(nT_ + 1) * 9 * 256, ZERO);
+      auto elem = [&](int r, int c) -> uint32_t {   // element (r, c) of the symmetric matrix, r, c < Dn_
+        int bi = r / 3, bj = c / 3, er = r % 3, ec = c % 3;
+        if (bj > bi) { std::swap(bi, bj); std::swap(er, ec); }
+        if (bi == bj) return (uint32_t)(8 * (9 * (size_t)(bi + g.off_ptr[bi]) + 3 * er + ec));
+        int lo = g.off_ptr[bi], hi = g.off_ptr[bi + 1] - 1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1, cm = g.off_rc[2 * mid + 1];
+          if (cm == bj) return (uint32_t)(8 * (9 * (size_t)(bi + 1 + mid) + 3 * er + ec));
+          if (cm < bj) lo = mid + 1; else hi = mid - 1;
+        }
+        return ZERO;
+      };
+      for (int I = 0; I < nT_; I++)
+        for (int d = 0; d <= 8 && d <= I; d++) {
+          if (!((g.tmask[I] >> d) & 1)) continue;
+          uint32_t* tl = g.hgather.data() + ((size_t)I * 9 + d) * 256;
+          for (int l = 0; l < 64; l++)
+            for (int q = 0; q < 4; q++) {
+              const int r = kTS * I + (l >> 4) + 4 * q, c = kTS * (I - d) + (l & 15);
+              tl[4 * l + q] = (r >= Dn_ || c >= Dn_) ? (r == c ? ONE : ZERO) : elem(r, c);
+            }
+        }
+    }
   }
   uint64_t h = 1469598103934665603ull;
   for (uint8_t b : opt) { h ^= b; h *= 1099511628211ull; }

@@ -37,11 +37,18 @@ struct SftGraph {
   std::vector<double> sh_cf;         // 2 per contribution: H factor and b factor WITHOUT the regulariser weight
                                      //   curvature: sL * c_s * c_t, sL * c_s ; stretch: +-1, +-1
   std::vector<int32_t> tmask;        // tile mode 1: bit d of entry I = tile (I, I-d) holds an element of some block
+  // tile mode 1 (kd <= 128): H lives in HBM as compact 3x3 blocks, Hc[9 * hpos(block) + 3 * row + col] (row-major, diagonal blocks
+  // full), block rows interleaved: hpos(diagonal a) = a + off_ptr[a], hpos(off-diagonal q of block row a) = a + 1 + q; behind the
+  // blocks one 0.0 and one 1.0.  hgather: for every 16x16 tile (I, I-d), d = 0..8, I = 0..nT (row nT: all zero), the BYTE offset into Hc
+  // each (lane, register) of the MFMA accumulator layout takes -- 256 entries, entry 4 * lane + q = element (row (lane >> 4) + 4 q,
+  // column lane & 15); the factorisation gathers its tiles through it, the padded tile form never exists in memory.
+  std::vector<uint32_t> hgather;
+  size_t hc_elems() const { return 9 * (size_t)(nA + noff) + 2; }
   int nblk() const { return nA + noff; }
   // device copy (owned by the context)
   char* d_base = nullptr;
   size_t d_bytes = 0;
-  struct { size_t act, actnode, star_node, star_sL, str_nodes, str_L0, off_ptr, off_rc, sh_ptr, sh_rec, sh_cf, tmask; } o{};
+  struct { size_t act, actnode, star_node, star_sL, str_nodes, str_L0, off_ptr, off_rc, sh_ptr, sh_rec, sh_cf, tmask, hgather; } o{};
 };
 
 // Node degree limit of the device kernels (slot fields of SFT_REC are 4 bits: centre + 14 neighbours).

@@ -76,8 +76,7 @@ struct SftDev {
   int32_t n, nA, Dn, kd, ldh, M, V, S, Es, noff, max_iters, mode;
   int32_t tile_mode;          // 1: 16x16-tile band storage + register-window MFMA factorisation (kd <= 128); 2: wide tile band, left-looking
                               // MFMA factorisation (kd <= 256, sft_wide.h); 0: row-major band (general)
-  int32_t asm_slots;          // tile mode 1: LDS tiles per tile row of the assembly's staging buffer (= most structurally non-zero tiles of
-                              // a tile row); 0: the assembly stores its 3x3 blocks straight to global memory
+  int32_t pad1;
   int32_t lds_class;          // assembly records kept in LDS instead of the workspace: 0 none, 1 observation weights + curvature records, 2 also node matrices + stretch records
   int32_t tpr, wbt;           // tile modes: pitch of a tile row of the band storage in tiles (wbt + 1), sub-diagonal tiles per block
                               // column (mode 1: 8; mode 2: ceil(kd/16); an even pitch, i.e. an odd tile distance between (I,K) and
@@ -105,8 +104,8 @@ struct SftDev {
   const SFT_G int32_t* sh_ptr;    // nblk+1: curvature / stretch contributions of block q
   const SFT_G uint32_t* sh_rec;   // SFT_REC
   const SFT_G double* sh_cf;      // 2 per contribution: H and b factors without the regulariser weight
-  const SFT_G int32_t* tmask;     // tile mode 1: per tile row I (nT + SFT_H_PAD_TILE_ROWS entries) bit d set if tile (I, I-d) holds any element of H;
-                                  // the factorisation reads the other (structurally zero) tiles from one shared zero tile instead of HBM
+  const SFT_G int32_t* tmask;     // tile mode 1: per tile row I (nT + SFT_H_PAD_TILE_ROWS entries) bit d set if tile (I, I-d) holds any element of H
+  const SFT_G uint32_t* hgather;  // tile mode 1: the element of Hc every (lane, register) of tile (I, I-d) takes: ((I*9 + d)*64 + lane)*4 + q (sft_pack.h)
   // frame
   const SFT_G int32_t* obs_nodes; // M*3
   const SFT_G double* obs_bary;   // M*3
@@ -128,10 +127,12 @@ struct SftDev {
   SFT_G double* Anode;            // nA*6  node matrices A_i (when not in LDS): J_node of an observation = b_s A_node (sft_types.h:176-205)
   SFT_G double* Jstar;            // S*4  (u, r)           (when not in LDS)
   SFT_G double* Jstr;             // Es*4 (g, e)           (when not in LDS)
+  SFT_G double* Hc;               // tile mode 1: H as compact 3x3 blocks, 9 * (nA + noff) doubles + one 0.0 + one 1.0; block rows interleaved:
+                            //            diagonal block of node a at 9 * (a + off_ptr[a]), off-diagonal block q of block row a at 9 * (a + 1 + q)
   SFT_G double* Hb;               // band mode: Dnp*ldh lower band, row-major: (r,c) at r*ldh + c-r+kd
-                            // tile mode: nT*tpr 16x16 tiles, tile (I,J) at (I*tpr + I-J)*256, element (row,col) at
-                            //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register);
-                            //            mode 2 stores the off-diagonal tiles transposed (element (col,row))
+                            // tile mode 2: nT*tpr 16x16 tiles, tile (I,J) at (I*tpr + I-J)*256, element (row,col) at
+                            //            ((row&3)*16 + col)*4 + (row>>2)  (= MFMA accumulator order: lane, register),
+                            //            off-diagonal tiles transposed (element (col,row)); L uses the tile layout in modes 1 and 2
   SFT_G double* Hbord;            // 7*Dn     rows 0-5: camera x node, row 6: b_node
   SFT_G double* Hcorner;          // 7*7      camera x camera (lower) + b_cam in row 6
   SFT_G double* Lb;               // Dn*ldh

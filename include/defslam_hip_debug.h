@@ -23,7 +23,6 @@ extern "C" {
  *   "waves"    0 = automatic (default), 4 or 8 wavefronts per problem of the persistent kernel
  *   "dataflow" 1 = barrier-free factor steps (default), 0 = the barrier version (only compiled into the lab library)
  *   "wide_off" 1 = half-bandwidths 128 < kd <= 256 use the row-major band solver instead of the wide tile solver
- *   "asm_direct" 1 = the assembly stores its 3x3 blocks straight to global memory instead of staging whole tiles in LDS
  *   "speculate"  0 = automatic, 1 = off (the one-workgroup persistent kernel), 2..4 = that many workgroups per problem try
  *                consecutive dampings of an iteration side by side (latency mode; results are bit-identical either way) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
