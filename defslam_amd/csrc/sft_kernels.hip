@@ -562,18 +562,45 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       }
       if (on) {
         const int ob0 = cur.dob0, ob1 = cur.dob1, sh0 = cur.dsh0, sh1 = cur.dsh1;
-        constexpr int DCH = 2;   // per lane: 8 lanes x 2 = 16 contributions of each kind per round trip
-        for (int p0 = ob0 + sub; p0 < ob1; p0 += 8 * DCH) {
-          int mm[DCH];
-          double bb[DCH];
+        constexpr int DCH = 2, HCH = 3;   // per lane and round trip: 8 lanes x 2 = 16 observations, 8 x 3 = 24 curvature / stretch contributions
+        auto add_obs = [&](const double (&rr)[13], double b) {
+          const double om = rr[0] * b;
+          sii += om * b;
 #pragma unroll
-          for (int i = 0; i < DCH; i++) {
-            const int p = p0 + 8 * i;
-            const bool in = p < ob1;
-            mm[i] = in ? P.ob_m[p] : 0;
-            bb[i] = in ? P.ob_c[p] : 0.0;      // a zero coefficient switches a padding entry off
-          }
-          double rr[DCH][13];
+          for (int k = 0; k < 5; k++) { G0[k] += om * rr[3 + k]; G1[k] += om * rr[8 + k]; }
+          g0 += om * rr[1];
+          g1 += om * rr[2];
+        };
+        auto add_sh = [&](uint32_t rcv, double c0v, double c1v, const double (&r)[4]) {
+          const double wgt = (rcv >> 30) == SFT_KIND_STAR ? P.w_curv : P.w_str;
+          const double f = wgt * c0v, g = (wgt * c1v) * r[3];
+          const double u0 = r[0], u1 = r[1], u2 = r[2];
+          Hs[0] += f * (u0 * u0); Hs[1] += f * (u1 * u0); Hs[2] += f * (u1 * u1);
+          Hs[3] += f * (u2 * u0); Hs[4] += f * (u2 * u1); Hs[5] += f * (u2 * u2);
+          bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
+        };
+        // first chunk of BOTH lists in one round trip, their records in the next; the sums stay in list order per lane
+        int mm[DCH];
+        double bb[DCH];
+        uint32_t rc[HCH];
+        double c0[HCH], c1[HCH];
+#pragma unroll
+        for (int i = 0; i < DCH; i++) {
+          const int p = ob0 + sub + 8 * i;
+          const bool in = p < ob1;
+          mm[i] = in ? P.ob_m[p] : 0;
+          bb[i] = in ? P.ob_c[p] : 0.0;      // a zero coefficient switches a padding entry off
+        }
+#pragma unroll
+        for (int i = 0; i < HCH; i++) {
+          const int p = sh0 + sub + 8 * i;
+          const bool in = p < sh1;
+          rc[i] = in ? P.sh_rec[p] : 0xFFFFFFFFu;
+          c0[i] = in ? P.sh_cf[2 * p] : 0.0;
+          c1[i] = in ? P.sh_cf[2 * p + 1] : 0.0;
+        }
+        {
+          double rr[DCH][13], r[HCH][4];
 #pragma unroll
           for (int i = 0; i < DCH; i++) {
             const auto rec = P.camrec + (size_t)mm[i] * SFT_CAM_STRIDE;
@@ -581,40 +608,26 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
             for (int k = 0; k < 13; k++) rr[i][k] = rec[k];
           }
 #pragma unroll
-          for (int i = 0; i < DCH; i++) {
-            if (p0 + 8 * i >= ob1) continue;
-            const double om = rr[i][0] * bb[i];
-            sii += om * bb[i];
+          for (int i = 0; i < HCH; i++) ar.rec4((rc[i] >> 30) == SFT_KIND_STAR, rc[i] & 0x3FFFFFu, rc[i] != 0xFFFFFFFFu, r[i]);
 #pragma unroll
-            for (int k = 0; k < 5; k++) { G0[k] += om * rr[i][3 + k]; G1[k] += om * rr[i][8 + k]; }
-            g0 += om * rr[i][1];
-            g1 += om * rr[i][2];
-          }
+          for (int i = 0; i < DCH; i++)
+            if (ob0 + sub + 8 * i < ob1) add_obs(rr[i], bb[i]);
+#pragma unroll
+          for (int i = 0; i < HCH; i++)
+            if (rc[i] != 0xFFFFFFFFu) add_sh(rc[i], c0[i], c1[i], r[i]);
         }
-        for (int p0 = sh0 + sub; p0 < sh1; p0 += 8 * DCH) {
-          uint32_t rc[DCH];
-          double c0[DCH], c1[DCH];
+        for (int p = ob0 + sub + 8 * DCH; p < ob1; p += 8) {   // nodes seen by more than 16 observations
+          const auto rec = P.camrec + (size_t)P.ob_m[p] * SFT_CAM_STRIDE;
+          double rr[13];
 #pragma unroll
-          for (int i = 0; i < DCH; i++) {
-            const int p = p0 + 8 * i;
-            const bool in = p < sh1;
-            rc[i] = in ? P.sh_rec[p] : 0xFFFFFFFFu;
-            c0[i] = in ? P.sh_cf[2 * p] : 0.0;
-            c1[i] = in ? P.sh_cf[2 * p + 1] : 0.0;
-          }
-          double r[DCH][4];
-#pragma unroll
-          for (int i = 0; i < DCH; i++) ar.rec4((rc[i] >> 30) == SFT_KIND_STAR, rc[i] & 0x3FFFFFu, rc[i] != 0xFFFFFFFFu, r[i]);
-#pragma unroll
-          for (int i = 0; i < DCH; i++) {
-            if (rc[i] == 0xFFFFFFFFu) continue;
-            const double wgt = (rc[i] >> 30) == SFT_KIND_STAR ? P.w_curv : P.w_str;
-            const double f = wgt * c0[i], g = (wgt * c1[i]) * r[i][3];
-            const double u0 = r[i][0], u1 = r[i][1], u2 = r[i][2];
-            Hs[0] += f * (u0 * u0); Hs[1] += f * (u1 * u0); Hs[2] += f * (u1 * u1);
-            Hs[3] += f * (u2 * u0); Hs[4] += f * (u2 * u1); Hs[5] += f * (u2 * u2);
-            bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
-          }
+          for (int k = 0; k < 13; k++) rr[k] = rec[k];
+          add_obs(rr, P.ob_c[p]);
+        }
+        for (int p = sh0 + sub + 8 * HCH; p < sh1; p += 8) {   // more than 24 curvature / stretch contributions
+          const uint32_t rcv = P.sh_rec[p];
+          double r1[4];
+          ar.rec4((rcv >> 30) == SFT_KIND_STAR, rcv & 0x3FFFFFu, true, r1);
+          add_sh(rcv, P.sh_cf[2 * p], P.sh_cf[2 * p + 1], r1);
         }
       }
       AS_ADD(33);
