@@ -308,6 +308,11 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
   t[0] = ctl->t[0]; t[1] = ctl->t[1]; t[2] = ctl->t[2];
   const auto xyz = P.xyz;
   double chi = 0.0;
+  // camera corner of the normal equations, H_cc (lower 21) and b_c (6): accumulated while the camera Jacobian of an observation is
+  // in registers, reduced over the block in a fixed tree below (the assembly used to re-read every record for it)
+  double cc_acc[WANT_J ? 27 : 1];
+#pragma unroll
+  for (int i = 0; i < (WANT_J ? 27 : 1); i++) cc_acc[i] = 0.0;
   const int total = P.M + P.n + P.S + P.Es;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     if (idx < P.M) {
@@ -344,19 +349,23 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
         const double z2 = z * z, fx = P.fx, fy = P.fy;
         const auto rec = P.camrec + (size_t)m * SFT_CAM_STRIDE;
         const double wt = rho1 * w;
+        // row 0: columns 0, 1, 2, 3, 5 (column 4 is zero); row 1: columns 0, 1, 2, 4, 5 (column 3 is zero)
+        const double j0[6] = {x * y / z2 * fx, -(1 + (x * x / z2)) * fx, y / z * fx, -1. / z * fx, 0.0, x / z2 * fx};
+        const double j1[6] = {(1 + y * y / z2) * fy, -x * y / z2 * fy, -x / z * fy, 0.0, -1. / z * fy, y / z2 * fy};
         rec[0] = wt; rec[1] = e0; rec[2] = e1;
-        rec[3] = x * y / z2 * fx;            // row 0: columns 0, 1, 2, 3, 5 (column 4 is zero)
-        rec[4] = -(1 + (x * x / z2)) * fx;
-        rec[5] = y / z * fx;
-        rec[6] = -1. / z * fx;
-        rec[7] = x / z2 * fx;
-        rec[8] = (1 + y * y / z2) * fy;      // row 1: columns 0, 1, 2, 4, 5 (column 3 is zero)
-        rec[9] = -x * y / z2 * fy;
-        rec[10] = -x / z * fy;
-        rec[11] = -1. / z * fy;
-        rec[12] = y / z2 * fy;
+        rec[3] = j0[0]; rec[4] = j0[1]; rec[5] = j0[2]; rec[6] = j0[3]; rec[7] = j0[5];
+        rec[8] = j1[0]; rec[9] = j1[1]; rec[10] = j1[2]; rec[11] = j1[4]; rec[12] = j1[5];
         rec[13] = c2;
         ar.set_wt(m, wt);
+        if constexpr (WANT_J) {
+          int q = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c <= r; c++) cc_acc[q++] += wt * (j0[r] * j0[c] + j1[r] * j1[c]);
+#pragma unroll
+          for (int r = 0; r < 6; r++) cc_acc[21 + r] -= wt * (j0[r] * e0 + j1[r] * e1);
+        }
       }
     } else if (idx < P.M + P.n) {
       const int nd = idx - P.M;
@@ -413,6 +422,17 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
       }
     }
   }
+  if constexpr (WANT_J) {
+    block_sum<27>(cc_acc, red, out);
+    if (threadIdx.x == 0) {
+      int q = 0;
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c <= r; c++) P.Hcorner[r * 7 + c] = out[q++];
+      for (int r = 0; r < 6; r++) P.Hcorner[6 * 7 + r] = out[21 + r];
+      P.Hcorner[48] = 0.0;
+    }
+    __syncthreads();
+  }
   block_sum<1>(&chi, red, out);
   return out[0];
 }
@@ -460,34 +480,6 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   AS_T0();
-  // camera corner: H_cc (lower 21) and b_c (6) as a block-wide reduction over the observations
-  {
-    double acc[27];
-#pragma unroll
-    for (int i = 0; i < 27; i++) acc[i] = 0.0;
-    for (int m = threadIdx.x; m < P.M; m += blockDim.x) {
-      const auto rec = P.camrec + (size_t)m * SFT_CAM_STRIDE;
-      const double wt = rec[0], e0 = rec[1], e1 = rec[2];
-      const double j0[6] = {rec[3], rec[4], rec[5], rec[6], 0.0, rec[7]};
-      const double j1[6] = {rec[8], rec[9], rec[10], 0.0, rec[11], rec[12]};
-      int q = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++)
-#pragma unroll
-        for (int c = 0; c <= r; c++) acc[q++] += wt * (j0[r] * j0[c] + j1[r] * j1[c]);
-#pragma unroll
-      for (int r = 0; r < 6; r++) acc[21 + r] -= wt * (j0[r] * e0 + j1[r] * e1);
-    }
-    block_sum<27>(acc, red, out);
-    if (threadIdx.x == 0) {
-      int q = 0;
-      for (int r = 0; r < 6; r++)
-        for (int c = 0; c <= r; c++) P.Hcorner[r * 7 + c] = out[q++];
-      for (int r = 0; r < 6; r++) P.Hcorner[6 * 7 + r] = out[21 + r];
-      P.Hcorner[48] = 0.0;
-    }
-    __syncthreads();
-  }
   AS_ADD(32);
   // Tile mode 1 keeps H as compact 3x3 blocks (P.Hc; the factorisation gathers its tiles from them): a lane that finishes a
   // block stores its nine doubles, nothing is padded to tiles.  The other modes store into their band / tile layout element by element.
