@@ -530,6 +530,25 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
         Hg[idx + (P.tile_mode == 2 ? e1 - e2 : e2 - e1)] = v;
       }
     };
+    // first chunk of the lists of the lane's (first) off-diagonal block: issued here, with the diagonal lists below, used after the
+    // diagonal section -- one memory round trip less per round
+    constexpr int OCH = 4, SCH = 6;
+    int om0[OCH];
+    double oc0[OCH];
+    uint32_t orc0[SCH];
+    double occ0[SCH];
+#pragma unroll
+    for (int i = 0; i < OCH; i++) {
+      const bool in = cur.ob0 + i < cur.ob1;
+      om0[i] = in ? P.ob_m[cur.ob0 + i] : 0;
+      oc0[i] = in ? P.ob_c[cur.ob0 + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < SCH; i++) {
+      const bool in = cur.sh0 + i < cur.sh1;
+      orc0[i] = in ? P.sh_rec[cur.sh0 + i] : 0xFFFFFFFFu;
+      occ0[i] = in ? P.sh_cf[2 * (cur.sh0 + i)] : 0.0;
+    }
     // ---- diagonal blocks: 8 lanes per node, contributions dealt round-robin, partial sums combined by a fixed xor butterfly.
     // Every level of the gather (list entries -> records) is issued for up to DCH contributions at once.
     {
@@ -665,23 +684,28 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
         h.ob0 = P.ob_ptr[blk]; h.ob1 = P.ob_ptr[blk + 1]; h.sh0 = P.sh_ptr[blk]; h.sh1 = P.sh_ptr[blk + 1];
       }
       const int bi = h.bi, bj = h.bj;
-      // first chunk of both lists in one round trip; the records (LDS when they fit) in the next
-      constexpr int OCH = 4, SCH = 6;
       int om[OCH];
       double oc[OCH];
       uint32_t rc[SCH];
       double c0[SCH];
+      if (q == cur.q) {
 #pragma unroll
-      for (int i = 0; i < OCH; i++) {
-        const bool in = h.ob0 + i < h.ob1;
-        om[i] = in ? P.ob_m[h.ob0 + i] : 0;
-        oc[i] = in ? P.ob_c[h.ob0 + i] : 0.0;
-      }
+        for (int i = 0; i < OCH; i++) { om[i] = om0[i]; oc[i] = oc0[i]; }
 #pragma unroll
-      for (int i = 0; i < SCH; i++) {
-        const bool in = h.sh0 + i < h.sh1;
-        rc[i] = in ? P.sh_rec[h.sh0 + i] : 0xFFFFFFFFu;
-        c0[i] = in ? P.sh_cf[2 * (h.sh0 + i)] : 0.0;
+        for (int i = 0; i < SCH; i++) { rc[i] = orc0[i]; c0[i] = occ0[i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < OCH; i++) {
+          const bool in = h.ob0 + i < h.ob1;
+          om[i] = in ? P.ob_m[h.ob0 + i] : 0;
+          oc[i] = in ? P.ob_c[h.ob0 + i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < SCH; i++) {
+          const bool in = h.sh0 + i < h.sh1;
+          rc[i] = in ? P.sh_rec[h.sh0 + i] : 0xFFFFFFFFu;
+          c0[i] = in ? P.sh_cf[2 * (h.sh0 + i)] : 0.0;
+        }
       }
       double Ai[6], Aj[6];
 #pragma unroll
