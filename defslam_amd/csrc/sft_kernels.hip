@@ -1523,6 +1523,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
   if (tid == 0) ctl->fact_ok = 1;
   __syncthreads();
 
+  v4d araw_n = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
   for (int k = -1; k < nT; k++) {
     const int kc = k + 1, kslot = kc & (BT - 1), par = k & 1, p3 = (k + 3) % 3, p3c = kc % 3;
@@ -1531,18 +1532,9 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
     lds_double* Xp = XpB + par * (BT + 1) * TILE_LDS;
     lds_int* xflag = F + 2 + 10 * par;
     const bool memwave = wave == (k & (BT - 1));     // factored column k: its ring row is free, it takes the global-memory duties
-    v4d araw = {0.0, 0.0, 0.0, 0.0};
+    // the wave that factored column k recycled its ring row with tile row k+BT right behind its Cholesky of the previous step
+    // (below): tile (k+BT, k) is raw H and waits in araw_n
     if (k >= 0) {
-      if (memwave) {                                 // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
-        const int mk = uni(tmask[k + BT]);
-        v4u_t ix[BT + 1];
-        ix[BT] = fresh_idx(k + BT, BT, mk);
-#pragma unroll
-        for (int b = 0; b < BT; b++) ix[b] = fresh_idx(k + BT, (k + BT - b) & (BT - 1), mk);
-        araw = fresh_data(ix[BT], BT, mk);           // first: the TRSM of this step waits for it
-#pragma unroll
-        for (int b = 0; b < BT; b++) acc[b] = fresh_data(ix[b], (k + BT - b) & (BT - 1), mk);
-      }
       if (((wave + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc = fresh_border(k + BT);
       // nobody may still be reading the buffers of step k-2 (same parity)
       WT_BEGIN();
@@ -1556,7 +1548,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
       if (memwave) {                                 // its raw tile arrives from HBM: through the private LDS slot into operand layout
         lds_double* dst = Aself + ccol * TP + crow;
 #pragma unroll
-        for (int q = 0; q < 4; q++) dst[4 * q] = araw[q];
+        for (int q = 0; q < 4; q++) dst[4 * q] = araw_n[q];
       }
       {
         double av[4], bv[4];
@@ -1643,6 +1635,20 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
         flag_set(wflag, kc);
         *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
         __builtin_amdgcn_s_setprio(0);
+        // The ring row of column kc is free from here on: tile row kc+BT is gathered into it now, a step ahead of its first use, so
+        // that the two dependent round trips (element list, then the elements) overlap with the rest of this step.  The border
+        // registers are waited for first -- otherwise the in-order memory counter would make their next use wait for the gathers.
+        asm volatile("" ::"v"(bacc));
+        {
+          const int mk = uni(tmask[kc + BT]);
+          v4u_t ix[BT + 1];
+          ix[BT] = fresh_idx(kc + BT, BT, mk);
+#pragma unroll
+          for (int b = 0; b < BT; b++) ix[b] = fresh_idx(kc + BT, (kc + BT - b) & (BT - 1), mk);
+          araw_n = fresh_data(ix[BT], BT, mk);
+#pragma unroll
+          for (int b = 0; b < BT; b++) acc[b] = fresh_data(ix[b], (kc + BT - b) & (BT - 1), mk);
+        }
       } else {
         lds_double* dst = Aself + ccol * TP + crow;  // raw tile (I, kc) for the next step's TRSM: private slot
 #pragma unroll
@@ -1831,6 +1837,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
   if (tid == 0) ctl->fact_ok = 1;
   __syncthreads();
 
+  v4d araw_n = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
   for (int k = -1; k < nT; k++) {
     const int kc = k + 1, kslot = kc & (BT - 1), par = k & 1, p3 = (k + 3) % 3, p3c = kc % 3;
@@ -1842,21 +1849,12 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
     // the row closer to the diagonal goes first everywhere (it is the one other waves -- and the factorisation -- wait for)
     const bool swap = RPW == 2 && I[RPW - 1] < I[0];
     bool memwave = false;                             // holds the ring slot of column k: that row is free, it takes the global-memory duties
-    v4d araw = {0.0, 0.0, 0.0, 0.0};
+    // the wave that factored column k recycled that ring row with tile row k+BT right behind its Cholesky of the previous step
+    // (below): tile (k+BT, k) is raw H and waits in araw_n
     if (k >= 0) {
 #pragma unroll
       for (int t = 0; t < RPW; t++) {
-        if (wave + NW * t == (k & (BT - 1))) {        // recycle the ring row with tile row k+BT; tile (k+BT, k) is raw H
-          const int mk = uni(tmask[k + BT]);
-          memwave = true;
-          v4u_t ix[BT + 1];
-          ix[BT] = fresh_idx(k + BT, BT, mk);
-#pragma unroll
-          for (int b = 0; b < BT; b++) ix[b] = fresh_idx(k + BT, (k + BT - b) & (BT - 1), mk);
-          araw = fresh_data(ix[BT], BT, mk);          // first: the TRSM of this step waits for it
-#pragma unroll
-          for (int b = 0; b < BT; b++) acc[t][b] = fresh_data(ix[b], (k + BT - b) & (BT - 1), mk);
-        }
+        if (wave + NW * t == (k & (BT - 1))) memwave = true;
         if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
       }
       // nobody may still be reading the buffers of step k-2 (same parity)
@@ -1881,7 +1879,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
         if (i == BT) {                                // the recycled row: its raw tile arrives from HBM, through the private LDS slot into operand layout
           lds_double* dst = Aself + ccol * TP + crow;
 #pragma unroll
-          for (int q = 0; q < 4; q++) dst[4 * q] = araw[q];
+          for (int q = 0; q < 4; q++) dst[4 * q] = araw_n[q];
         }
         double av[4];
 #pragma unroll
@@ -1975,6 +1973,21 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
           flag_set(wflag, kc);
           *reinterpret_cast<v4d*>(Linv_g + (size_t)kc * TS * TS + 4 * lane) = w;
           __builtin_amdgcn_s_setprio(0);
+          // The ring row of column kc is free from here on: tile row kc+BT is gathered into it now, a step ahead of its first use, so
+          // that the two dependent round trips (element list, then the elements) overlap with the rest of this step.  The border
+          // registers are waited for first -- otherwise the in-order memory counter would make their next use wait for the gathers.
+#pragma unroll
+          for (int u = 0; u < RPW; u++) asm volatile("" ::"v"(bacc[u]));
+          {
+            const int mk = uni(tmask[kc + BT]);
+            v4u_t ix[BT + 1];
+            ix[BT] = fresh_idx(kc + BT, BT, mk);
+#pragma unroll
+            for (int b = 0; b < BT; b++) ix[b] = fresh_idx(kc + BT, (kc + BT - b) & (BT - 1), mk);
+            araw_n = fresh_data(ix[BT], BT, mk);
+#pragma unroll
+            for (int b = 0; b < BT; b++) acc[t][b] = fresh_data(ix[b], (kc + BT - b) & (BT - 1), mk);
+          }
         } else {
           lds_double* dst = AselfB + (wave + NW * t) * TILE_LDS + ccol * TP + crow;   // raw tile (I, kc) for the next step's TRSM: private slot
 #pragma unroll
