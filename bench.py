@@ -314,7 +314,9 @@ def main():
         # assembly: algorithmic bytes per launch (SURVEY 8d per-iteration figure x iterations the launch executes)
         bytes_per_launch = (alg_bytes / args.batch) * iters
         nTt = ((Dn + 31) // 32) * 2                      # 16-row tile rows of the padded node block
-        stream_trial = nTt * 9 * 2048 + 2 * nTt * 8 * 2048 + 3 * 7 * 16 * nTt * 8 + 2 * nTt * 2048   # H tiles, L write + read, border rows, Linv
+        # per damping trial: H read once (register-window solver: compact 3x3 blocks; wider bands: tiles), L written + read, border rows, Linv
+        h_read = 72 * (int(counts[1]) + int(counts[8])) if kd <= 128 else nTt * (-(-kd // 16) + 1) * 2048
+        stream_trial = h_read + 2 * nTt * 8 * 2048 + 3 * 7 * 16 * nTt * 8 + 2 * nTt * 2048
         stream_bytes = stream_trial * trials
         hbm_gbs = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {

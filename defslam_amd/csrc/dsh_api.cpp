@@ -671,7 +671,7 @@ int dsh_sft_batch_problem_info(dsh_ctx* c, int b, int64_t* bytes, int32_t* count
   const int64_t reads = 60 * M + 24 * n + 88 + 92 * C + 16 * E + 28 * V;
   const int64_t writes = 8 * (30 * M + 21 * C + 6 * E + 9 * V) + 8 * (2 * M + C + E + 3 * V) + 8 * M;
   if (bytes) *bytes = reads + writes;
-  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.g->n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; counts[6] = h.kd; counts[7] = c->nw; }
+  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.g->n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; counts[6] = h.kd; counts[7] = c->nw; counts[8] = P.g->noff; }
   return DSH_OK;
 }
 

@@ -241,7 +241,7 @@ class Context:
 
     def problem_info(self, b: int):
         nbytes = C.c_int64()
-        counts = np.zeros(8, np.int32)
+        counts = np.zeros(9, np.int32)
         self._check(self._L.dsh_sft_batch_problem_info(self._h, b, C.byref(nbytes), _ptr(counts, C.c_int32)), "dsh_sft_batch_problem_info")
         return nbytes.value, counts
 

@@ -121,8 +121,9 @@ int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
 /* Totals of the last completed run (valid after a synchronise): outer iterations and trials over the batch. */
 int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
 /* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts
- * counts[8] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim,
- * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload. */
+ * counts[9] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim,
+ * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload,
+ * off-diagonal 3x3 blocks of H (lower triangle). */
 int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int32_t* counts);
 
 /* ---- shared-camera Shape-from-Template across GPUs ---------------------------------------------------------------------
