@@ -31,7 +31,10 @@ namespace {
 #define HIPCHK(c, call)                                                                                        \
   do {                                                                                                         \
     hipError_t e__ = (call);                                                                                   \
-    if (e__ != hipSuccess) return dsh_fail(c, DSH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    if (e__ != hipSuccess) {   /* copies from local host buffers may be in flight: drain the stream before they go away */    \
+      (void)hipStreamSynchronize((c)->stream);                                                                  \
+      return dsh_fail(c, DSH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));                      \
+    }                                                                                                           \
   } while (0)
 
 struct DevBuf {   // a slice of the context's scratch (dsh_ctx.h); nothing to free

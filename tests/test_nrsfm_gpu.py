@@ -189,6 +189,37 @@ def test_shape_from_normals_matches_oracle(gpu_ctx, oracle_mod, n, seed, lam):
     assert ptsg.dtype == np.float32
 
 
+@pytest.mark.parametrize("n,lam", [(12, 1e-3), (5, 1e-2), (40, 1e-5)])
+def test_shape_from_normals_few_clustered_normals_against_numpy_lstsq(gpu_ctx, oracle_mod, n, lam):
+    """The reference solves the stacked system [M; Bend; 1] with Eigen's HouseholderQR (ShapeFromNormals.cc:95); the device forms
+    A^T A (which squares the condition number of the already ill-conditioned bending block) and repairs that with two
+    refinement steps on residuals taken from A itself.  Worst case for that deviation: a handful of normals clustered in one
+    corner of the domain -- almost all of the surface is determined by the bending energy alone (its null space, affine depth
+    maps, is pinned only by those few rows and the mean-depth row).  Compared against an SVD least-squares solve of the same
+    stacked system (numpy.linalg.lstsq), independent of both the oracle's QR and the device's normal equations."""
+    from defslam_amd import nrsfm, synth
+    sc = synth.make_sfn_scene(400, seed=11)
+    bbs = sc["bbs"]
+    # keep only the n sites closest to one corner of the definition domain
+    d = (sc["u"] - bbs[0]) ** 2 + (sc["v"] - bbs[3]) ** 2
+    keep = np.argsort(d)[:n]
+    u, v, nr = sc["u"][keep], sc["v"][keep], sc["normals"][keep]
+    N = bbs[2] * bbs[5]
+    M = oracle_mod.sfn_rows(bbs, u, v, nr)
+    A = np.vstack([M, oracle_mod.sfn_bending(bbs, lam), np.ones((1, N))])
+    b = np.zeros(A.shape[0])
+    b[-1] = N * sc["mean_depth"]
+    ref, _, rank, sv = np.linalg.lstsq(A, b, rcond=None)
+    assert rank == N and sv[0] / sv[-1] > 1e3          # full rank, but badly conditioned: that is the point of the case
+    ok, raw, ctrl, pts = nrsfm.ShapeFromNormals(gpu_ctx, nrsfm.Bbs(*bbs), u, v, nr, lam, sc["mean_depth"], sc["u_all"], sc["v_all"])
+    assert ok
+    # north-star tolerance 1e-4 relative; the refined semi-normal equations stay orders of magnitude inside it even here
+    np.testing.assert_allclose(raw, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+    oko, rawo, *_ = oracle_mod.sfn_estimate(bbs, u, v, nr, lam, sc["mean_depth"], sc["u_all"], sc["v_all"])
+    assert oko
+    np.testing.assert_allclose(rawo, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+
+
 def test_shape_from_normals_edge_cases(gpu_ctx, oracle_mod):
     from defslam_amd import nrsfm, synth
     sc = synth.make_sfn_scene(80, seed=5)
