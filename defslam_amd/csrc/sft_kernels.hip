@@ -1587,6 +1587,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
     }
     // ---- D1: block column kc of the own row, then publish it (private slot) or factor it (owner) ----
     double an[4] = {0.0, 0.0, 0.0, 0.0};
+    v4d dtile = acc[0];        // k == -1: column 0 sits in slot 0
     if (k >= 0) {
       WT_BEGIN();
       flag_wait(xflag + 1, k + 1);                   // X of tile (kc, k); the owner produced it itself
@@ -1611,14 +1612,11 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
             side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[3], bc[3], side, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             acc[c] += side;
+            dtile = acc[c];      // picked out of the ring inside the wave-uniform branch (a run-time register index costs 56 v_cndmask)
           }
       }
     }
     if (kc < nT) {
-      v4d dtile = acc[0];
-#pragma unroll
-      for (int c = 1; c < BT; c++)
-        if (c == kslot) dtile = acc[c];
       if (I == kc) {
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -1925,6 +1923,9 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
     if (t == (swap ? RPW - 1 - o : o)) {
       const int i = I[t] - k;
       double an[4] = {0.0, 0.0, 0.0, 0.0};
+      // the tile of block column kc is picked out of the ring inside the (wave-uniform) branch that updates it: a run-time index into
+      // the register array costs 56 v_cndmask per row and step.  k == -1: column 0 sits in slot 0; rows behind the matrix never use it.
+      v4d dtile = acc[t][0];
       if (k >= 0) {
         WT_BEGIN();
         flag_wait(xflag + 1, k + 1);                  // X of tile (kc, k); the owner produced it itself
@@ -1949,14 +1950,11 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
               side = __builtin_amdgcn_mfma_f64_16x16x4f64(an[3], bc[3], side, 0, 0, 0);
               __builtin_amdgcn_sched_barrier(0);
               acc[t][c] += side;
+              dtile = acc[t][c];
             }
         }
       }
       if (kc < nT) {
-        v4d dtile = acc[t][0];
-#pragma unroll
-        for (int c = 1; c < BT; c++)
-          if (c == kslot) dtile = acc[t][c];
         if (I[t] == kc) {
           __builtin_amdgcn_s_setprio(3);
 #pragma unroll
