@@ -1565,7 +1565,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
         x += x2;
         lds_double* dst = Xp + i * TILE_LDS + ccol * TP + crow;
 #pragma unroll
-        for (int q = 0; q < 4; q++) dst[4 * q] = (I < nT) ? x[q] : 0.0;
+        for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
         flag_set(xflag + i, k + 1);
         if (i == 4) {                                // border panel (7 camera/rhs rows): one more MFMA tile, off the critical path
           flag_wait(bflag, k);
@@ -1890,7 +1890,7 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
         x += x2;
         lds_double* dst = Xp + i * TILE_LDS + ccol * TP + crow;
 #pragma unroll
-        for (int q = 0; q < 4; q++) dst[4 * q] = (I[t] < nT) ? x[q] : 0.0;
+        for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
         flag_set(xflag + i, k + 1);
       }
       bool border_trsm = false;
