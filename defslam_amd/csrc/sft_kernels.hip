@@ -1660,14 +1660,14 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
         flags_wait(xflag, 2, i, k + 1);
         WT_END(3);
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          double bb[BT];
+        for (int b = 0; b < BT; b++) {                 // one wave-uniform branch per tile; only the X tiles the row needs are read
+          const int J = kc + ((b - kc) & (BT - 1));
+          if (J <= I && J != kc) {
+            double bb[4];
 #pragma unroll
-          for (int b = 0; b < BT; b++) bb[b] = Xp[(kc + ((b - kc) & (BT - 1)) - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+            for (int kk = 0; kk < 4; kk++) bb[kk] = Xp[(J - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
 #pragma unroll
-          for (int b = 0; b < BT; b++) {
-            const int J = kc + ((b - kc) & (BT - 1));
-            if (J <= I && J != kc) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[b], acc[b], 0, 0, 0);
+            for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[kk], acc[b], 0, 0, 0);
           }
         }
       }
@@ -1997,14 +1997,14 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
         flags_wait(xflag, 2, i, k + 1);
         WT_END(3);
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          double bb[BT];
+        for (int b = 0; b < BT; b++) {                // one wave-uniform branch per tile; only the X tiles the row needs are read
+          const int J = kc + ((b - kc) & (BT - 1));
+          if (J <= I[t] && J != kc) {
+            double bb[4];
 #pragma unroll
-          for (int b = 0; b < BT; b++) bb[b] = Xp[(kc + ((b - kc) & (BT - 1)) - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
+            for (int kk = 0; kk < 4; kk++) bb[kk] = Xp[(J - k) * TILE_LDS + (4 * kk + crow) * TP + ccol];
 #pragma unroll
-          for (int b = 0; b < BT; b++) {
-            const int J = kc + ((b - kc) & (BT - 1));
-            if (J <= I[t] && J != kc) acc[t][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[b], acc[t][b], 0, 0, 0);
+            for (int kk = 0; kk < 4; kk++) acc[t][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[kk], bb[kk], acc[t][b], 0, 0, 0);
           }
         }
       }
