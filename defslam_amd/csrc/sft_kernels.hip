@@ -1567,6 +1567,8 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
 #pragma unroll
         for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
         flag_set(xflag + i, k + 1);
+        // the tile of L leaves from the registers it was computed in (accumulator order = storage order): nobody re-reads the panel
+        if (I < nT) *reinterpret_cast<v4d*>(Lg + tile_off(k, i) + 4 * lane) = x;   // L is stored by block COLUMN: tile (k+i, k) at slot (k, i)
         if (i == 4) {                                // border panel (7 camera/rhs rows): one more MFMA tile, off the critical path
           flag_wait(bflag, k);
           lds_double* Abord = AbordB + p3 * SFT_BORDER * TS;
@@ -1582,6 +1584,8 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
           Xp[ccol * TP + crow] = xb[0];
           if (crow + 4 < SFT_BORDER) Xp[ccol * TP + crow + 4] = xb[1];
           flag_set(xflag, k + 1);
+          Lbord[(size_t)crow * Dnp + TS * k + ccol] = xb[0];
+          if (crow + 4 < SFT_BORDER) Lbord[(size_t)(crow + 4) * Dnp + TS * k + ccol] = xb[1];
         }
       }
     }
@@ -1695,26 +1699,6 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
           Abord[crow * TS + ccol] = bacc[0];
           if (crow + 4 < SFT_BORDER) Abord[(crow + 4) * TS + ccol] = bacc[1];
           flag_set(bflag, kc);
-        }
-      }
-      // ---- block column k of L goes to global memory from the LDS panel ----
-      if (memwave) {
-        WT_BEGIN();
-        flags_wait(xflag, 0, BT, k + 1);
-        WT_END(5);
-#pragma unroll
-        for (int j = 1; j <= BT; j++)
-          if (k + j < nT) {
-            const lds_double* src = Xp + j * TILE_LDS + ccol * TP + crow;
-            v4d x;
-#pragma unroll
-            for (int q = 0; q < 4; q++) x[q] = src[4 * q];
-            *reinterpret_cast<v4d*>(Lg + tile_off(k, j) + 4 * lane) = x;   // L is stored by block COLUMN: tile (k+j, k) at slot (k, j)
-          }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int e = lane + 64 * h, r = e >> 4, j = e & 15;
-          if (r < SFT_BORDER) Lbord[(size_t)r * Dnp + TS * k + j] = Xp[j * TP + r];
         }
       }
       flag_set(dflag + wave, k + 1);                 // done with the buffers of step k
@@ -1846,13 +1830,11 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
     for (int t = 0; t < RPW; t++) I[t] = kc + ((wave + NW * t - kc) & (BT - 1));
     // the row closer to the diagonal goes first everywhere (it is the one other waves -- and the factorisation -- wait for)
     const bool swap = RPW == 2 && I[RPW - 1] < I[0];
-    bool memwave = false;                             // holds the ring slot of column k: that row is free, it takes the global-memory duties
     // the wave that factored column k recycled that ring row with tile row k+BT right behind its Cholesky of the previous step
     // (below): tile (k+BT, k) is raw H and waits in araw_n
     if (k >= 0) {
 #pragma unroll
       for (int t = 0; t < RPW; t++) {
-        if (wave + NW * t == (k & (BT - 1))) memwave = true;
         if (((wave + NW * t + BOFF) & (BT - 1)) == (k & (BT - 1))) bacc[t] = fresh_border(k + BT);
       }
       // nobody may still be reading the buffers of step k-2 (same parity)
@@ -1892,6 +1874,8 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
 #pragma unroll
         for (int q = 0; q < 4; q++) dst[4 * q] = x[q];
         flag_set(xflag + i, k + 1);
+        // the tile of L leaves from the registers it was computed in (accumulator order = storage order): nobody re-reads the panel
+        if (I[t] < nT) *reinterpret_cast<v4d*>(Lg + tile_off(k, i) + 4 * lane) = x;   // L is stored by block COLUMN: tile (k+i, k) at slot (k, i)
       }
       bool border_trsm = false;
 #pragma unroll
@@ -1913,6 +1897,8 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
         Xp[ccol * TP + crow] = xb[0];
         if (crow + 4 < SFT_BORDER) Xp[ccol * TP + crow + 4] = xb[1];
         flag_set(xflag, k + 1);
+        Lbord[(size_t)crow * Dnp + TS * k + ccol] = xb[0];
+        if (crow + 4 < SFT_BORDER) Lbord[(size_t)(crow + 4) * Dnp + TS * k + ccol] = xb[1];
       }
     }
     // ---- D1: block column kc of the own rows, then publish (private slot) or factor (owner); D2: rest of the row ----
@@ -2038,26 +2024,6 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
       if (wave == 0) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[kk], -bn[kk], cacc, 0, 0, 0);
-      }
-      // ---- block column k of L goes to global memory from the LDS panel ----
-      if (memwave) {
-        WT_BEGIN();
-        flags_wait(xflag, 0, BT, k + 1);
-        WT_END(5);
-#pragma unroll
-        for (int j = 1; j <= BT; j++)
-          if (k + j < nT) {
-            const lds_double* src = Xp + j * TILE_LDS + ccol * TP + crow;
-            v4d x;
-#pragma unroll
-            for (int q = 0; q < 4; q++) x[q] = src[4 * q];
-            *reinterpret_cast<v4d*>(Lg + tile_off(k, j) + 4 * lane) = x;   // L is stored by block COLUMN: tile (k+j, k) at slot (k, j)
-          }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int e = lane + 64 * h, r = e >> 4, j = e & 15;
-          if (r < SFT_BORDER) Lbord[(size_t)r * Dnp + TS * k + j] = Xp[j * TP + r];
-        }
       }
       flag_set(dflag + wave, k + 1);                  // done with the buffers of step k
     } else {
