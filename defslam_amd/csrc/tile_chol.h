@@ -55,8 +55,8 @@ __device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
   w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
-  bool bad = false;
   const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  double plast = 1.0;
 #pragma unroll
   for (int J = 0; J < 4; J++) {
     const double aJ = a[J];
@@ -65,20 +65,19 @@ __device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
     const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
     const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
     double i0, i1, i2, i3, sq;
-    if (!(d00 > 0.0)) bad = true;
     rsqrt_sqrt(d00, i0, sq);
     const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
     const double p1 = fma(-l10, l10, d11);
-    if (!(p1 > 0.0)) bad = true;
     rsqrt_sqrt(p1, i1, sq);
     const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
     const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
-    if (!(p2 > 0.0)) bad = true;
     rsqrt_sqrt(p2, i2, sq);
     const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
     const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-    if (!(p3 > 0.0)) bad = true;
     rsqrt_sqrt(p3, i3, sq);
+    // A pivot that is not positive (or not a number) turns its 1/sqrt into NaN or infinity, and from there every later pivot of the
+    // tile into NaN (through l = d * inv and through the rank-4 update): the LAST pivot tells whether all sixteen were positive.
+    plast = p3;
     // M = Ld^-1 (lower triangular)
     const double m10 = -(l10 * i0) * i1;
     const double m21 = -(l21 * i1) * i2;
@@ -103,6 +102,6 @@ __device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
     }
     w[J] = zw[0];
   }
-  return !bad;
+  return plast > 0.0;
 }
 
