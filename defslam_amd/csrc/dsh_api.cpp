@@ -98,6 +98,7 @@ struct dsh_ctx : dsh_ctx_base {
   } dt{};
   // structure of the normal equations per active set of the current template (sft_pack.h), device-resident, built on first use
   std::vector<std::unique_ptr<dsh::SftGraph>> graphs;
+  uint64_t upload_serial = 0;     // graphs touched by the upload in progress carry it (eviction keeps them)
   // batch
   int B = 0;
   std::vector<Packed> packed;
@@ -201,15 +202,25 @@ int graph_for(dsh_ctx* c, const std::vector<uint8_t>& opt, dsh::SftGraph** out, 
   uint64_t h = 1469598103934665603ull;
   for (uint8_t b : opt) { h ^= b; h *= 1099511628211ull; }
   for (auto& g : c->graphs)
-    if (g->opt_hash == h && g->opt == opt) { *out = g.get(); return DSH_OK; }
-  if (c->graphs.size() >= 64) {   // a long sequence with an ever-changing view: start over (rebuilding costs one slow frame)
-    const int Bkeep = c->B;
-    drop_graphs(c);
-    c->B = Bkeep;
+    if (g->opt_hash == h && g->opt == opt) { g->last_use = c->upload_serial; *out = g.get(); return DSH_OK; }
+  if (c->graphs.size() >= 64) {
+    // A long sequence with an ever-changing view: drop every graph the upload in progress does not use (rebuilding one costs a slow
+    // frame).  Graphs of the problems already packed by THIS upload stay -- a batch with more than 64 active sets just grows the cache.
+    if (!c->host_only && c->stream) (void)hipStreamSynchronize(c->stream);   // the previous batch may still read them
+    auto& gs = c->graphs;
+    for (size_t i = 0; i < gs.size();) {
+      if (gs[i]->last_use != c->upload_serial) {
+        if (gs[i]->d_base) (void)hipFree(gs[i]->d_base);
+        gs.erase(gs.begin() + i);
+      } else {
+        i++;
+      }
+    }
   }
   std::unique_ptr<dsh::SftGraph> g(new dsh::SftGraph());
   const int rc = dsh::build_graph(c->tmpl, opt, *g, err);
   if (rc != DSH_OK) return rc;
+  g->last_use = c->upload_serial;
   if (!c->host_only) {
     Arena a;
     auto& o = g->o;
@@ -449,6 +460,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   if (!c->host_only) (void)hipSetDevice(c->device);
   c->B = 0;
   c->ran = false;
+  c->upload_serial++;
   if ((int)c->packed.size() != B) c->packed.resize(B);   // the vectors inside keep their capacity from frame to frame
   for (int b = 0; b < B; b++) {
     std::string e;

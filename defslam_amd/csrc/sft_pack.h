@@ -45,6 +45,7 @@ struct SftGraph {
   std::vector<uint32_t> hgather;
   size_t hc_elems() const { return 9 * (size_t)(nA + noff) + 2; }
   int nblk() const { return nA + noff; }
+  uint64_t last_use = 0;             // serial of the last upload that used the graph (cache eviction)
   // device copy (owned by the context)
   char* d_base = nullptr;
   size_t d_bytes = 0;

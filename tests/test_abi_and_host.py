@@ -224,3 +224,35 @@ def test_packer_counts_and_algorithmic_bytes(host_ctx, oracle_mod):
     expect = (60 * M + 24 * n + 88 + 92 * Cc + 16 * E + 28 * V) + 8 * (30 * M + 21 * Cc + 6 * E + 9 * V) + 8 * (2 * M + Cc + E + 3 * V) + 8 * M
     assert nbytes == expect
     assert 1.1e6 < nbytes < 1.25e6    # ~1.17 MB per assembly pass at C2
+
+
+def test_graph_cache_survives_more_active_sets_than_it_holds(host_ctx):
+    """The structure of the normal equations is cached per active set (64 entries).  A sequence whose view changes every frame, and a
+    batch with more distinct active sets than the cache holds, must keep packing correctly: the eviction may only drop graphs the
+    upload in progress does not use (regression: it used to clear the problems already packed by the same upload)."""
+    from defslam_amd import sft, synth
+    tmpl = synth.make_grid_template(14, 14)
+    host_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    base = synth.make_frame(tmpl, 900, 3)
+
+    def windowed(r0, c0):
+        keep = [c + 14 * r for r in range(r0, r0 + 6) for c in range(c0, c0 + 6)]
+        sel = np.all(np.isin(base.obs_nodes, keep), axis=1)
+        f = sft.frame_from_synth(base)
+        f.obs_nodes, f.obs_bary, f.obs_uv, f.obs_invsig2 = base.obs_nodes[sel], base.obs_bary[sel], base.obs_uv[sel], base.obs_invsig2[sel]
+        return f
+
+    views = [(r, c) for r in range(9) for c in range(9)]          # 81 different 6x6 windows = 81 active sets
+    ref = {}
+    for v in views:                                                # one frame at a time: the 65th evicts
+        host_ctx.batch_upload([windowed(*v)], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 10)
+        ref[v] = host_ctx.problem_info(0)
+        assert ref[v][1][0] > 0 and 0 < ref[v][1][1] <= 64         # some observations, at most the 8x8 nodes of window + ring
+    # all of them in ONE upload (more active sets than the cache holds), in a different order
+    order = views[::-1]
+    host_ctx.batch_upload([windowed(*v) for v in order], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 10)
+    for b, v in enumerate(order):
+        nb, counts = host_ctx.problem_info(b)
+        assert nb == ref[v][0]
+        np.testing.assert_array_equal(counts[:7], ref[v][1][:7])
+        assert counts[8] == ref[v][1][8]

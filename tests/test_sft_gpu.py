@@ -486,3 +486,26 @@ def test_speculative_damping_trials_are_bit_identical(lab_ctx, cfg, pids, iters)
             np.testing.assert_array_equal(a.mvbOutlier, b.mvbOutlier)
             np.testing.assert_array_equal(a.mappoints, b.mappoints)
             assert a.rep_error_f64 == b.rep_error_f64
+
+
+def test_changing_view_sequence_through_the_graph_cache(gpu_ctx, oracle_mod):
+    """Seventy frames that each see a different 6x6 window of a 14x14 template: every frame has its own active set, the 65th evicts
+    the graph cache while the device may still hold the previous batch.  The last frames are checked against the oracle."""
+    from defslam_amd import sft, synth
+    tmpl = synth.make_grid_template(14, 14)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    base = synth.make_frame(tmpl, 900, 3)
+    views = [(r, c) for r in range(9) for c in range(9)][:70]
+    for n, (r0, c0) in enumerate(views):
+        keep = [c + 14 * r for r in range(r0, r0 + 6) for c in range(c0, c0 + 6)]
+        sel = np.all(np.isin(base.obs_nodes, keep), axis=1)
+        fr = synth.make_frame(tmpl, 900, 3)
+        for k in ["obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+            setattr(fr, k, getattr(base, k)[sel])
+        f = sft.frame_from_synth(fr)
+        inl = sft.DefPoseOptimization(gpu_ctx, f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        assert f.status == 0
+        if n >= 66:
+            tc, args = oracle_args(oracle_mod, tmpl, fr)
+            r = oracle_mod.sft_solve(*args)
+            _compare(f, inl, r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
