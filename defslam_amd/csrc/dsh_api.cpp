@@ -122,6 +122,7 @@ struct dsh_ctx : dsh_ctx_base {
   size_t lds_configured_spec = 0;      // and for the speculative-trial kernel
   // latency mode: K workgroups per problem run the next K damping trials of an iteration side by side (sft_kernels.hip: sft_spec_kernel)
   int spec_k = 1;
+  int spec_hint = 12;                  // launches the previous speculative run needed (first group of the next one)
   int max_iters_batch = 0;
   SftSpec* d_spec = nullptr;           // K*B controller states, inside d_batch
   size_t spec_bytes = 0;
@@ -284,19 +285,23 @@ int run_once(dsh_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->d_spec, 0, c->spec_bytes, c->stream));
   const int rounds_per_iter = (10 + K - 1) / K;
   const int worst = c->max_iters_batch * rounds_per_iter + 1;
-  int launched = 0, group = std::min(worst, c->max_iters_batch + 1);
+  // First group: as many launches as the previous run of this context needed (tracking is coherent from frame to frame: usually
+  // exact), then the done flags are read back and rounds of two are added while a problem still runs.  Launches behind the end
+  // of a problem cost a few microseconds each (it leaves at the first instruction); a read-back costs a stream synchronisation.
+  int launched = 0, group = std::max(2, std::min(worst, c->spec_hint));
   HIPCHK(c, c->spec_done.ensure(sizeof(SftSpec) * (size_t)B, true));
-  while (launched < worst) {
+  while (true) {
     for (int i = 0; i < group && launched < worst; i++, launched++)
       HIPCHK(c, sft_spec_launch(c->d_probs, c->d_spec, B, K, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream));
-    if (launched >= worst) break;
     HIPCHK(c, hipMemcpyAsync(c->spec_done.p, c->d_spec, sizeof(SftSpec) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const SftSpec* sp = reinterpret_cast<const SftSpec*>(c->spec_done.p);
     bool all_done = true;
-    for (int b = 0; b < B; b++) all_done = all_done && sp[b].done;
-    if (all_done) break;
-    group = 3;
+    int needed = 0;
+    for (int b = 0; b < B; b++) { all_done = all_done && sp[b].done; needed = std::max(needed, sp[b].launches + 1); }
+    if (all_done) { c->spec_hint = needed; break; }
+    if (launched >= worst) return fail(c, DSH_ERR_STATE, "speculative trials: a problem did not terminate within its launch budget");
+    group = 2;
   }
   return DSH_OK;
 }
@@ -344,6 +349,7 @@ int dsh_destroy(dsh_ctx* c) {
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
   c->stage.release();
   c->results.release();
+  c->spec_done.release();
   if (c->d_tmpl) (void)hipFree(c->d_tmpl);
   c->scratch.release();
   c->pin_in.release();
