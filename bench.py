@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="independent problems per GPU per step (default: 8192 for C2 = 32 per CU, 27 GB of HBM: problems need 7-35 damping "
+    ap.add_argument("--batch", type=int, default=0, help="independent problems per GPU per step (default: 16384 for C2 = 64 per CU, 42 GB of HBM: problems need 7-35 damping "
                                                          "trials and a launch ends with its slowest one, so a deep batch amortises the tail; 16 for C5 = BASELINE configs[4])")
     ap.add_argument("--config", default="C2", choices=["smoke", "C2", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing aid: every rank uses this device index instead of LOCAL_RANK")
     args = ap.parse_args()
     if args.batch <= 0:
-        args.batch = {"C2": 8192, "C5": 16, "smoke": 512}[args.config]
+        args.batch = {"C2": 16384, "C5": 16, "smoke": 512}[args.config]
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         sys.exit(2)

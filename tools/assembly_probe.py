@@ -3,7 +3,7 @@ that do one linearisation + normal-equation assembly per problem."""
 import sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import sft, synth
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ctx = sft.Context(0, lab=True)   # lab build: timers, test hooks, A/B switches (include/defslam_hip_debug.h)
 rows, cols, m = synth.CONFIGS["C2"]

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash  # noqa: E402
 
 out_dir, commit = sys.argv[1], sys.argv[2]
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16384   # problems per launch of both passes (bench.py's C2 default)
 
 
 def per_launch(sub, counter, kernel):
@@ -35,8 +36,8 @@ def avg_ms(sub, kernel):
 res = {"_comment": "HBM traffic per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, --kernel-trace only; "
                    "FETCH_SIZE x2, both KiB); bench.py drops these numbers when its device code hash differs",
        "kernel_source_hash": kernel_source_hash(), "commit": commit}
-for key, kernel, fs, ws, st in (("C2_B8192", "sft_lm_kernel", "pmc_fetch", "pmc_write", "stats"),
-                                ("C2_B8192_assembly", "sft_assembly_kernel", "asm_fetch", "asm_write", "asm_stats")):
+for key, kernel, fs, ws, st in ((f"C2_B{batch}", "sft_lm_kernel", "pmc_fetch", "pmc_write", "stats"),
+                                (f"C2_B{batch}_assembly", "sft_assembly_kernel", "asm_fetch", "asm_write", "asm_stats")):
     f, nf = per_launch(fs, "FETCH_SIZE", kernel)
     w, nw = per_launch(ws, "WRITE_SIZE", kernel)
     ms, calls = avg_ms(st, kernel)
