@@ -394,10 +394,27 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
       const int s = idx - P.M - P.n;
       const int nd = P.star_node[s];
       double a0 = 0, a1 = 0, a2 = 0;
-      for (int q = P.nbr_ptr[nd]; q < P.nbr_ptr[nd + 1]; q++) {
-        const int j = P.nbr_idx[q];
-        const double wj = P.nbr_w[q];
-        a0 = a0 + wj * xyz[3 * j]; a1 = a1 + wj * xyz[3 * j + 1]; a2 = a2 + wj * xyz[3 * j + 2];
+      {   // weighted mean of the 1-ring, neighbours in list order; the loads of up to eight neighbours travel together (one round trip
+          // for the indices and weights, one for the positions) instead of two dependent round trips per neighbour
+        constexpr int NCH = 8;
+        const int q0 = P.nbr_ptr[nd], q1 = P.nbr_ptr[nd + 1];
+        for (int qb = q0; qb < q1; qb += NCH) {
+          int jj[NCH];
+          double ww[NCH], xx[NCH][3];
+#pragma unroll
+          for (int i = 0; i < NCH; i++) {
+            const bool in = qb + i < q1;
+            jj[i] = in ? P.nbr_idx[qb + i] : nd;
+            ww[i] = in ? P.nbr_w[qb + i] : 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < NCH; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) xx[i][k] = xyz[3 * jj[i] + k];
+#pragma unroll
+          for (int i = 0; i < NCH; i++)
+            if (qb + i < q1) { a0 = a0 + ww[i] * xx[i][0]; a1 = a1 + ww[i] * xx[i][1]; a2 = a2 + ww[i] * xx[i][2]; }
+        }
       }
       const double sw = P.nbr_sumw[nd];
       const double m0 = xyz[3 * nd] - a0 / sw, m1 = xyz[3 * nd + 1] - a1 / sw, m2 = xyz[3 * nd + 2] - a2 / sw;
