@@ -73,7 +73,7 @@ class BbsC(C.Structure):
 
 SchwarpProblemC._fields_ = [("bbs", BbsC), ("P", C.c_int32), ("kp1", c_float_p), ("kp2", c_float_p), ("invsig", c_float_p), ("fx_slot", C.c_double),
                             ("fy_slot", C.c_double), ("lam", C.c_double), ("fx", C.c_float), ("fy", C.c_float), ("max_iters", C.c_int32), ("x", c_double_p),
-                            ("diff", c_float_p), ("drop", c_u8_p), ("info", C.c_int32 * 2), ("costs", C.c_double * 2)]
+                            ("diff", c_float_p), ("drop", c_u8_p), ("info", C.c_int32 * 2), ("costs", C.c_double * 2), ("init_lambda", C.c_double), ("init_ok", C.c_int32)]
 
 DIFFPROP_FIELDS = ["I1u", "I1v", "I2u", "I2v", "J12a", "J12b", "J12c", "J12d", "J21a", "J21b", "J21c", "J21d",
                    "H12uux", "H12uuy", "H12uvx", "H12uvy", "H12vvx", "H12vvy"]

@@ -22,8 +22,10 @@ extern "C" int nrsfm_swp_solve_np(int);
 extern "C" hipError_t nrsfm_swp_step(int, const double*, const double*, const double*, const double*, double*, double*, hipStream_t);
 extern "C" size_t nrsfm_swp_fit_bytes();
 extern "C" void nrsfm_swp_fit_fill(void*, double, double, int, double, double, int, int, double, double, double, float, float, int, const float*, const float*, const float*,
-                                   double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, float*, uint8_t*, int32_t*, double*);
-extern "C" hipError_t nrsfm_swp_fit_batch(void*, int, int, int, int, hipStream_t);
+                                   double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, float*, uint8_t*, int32_t*, double*,
+                                   const double*);
+extern "C" hipError_t nrsfm_swp_fit_batch(void*, int, int, int, int, int, hipStream_t);
+namespace dsh { void bbs_bending_dense(const dsh_bbs* b, double lambda, double* Bm); }
 extern "C" hipError_t nrsfm_swp_diffprop(double, double, int, double, double, int, int, const float*, const float*, const double*, float, float, float*,
                                          uint8_t*, hipStream_t);
 
@@ -138,7 +140,8 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
   // ---- layout of the input block (host-staged) and of the output block
   const size_t fit_bytes = nrsfm_swp_fit_bytes();
   size_t in_bytes = al(fit_bytes * (size_t)B), out_bytes = 0;
-  struct Off { size_t kp1, kp2, isg, x0, cs, xo, diff, drop, info, costs; };
+  int with_init = 0;
+  struct Off { size_t kp1, kp2, isg, x0, cs, xo, diff, drop, info, costs, bend; };
   std::vector<Off> off(B);
   for (int b = 0; b < B; b++) {
     const dsh_schwarp_problem& q = probs[b];
@@ -148,6 +151,14 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
     o.kp2 = in_bytes; in_bytes += al(8 * (size_t)q.P);
     o.isg = in_bytes; in_bytes += al(4 * (size_t)q.P);
     o.cs = in_bytes; in_bytes += al(8 * n2);
+    // bending matrix of the Warp::initialize stage: one per run of problems with the same grid and weight
+    o.bend = 0;
+    if (q.init_lambda > 0.0) {
+      const bool same = b > 0 && probs[b - 1].init_lambda == q.init_lambda && std::memcmp(&probs[b - 1].bbs, &q.bbs, sizeof(dsh_bbs)) == 0 && off[b - 1].bend;
+      if (same) o.bend = off[b - 1].bend;
+      else { o.bend = in_bytes; in_bytes += al(8 * (n2 / 2) * (n2 / 2)); }
+      with_init = 1;
+    }
     o.xo = out_bytes; out_bytes += al(8 * n2);                  // x lives in the output block (in/out): its start value is copied there
     o.diff = out_bytes; out_bytes += al(q.diff ? 72 * (size_t)q.P : 0);
     o.drop = out_bytes; out_bytes += al(q.drop ? (size_t)q.P : 0);
@@ -169,7 +180,11 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
     std::memcpy(hin + o.kp1, q.kp1, 8 * (size_t)q.P); std::memcpy(hin + o.kp2, q.kp2, 8 * (size_t)q.P); std::memcpy(hin + o.isg, q.invsig, 4 * (size_t)q.P);
     double* cs = reinterpret_cast<double*>(hin + o.cs);
     for (int j = 0; j < n2; j++) cs[j] = 1.0;
-    std::memcpy(hx + o.xo, q.x, 8 * (size_t)n2);
+    if (q.init_lambda > 0.0) {
+      if (b == 0 || off[b - 1].bend != o.bend) dsh::bbs_bending_dense(&q.bbs, q.init_lambda, reinterpret_cast<double*>(hin + o.bend));
+    } else {
+      std::memcpy(hx + o.xo, q.x, 8 * (size_t)n2);
+    }
     DevBuf xn, g, dx, r, J, A, M, W, scal;
     const size_t np = (size_t)nrsfm_swp_solve_np(n2);
     HIPCHK(c, xn.alloc(c, 8 * (size_t)n2)); HIPCHK(c, g.alloc(c, 8 * (size_t)n2)); HIPCHK(c, dx.alloc(c, 8 * (size_t)n2)); HIPCHK(c, r.alloc(c, 8 * (size_t)m));
@@ -181,11 +196,12 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
                        q.max_iters, reinterpret_cast<const float*>(dib + o.kp1), reinterpret_cast<const float*>(dib + o.kp2), reinterpret_cast<const float*>(dib + o.isg),
                        reinterpret_cast<double*>(dob + o.xo), xn.as<double>(), reinterpret_cast<double*>(dib + o.cs), g.as<double>(), dx.as<double>(), r.as<double>(),
                        J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal.as<double>(), q.diff ? reinterpret_cast<float*>(dob + o.diff) : nullptr,
-                       q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr, reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs));
+                       q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr, reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs),
+                       q.init_lambda > 0.0 ? reinterpret_cast<const double*>(dib + o.bend) : nullptr);
   }
   HIPCHK(c, hipMemcpyAsync(dib, hin, in_bytes, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(dob, hx, out_bytes, hipMemcpyHostToDevice, st));
-  HIPCHK(c, nrsfm_swp_fit_batch(dib, B, maxP, maxN, max_it, st));
+  HIPCHK(c, nrsfm_swp_fit_batch(dib, B, maxP, maxN, max_it, with_init, st));
   HIPCHK(c, hipMemcpyAsync(c->pin_out.p, dob, out_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   const char* ho = c->pin_out.p;
@@ -196,6 +212,7 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
     std::memcpy(q.x, ho + o.xo, 8 * n2);
     if (q.diff) { std::memcpy(q.diff, ho + o.diff, 72 * (size_t)q.P); std::memcpy(q.drop, ho + o.drop, (size_t)q.P); }
     std::memcpy(q.info, ho + o.info, sizeof q.info);
+    std::memcpy(&q.init_ok, ho + o.info + sizeof q.info, sizeof q.init_ok);
     std::memcpy(q.costs, ho + o.costs, sizeof q.costs);
   }
   return DSH_OK;

@@ -89,6 +89,11 @@ void bending_dense(const dsh_bbs* b, double lambda, double* Bm) {
 bool bbs_ok(const dsh_bbs* b) { return b && b->nptsu >= 4 && b->nptsv >= 4 && b->umax > b->umin && b->vmax > b->vmin; }
 }  // namespace
 
+namespace dsh {
+// dense N x N bending matrix of the grid (used by the batched Schwarp fit for its Warp::initialize stage, dsh_schwarp.cpp)
+void bbs_bending_dense(const dsh_bbs* b, double lambda, double* Bm) { bending_dense(b, lambda, Bm); }
+}  // namespace dsh
+
 extern "C" {
 
 int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending) {

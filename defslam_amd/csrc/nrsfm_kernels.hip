@@ -762,8 +762,8 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
 
 // Substitutions only, with the factor left in M / Winv by swp_solve_kernel: M dx = -g (iterative refinement of the
 // Shape-from-Normals least squares).  One workgroup, np <= 512.
-__global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, int il, int bwt, const double* __restrict__ g, const double* __restrict__ M,
-                                                          const double* __restrict__ Winv, double* __restrict__ dx) {
+__device__ __forceinline__ void swp_resolve_body(int n, int np, int il, int bwt, const double* __restrict__ g, const double* __restrict__ M,
+                                                 const double* __restrict__ Winv, double* __restrict__ dx) {
   __shared__ double yv[512];
   const int tid = threadIdx.x, NT = np / 16;
   yv[tid] = 0.0;
@@ -818,6 +818,10 @@ __global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, int il,
   }
   if (tid < n) dx[tid] = yv[swp_perm(n, il, tid)];
 }
+__global__ __launch_bounds__(512) void swp_resolve_kernel(int n, int np, int il, int bwt, const double* __restrict__ g, const double* __restrict__ M,
+                                                          const double* __restrict__ Winv, double* __restrict__ dx) {
+  swp_resolve_body(n, np, il, bwt, g, M, Winv, dx);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Shape from Normals (Modules/Mapping/ShapeFromNormals.cc): stacked least squares [M; Bending; 1^T] x = [0; 0; N mean]
@@ -851,8 +855,8 @@ __global__ void sfn_rows_kernel(BbsPar p, int n, const double* __restrict__ u, c
 
 // Colocation rows of Warps::Warp::initialize (Schwarp.cc:136-139): C[k, :] = 16 B-spline weights of key point k (float32 pair),
 // rhs[k] = -kp2 coordinate `coord` (negated: swp_solve_kernel returns M dx = -g).  C is P x N row-major and zeroed beforehand.
-__global__ void warp_coloc_kernel(BbsPar p, int P, const float* __restrict__ kp1, const float* __restrict__ kp2, int N, double* __restrict__ Cm,
-                                  double* __restrict__ rhs0, double* __restrict__ rhs1) {
+__device__ __forceinline__ void warp_coloc_body(BbsPar p, int P, const float* __restrict__ kp1, const float* __restrict__ kp2, int N, double* __restrict__ Cm,
+                                                double* __restrict__ rhs0, double* __restrict__ rhs1) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   rhs0[k] = -(double)kp2[2 * k];
@@ -866,6 +870,10 @@ __global__ void warp_coloc_kernel(BbsPar p, int P, const float* __restrict__ kp1
   cubic_basis(0, nv, bv);
   for (int iu = 0; iu < 4; iu++)
     for (int iv = 0; iv < 4; iv++) Cm[(size_t)k * N + (iu + Iu) * p.nptsv + iv + Iv] = bu[iu] * bv[iv];
+}
+__global__ void warp_coloc_kernel(BbsPar p, int P, const float* __restrict__ kp1, const float* __restrict__ kp2, int N, double* __restrict__ Cm,
+                                  double* __restrict__ rhs0, double* __restrict__ rhs1) {
+  warp_coloc_body(p, P, kp1, kp2, N, Cm, rhs0, rhs1);
 }
 
 __global__ void mat_add_kernel(size_t n, const double* __restrict__ B, double* __restrict__ A) {
@@ -1083,6 +1091,11 @@ struct SwpFit {
   // trust-region state (Ceres LM as restated in dsh_schwarp.cpp / oracle/schwarp_oracle.c)
   double radius, nu, cost, cost0, change, old;
   int it, good, invalid, done, accepted, pending;   // pending: an accepted step was re-linearised, its max |g| has not been tested yet
+  // optional first stage, Warps::Warp::initialize (Schwarp.cc:99-160): x = the regularised linear fit of the warp with this bending
+  // matrix (N x N, shared by the fits of one grid and weight; NULL: x holds the caller's start value).  It borrows the buffers of
+  // the fit: C in J, the two right-hand sides in r, C^T C + Bending in A, C^T kp2 in g, the factor in M / W.
+  const double* bend;
+  int npi, bwti;                 // padded size and band width (in tiles) of the N x N system
 };
 #define SWP_STAGE_ALWAYS 0      // setup stages: run for every fit
 #define SWP_STAGE_ACTIVE 1      // stages of an iteration: skipped once the fit is done
@@ -1145,6 +1158,51 @@ __global__ void swpb_diffprop_kernel(const SwpFit* fits) {
   if (!f.diff || !f.drop) return;
   swp_diffprop_body(f.p, f.kp1, f.kp2, f.x, f.fx, f.fy, f.diff, f.drop);
 }
+// ---- Warp::initialize as a first stage of the batch (fits with f.bend) ----
+__global__ void wib_coloc_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.bend) return;
+  warp_coloc_body(BbsPar{f.p.umin, f.p.umax, f.p.vmin, f.p.vmax, f.p.nu, f.p.nv, 2, 0}, f.p.P, f.kp1, f.kp2, f.p.N, f.J, f.r, f.r + f.p.P);
+}
+__global__ __launch_bounds__(256) void wib_normal_kernel(const SwpFit* fits, int second, int nt) {   // C^T C and C^T (-kp2 coordinate)
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.bend) return;
+  swp_normal_body(f.p.P, f.p.N, nt, f.J, f.r + (second ? f.p.P : 0), f.cs, f.A, f.g + (second ? f.p.N : 0));
+}
+__global__ void wib_bend_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.bend) return;
+  const size_t tot = (size_t)f.p.N * f.p.N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) f.A[i] += f.bend[i];
+}
+__global__ __launch_bounds__(256) void wib_damp_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.z];
+  if (!f.bend || (int)blockIdx.y >= f.npi) return;
+  swp_damp_body(f.p.N, f.npi, 0, f.A, 1e300, f.M);
+}
+__global__ __launch_bounds__(512) void wib_solve_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.bend) return;
+  swp_solve_body(f.p.N, f.npi, 0, f.bwti, f.A, f.g, 1e300, f.M, f.W, f.x, f.scal + 2);
+}
+__global__ __launch_bounds__(512) void wib_resolve_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!f.bend) return;
+  swp_resolve_body(f.p.N, f.npi, 0, f.bwti, f.g + f.p.N, f.M, f.W, f.x + f.p.N);
+}
+// info[2] = the reference's verdict on the initialisation (positive definite system, finite control points); the scalars go back to
+// zero for the fit
+__global__ void wib_finish_kernel(const SwpFit* fits, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const SwpFit& f = fits[b];
+  if (!f.bend) { f.info[2] = 1; return; }
+  bool finite = true;
+  for (int i = 0; i < 2 * f.p.N; i++) finite = finite && isfinite(f.x[i]);
+  f.info[2] = ((f.scal[2] != 0.0 || f.scal[3] != 0.0) && finite) ? 1 : 0;
+  for (int i = 0; i < 16; i++) f.scal[i] = 0.0;
+}
+
 // x <- xn after an accepted step
 __global__ void swpb_accept_kernel(SwpFit* fits) {
   const SwpFit& f = fits[blockIdx.y];
@@ -1284,11 +1342,9 @@ extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, 
   const int bwt = min(NT - 1, (max(kd, 0) + 15) / 16);
   const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + np + 16);
   if (lds > 150 * 1024 || np > 512) return hipErrorInvalidValue;   // one thread per unknown in the backward substitution
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swp_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {   // the attribute is per device: set every time (microseconds) rather than cached per process
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swp_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
   }
   hipLaunchKernelGGL(swp_damp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, n2, np, interleave, A, radius, M);
   hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), lds, st, n2, np, interleave, bwt, A, g, radius, M, Winv, dx, out);
@@ -1311,7 +1367,7 @@ extern "C" size_t nrsfm_swp_fit_bytes() { return sizeof(SwpFit); }
 extern "C" void nrsfm_swp_fit_fill(void* host_slot, double umin, double umax, int nu, double vmin, double vmax, int nv, int P, double fxs, double fys, double lambda,
                                    float fx, float fy, int max_iters, const float* kp1, const float* kp2, const float* isg, double* x, double* xn, double* cs,
                                    double* g, double* dx, double* r, double* J, double* A, double* M, double* W, double* scal, float* diff, uint8_t* drop,
-                                   int32_t* info, double* costs) {
+                                   int32_t* info, double* costs, const double* bend) {
   SwpFit f{};
   f.p = SwpPar{umin, umax, vmin, vmax, fxs, fys, lambda, nu, nv, nu * nv, P};
   f.fx = fx; f.fy = fy;
@@ -1320,18 +1376,20 @@ extern "C" void nrsfm_swp_fit_fill(void* host_slot, double umin, double umax, in
   f.max_iters = max_iters;
   f.kp1 = kp1; f.kp2 = kp2; f.isg = isg; f.x = x; f.xn = xn; f.cs = cs; f.g = g; f.dx = dx; f.r = r; f.J = J; f.A = A; f.M = M; f.W = W; f.scal = scal;
   f.diff = diff; f.drop = drop; f.info = info; f.costs = costs;
+  f.bend = bend;
+  f.npi = nrsfm_swp_solve_np(nu * nv);
+  f.bwti = min(f.npi / 16 - 1, (3 * nv + 3 + 15) / 16);   // colocation and bending couple a 4 x 4 patch of control points
   memcpy(host_slot, &f, sizeof f);
 }
-extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int maxN, int max_iters, hipStream_t st) {
+extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int maxN, int max_iters, int with_init, hipStream_t st) {
   SwpFit* fits = static_cast<SwpFit*>(d_fits_v);
   const int maxn2 = 2 * maxN, maxnp = nrsfm_swp_solve_np(maxn2), NT = maxnp / 16;
   const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + maxnp + 16);
   if (lds > 150 * 1024 || maxnp > 512) return hipErrorInvalidValue;
-  static size_t configured = 0;
-  if (lds > configured) {
+  {   // the attribute is per device: set every time (microseconds) rather than cached per process
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swpb_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(wib_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
   }
   const int nt = (maxn2 + 15) / 16, tiles = nt * (nt + 1) / 2;
   const dim3 g_eval((maxP + maxN + 127) / 128, B), g_one(1, B);
@@ -1343,6 +1401,18 @@ extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int m
     hipLaunchKernelGGL(swpb_normal_kernel, dim3(tiles, B), dim3(256), 0, st, fits, stage, nt);
   };
   const dim3 g_ctl((B + 63) / 64);
+  if (with_init) {   // Warp::initialize for the fits that ask for it: same launches for everybody, a fit without it leaves at once
+    const int npi = nrsfm_swp_solve_np(maxN), nti = (maxN + 15) / 16, tiles_i = nti * (nti + 1) / 2;
+    hipLaunchKernelGGL(swpb_zero_j_kernel, dim3(64, B), dim3(256), 0, st, fits, SWP_STAGE_ALWAYS);
+    hipLaunchKernelGGL(wib_coloc_kernel, dim3((maxP + 127) / 128, B), dim3(128), 0, st, fits);
+    hipLaunchKernelGGL(wib_normal_kernel, dim3(tiles_i, B), dim3(256), 0, st, fits, 1, nti);
+    hipLaunchKernelGGL(wib_normal_kernel, dim3(tiles_i, B), dim3(256), 0, st, fits, 0, nti);
+    hipLaunchKernelGGL(wib_bend_kernel, dim3(32, B), dim3(256), 0, st, fits);
+    hipLaunchKernelGGL(wib_damp_kernel, dim3((npi + 255) / 256, npi, B), dim3(256), 0, st, fits);
+    hipLaunchKernelGGL(wib_solve_kernel, g_one, dim3(512), lds, st, fits);
+    hipLaunchKernelGGL(wib_resolve_kernel, g_one, dim3(512), 0, st, fits);
+  }
+  hipLaunchKernelGGL(wib_finish_kernel, g_ctl, dim3(64), 0, st, fits, B);
   // Jacobi scaling from the initial Jacobian (cs = 1 first), then the scaled linearisation of the start; a zero step measures |x|, max |g|
   linearise(SWP_STAGE_ALWAYS);
   hipLaunchKernelGGL(swpb_colscale_kernel, dim3((maxn2 + 127) / 128, B), dim3(128), 0, st, fits, SWP_STAGE_ALWAYS);

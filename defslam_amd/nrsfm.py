@@ -127,8 +127,9 @@ def calculateSchwarps(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot
 
 
 def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3):
-    """B fits in one call (dsh_schwarp_fit_batch).  problems: dicts with bbs (Bbs), kp1, kp2, invsig, fx_slot, fy_slot, lam, fx, fy, x0.
-    Returns a list of (x, diffprops, drop, info, costs) like calculateSchwarps."""
+    """B fits in one call (dsh_schwarp_fit_batch).  problems: dicts with bbs (Bbs), kp1, kp2, invsig, fx_slot, fy_slot, lam, fx, fy and
+    either x0 (start value) or init_lam (the fit starts from Warp::initialize with that bending weight, computed inside the call).
+    Returns a list of (x, diffprops, drop, info, costs) like calculateSchwarps; with init_lam the tuple ends with init_ok."""
     B = len(problems)
     arr = (_lib.SchwarpProblemC * B)()
     keep = []
@@ -136,7 +137,8 @@ def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3):
         kp1 = np.ascontiguousarray(q["kp1"], np.float32).reshape(-1, 2)
         kp2 = np.ascontiguousarray(q["kp2"], np.float32).reshape(-1, 2)
         isg = np.ascontiguousarray(q["invsig"], np.float32)
-        x = np.array(q["x0"], np.float64, copy=True)
+        init_lam = float(q.get("init_lam", 0.0))
+        x = np.array(q["x0"], np.float64, copy=True) if init_lam <= 0.0 else np.zeros(2 * q["bbs"].nptsu * q["bbs"].nptsv)
         P = kp1.shape[0]
         diff = np.zeros((P, 18), np.float32)
         drop = np.zeros(P, np.uint8)
@@ -148,8 +150,13 @@ def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3):
         a.fx_slot, a.fy_slot, a.lam, a.fx, a.fy = float(q["fx_slot"]), float(q["fy_slot"]), float(q["lam"]), float(q["fx"]), float(q["fy"])
         a.max_iters = int(q.get("max_iters", max_iters))
         a.x, a.diff, a.drop = _ptr(x, C.c_double), _ptr(diff, C.c_float), _ptr(drop, C.c_uint8)
+        a.init_lambda = init_lam
     ctx._check(ctx._L.dsh_schwarp_fit_batch(ctx._h, B, arr), "dsh_schwarp_fit_batch")
-    return [(keep[b][3], keep[b][4], keep[b][5].astype(bool), np.array(arr[b].info[:], np.int32), np.array(arr[b].costs[:])) for b in range(B)]
+    out = []
+    for b in range(B):
+        t = (keep[b][3], keep[b][4], keep[b][5].astype(bool), np.array(arr[b].info[:], np.int32), np.array(arr[b].costs[:]))
+        out.append(t + (bool(arr[b].init_ok),) if arr[b].init_lambda > 0.0 else t)
+    return out
 
 
 def bbs_bending(bbs: Bbs, lam: float) -> np.ndarray:

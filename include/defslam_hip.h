@@ -228,6 +228,10 @@ typedef struct dsh_schwarp_problem {
   uint8_t* drop;               /* P */
   int32_t info[2];             /* out: iterations, accepted steps */
   double costs[2];             /* out: initial, final cost */
+  double init_lambda;          /* > 0: x is an output only -- the fit starts from Warps::Warp::initialize (Schwarp.cc:99-160, see
+                                  dsh_warp_initialize below) with this bending weight, computed on the device as the first stage of the
+                                  batch; <= 0: x holds the caller's start value */
+  int32_t init_ok;             /* out: the verdict of that initialisation (1 when none was asked for) */
 } dsh_schwarp_problem;
 int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* problems);
 

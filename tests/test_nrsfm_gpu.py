@@ -173,6 +173,36 @@ def test_schwarp_fit_batch_equals_single_fits_and_the_oracle(gpu_ctx, oracle_mod
         np.testing.assert_array_equal(drb, dro)
 
 
+def test_schwarp_fit_batch_with_the_initialisation_inside(gpu_ctx):
+    """dsh_schwarp_problem.init_lambda: Warp::initialize runs as the first stage of the batch, on the device, for the fits that ask
+    for it (the others keep their start value): the same control points as dsh_warp_initialize followed by the same fit, bit for
+    bit, with mixed sizes and a fit without initialisation in the middle of the batch."""
+    from defslam_amd import nrsfm, synth
+    cases = [(300, 3, 0.1, 1e-2, True), (150, 5, 1.0, 1e-2, True), (500, 21, 1e-2, 0.0, False), (80, 22, 1e-2, 1.0, True), (25, 4, 0.5, 1e-4, True)]
+    probs, ref = [], []
+    for P, seed, lam, ilam, init in cases:
+        pr = synth.make_warp_problem(P, seed)
+        b = nrsfm.Bbs(*pr["bbs"])
+        q = dict(bbs=b, kp1=pr["kp1"], kp2=pr["kp2"], invsig=pr["invsig"], fx_slot=pr["fy"], fy_slot=pr["fx"], lam=lam, fx=pr["fx"], fy=pr["fy"], max_iters=3)
+        if init:
+            ok, x0 = nrsfm.WarpInitialize(gpu_ctx, b, pr["kp1"], pr["kp2"], ilam)
+            q["init_lam"] = ilam
+        else:
+            ok, x0 = True, pr["x0"]
+            q["x0"] = x0
+        probs.append(q)
+        ref.append((ok, nrsfm.calculateSchwarps(gpu_ctx, b, pr["kp1"], pr["kp2"], pr["invsig"], pr["fy"], pr["fx"], lam, pr["fx"], pr["fy"], x0, 3)))
+    res = nrsfm.calculateSchwarpsBatch(gpu_ctx, probs)
+    for (P, seed, lam, ilam, init), r, (ok, (xs, ds, drs, is_, cs)) in zip(cases, res, ref):
+        if init:
+            assert r[5] == ok
+        np.testing.assert_array_equal(r[0], xs)
+        np.testing.assert_array_equal(r[1].view(np.uint32), ds.view(np.uint32))
+        np.testing.assert_array_equal(r[2], drs)
+        np.testing.assert_array_equal(r[3], is_)
+        np.testing.assert_array_equal(r[4], cs)
+
+
 @pytest.mark.parametrize("n,seed,lam", [(600, 4, 1e-3), (150, 7, 0.05), (2500, 9, 1e-4)])
 def test_shape_from_normals_matches_oracle(gpu_ctx, oracle_mod, n, seed, lam):
     """ShapeFromNormals::estimate (SURVEY 8f rank 1): the device solves the stacked least squares by corrected semi-normal

@@ -86,6 +86,16 @@ def main():
         dtb = timeit(lambda: nrsfm.calculateSchwarpsBatch(ctx, probs, 3), max(2, args.reps // 4))
         out.append({"metric": "Schwarp fit keyframe pairs/s, batched (13x15 grid, 3 LM iterations, host buffers in/out)", "value": B / dtb, "unit": "fits/s", "pairs_per_call": B,
                     "matches": args.matches, "ms_per_call": 1e3 * dtb})
+    # the same with Warp::initialize inside the call (dsh_schwarp_problem.init_lambda) against one dsh_warp_initialize per pair before it
+    dt_init = timeit(lambda: nrsfm.WarpInitialize(ctx, wb, wp["kp1"], wp["kp2"], 1e-2), args.reps)
+    for B in (8, 64):
+        probs = []
+        for b in range(B):
+            q = synth.make_warp_problem(n_matches=args.matches, seed=100 + b)
+            probs.append(dict(bbs=nrsfm.Bbs(*q["bbs"]), kp1=q["kp1"], kp2=q["kp2"], invsig=q["invsig"], fx_slot=q["fy"], fy_slot=q["fx"], lam=1e-2, fx=q["fx"], fy=q["fy"], init_lam=1e-2))
+        dtb = timeit(lambda: nrsfm.calculateSchwarpsBatch(ctx, probs, 3), max(2, args.reps // 4))
+        out.append({"metric": "Schwarp initialise + fit keyframe pairs/s, batched with Warp::initialize inside the call", "value": B / dtb, "unit": "pairs/s",
+                    "pairs_per_call": B, "matches": args.matches, "ms_per_call": 1e3 * dtb, "ms_per_single_dsh_warp_initialize": 1e3 * dt_init})
     for r in out:
         print(json.dumps(r))
     ctx.close()
