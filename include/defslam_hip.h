@@ -108,8 +108,12 @@ int dsh_sft_solve(dsh_ctx* ctx, const dsh_sft_frame* frame, dsh_sft_result* resu
 /* Batched / device-resident form (independent problems against the current template):
  *   dsh_sft_batch_upload  packs B frames on the host and starts ONE asynchronous copy to HBM on dsh_stream
  *                         (the frame buffers may be reused as soon as it returns),
- *   dsh_sft_batch_run     launches the solve (asynchronous on dsh_stream); may be called
- *                         repeatedly -- every run restarts from the uploaded initial state,
+ *   dsh_sft_batch_run     launches the solve on dsh_stream; may be called repeatedly -- every run restarts from the uploaded
+ *                         initial state.  From 129 problems upwards it is one persistent kernel and returns at once.  Smaller
+ *                         batches (a tracked frame) run in latency mode: several workgroups per problem try consecutive
+ *                         dampings of a Levenberg-Marquardt iteration side by side, one launch per round, and the call
+ *                         returns when the problems have terminated (it reads their done flags between groups of launches);
+ *                         the results are bit-identical in both modes,
  *   dsh_sft_batch_download brings every result of the batch back with ONE copy (outlier classification, inlier count,
  *                         repError and the float32 map points are computed by the kernel) and waits for it.
  * To time the device work, record your own HIP events on dsh_stream() around dsh_sft_batch_run.
