@@ -272,14 +272,33 @@ def main():
     # ---- optional mode of the north star, measured next to the replicas: ONE joint problem, one patch per rank, shared camera,
     # RCCL all-reduce of the camera block (collective: every rank takes part)
     shared = None
+    shared_hung = False
     if not args.no_extra_legs and args.config == "C2" and args.dist_backend == "nccl":
-        try:
-            shared = shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch)
-        except Exception as e:  # noqa: BLE001
-            shared = {"error": f"{type(e).__name__}: {e}"}
-        ctx.batch_upload(frames, *regs, 1, 50)      # the legs below expect the replica batch
-        ctx.batch_run()
-        ctx.synchronize()
+        # The leg is a collective of the library's own RCCL communicator: with several ranks it runs under a watchdog, so that a rank
+        # that fails (or a communicator that cannot be formed on this node) costs this optional object, never the replica line above.
+        box = {}
+
+        def run_leg():
+            try:
+                box["r"] = shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch)
+            except Exception as e:  # noqa: BLE001
+                box["r"] = {"error": f"{type(e).__name__}: {e}"}
+
+        if world > 1:
+            import threading
+            th = threading.Thread(target=run_leg, daemon=True)
+            th.start()
+            th.join(timeout=120.0)
+            if th.is_alive():
+                box["r"] = {"error": "timeout: the shared-camera collective did not finish within 120 s on this rank"}
+                shared_hung = True
+        else:
+            run_leg()
+        shared = box.get("r")
+        if not shared_hung:
+            ctx.batch_upload(frames, *regs, 1, 50)      # the legs below expect the replica batch
+            ctx.batch_run()
+            ctx.synchronize()
 
     if rank == 0:
         # HBM traffic per launch: rocprofv3 PMC passes of exactly this configuration, carried with their provenance and dropped when the
@@ -346,7 +365,7 @@ def main():
         }
         if shared is not None:
             out["shared_camera"] = shared
-        if not args.no_extra_legs:
+        if not args.no_extra_legs and not shared_hung:   # (a context stuck in a hung collective cannot run the other legs)
             # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
             ctx.batch_upload(frames[:1], *regs, 1, 50)
             ctx.batch_run()
@@ -376,6 +395,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tmpl, m, args.cpu_seconds)
         flush_c_stdio()
         print(json.dumps(out), flush=True)
+    if shared_hung:
+        os._exit(0)   # the line is out; a thread is still inside the hung collective, a clean shutdown would wait for it
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
