@@ -25,7 +25,7 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
-extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
 #ifdef DSH_LAB
@@ -284,23 +284,29 @@ int run_once(dsh_ctx* c) {
   const int K = c->spec_k, B = c->B;
   HIPCHK(c, hipMemsetAsync(c->d_spec, 0, c->spec_bytes, c->stream));
   const int rounds_per_iter = (10 + K - 1) / K;
-  const int worst = c->max_iters_batch * rounds_per_iter + 1;
-  // First group: as many launches as the previous run of this context needed (tracking is coherent from frame to frame: usually
-  // exact), then the done flags are read back and rounds of two are added while a problem still runs.  Launches behind the end
-  // of a problem cost a few microseconds each (it leaves at the first instruction); a read-back costs a stream synchronisation.
-  int launched = 0, group = std::max(2, std::min(worst, c->spec_hint));
+  const int worst = c->max_iters_batch * rounds_per_iter;
+  // A round = a linearisation launch (verdict on the previous round; on a new iteration the lanes assemble H together) + a trial
+  // launch.  First group: as many rounds as the previous run of this context needed (tracking is coherent from frame to frame:
+  // usually exact), then the done flags are read back and rounds of two are added while a problem still runs.  Launches behind the
+  // end of a problem cost a few microseconds each (it leaves at the first instruction); a read-back costs a stream synchronisation.
+  auto launch = [&](int phase) { return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream); };
+  HIPCHK(c, launch(SFT_SPEC_INIT));
+  int rounds = 0, group = std::max(2, std::min(worst, c->spec_hint));
   HIPCHK(c, c->spec_done.ensure(sizeof(SftSpec) * (size_t)B, true));
   while (true) {
-    for (int i = 0; i < group && launched < worst; i++, launched++)
-      HIPCHK(c, sft_spec_launch(c->d_probs, c->d_spec, B, K, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream));
+    for (int i = 0; i < group && rounds < worst; i++, rounds++) {
+      HIPCHK(c, launch(SFT_SPEC_LIN));
+      HIPCHK(c, launch(SFT_SPEC_TRIAL));
+    }
+    HIPCHK(c, launch(SFT_SPEC_LIN));   // the verdict on the last round (and, unless the problem is finished, the next linearisation)
     HIPCHK(c, hipMemcpyAsync(c->spec_done.p, c->d_spec, sizeof(SftSpec) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const SftSpec* sp = reinterpret_cast<const SftSpec*>(c->spec_done.p);
     bool all_done = true;
     int needed = 0;
-    for (int b = 0; b < B; b++) { all_done = all_done && sp[b].done; needed = std::max(needed, sp[b].launches + 1); }
+    for (int b = 0; b < B; b++) { all_done = all_done && sp[b].done; needed = std::max(needed, sp[b].launches); }
     if (all_done) { c->spec_hint = needed; break; }
-    if (launched >= worst) return fail(c, DSH_ERR_STATE, "speculative trials: a problem did not terminate within its launch budget");
+    if (rounds >= worst) return fail(c, DSH_ERR_STATE, "speculative trials: a problem did not terminate within its launch budget");
     group = 2;
   }
   return DSH_OK;
@@ -627,6 +633,10 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
       h.xyz = (double*)(base + w.shadow_xyz); h.chi2_obs = (double*)(base + w.shadow_chi2);
       h.res = (SftResHdr*)(base + w.shadow_hdr); h.pose = ((SftResHdr*)(base + w.shadow_hdr))->pose;
       h.trace = nullptr; h.mappoint = nullptr; h.outlier = nullptr;
+      if (h.tile_mode == 1) {   // the lanes of a problem assemble one H together (each its share of the block rows) and all factor from it
+        const SftDev& h0 = c->h_probs[b];
+        h.Hc = h0.Hc; h.Hbord = h0.Hbord; h.Hcorner = h0.Hcorner;
+      }
     }
     c->h_probs[e] = h;
   }

@@ -483,7 +483,7 @@ __device__ __forceinline__ double group8_sum(double v) {
 }
 
 template <int NW, int CLS>
-__device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* out, const AsmRec<CLS>& ar) {
+__device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* out, const AsmRec<CLS>& ar, int part = 0, int nparts = 1) {
   // The pointers and scalars the gathers use, read once: wave-uniform values stay in scalar registers instead of being re-read
   // from the problem record (a scalar load + a wait that also drains the LDS counter) inside the loops.
   struct {
@@ -530,14 +530,17 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
     }
     return h;
   };
-  Hdr nxt = load_hdr(wave);
+  // (part, nparts): this workgroup takes every nparts-th round of its wavefronts -- the latency mode splits one assembly over the
+  // workgroups of a problem, which all write into the same H (sft_spec_kernel); 0, 1 = everything
+  const int I0 = wave + NW * part, dI = NW * nparts;
+  Hdr nxt = load_hdr(I0);
 
 #pragma unroll 1
-  for (int I = wave; I < ngroups; I += NW) {
+  for (int I = I0; I < ngroups; I += dI) {
     int a_lo, a_hi;
     group_nodes(I, a_lo, a_hi);
     Hdr cur = nxt;
-    nxt = load_hdr(I + NW);
+    nxt = load_hdr(I + dI);
     // element (r, c), c <= r, of H in the band / wide-tile layouts (and its mirror inside a diagonal tile, which is stored symmetric)
     auto put = [&](int r, int c, double v) {
       const size_t idx = h_index(P, r, c);
@@ -2311,12 +2314,12 @@ __device__ __forceinline__ void init_state(const SftDev& P) {
 // One linearisation: residuals + assembly records, then the normal equations.  The records and the staging tiles alias the
 // solver workspace (dead once H is assembled); their placement class is a template parameter (AsmRec).
 template <int NW, class F>
-__device__ __forceinline__ double linearise(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, F ph_residuals) {
+__device__ __forceinline__ double linearise(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, F ph_residuals, int part = 0, int nparts = 1) {
   double chi = 0.0;
   switch (P.lds_class) {
-    case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 2>(P, red, out, jp); break; }
-    case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 1>(P, red, out, jp); break; }
-    default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 0>(P, red, out, jp); break; }
+    case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 2>(P, red, out, jp, part, nparts); break; }
+    case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 1>(P, red, out, jp, part, nparts); break; }
+    default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 0>(P, red, out, jp, part, nparts); break; }
   }
   return chi;
 }
@@ -2485,7 +2488,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 // (no device-scope fences, no flags); results, state and decisions are bit-identical to sft_lm_kernel.
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K) {
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K, int phase) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int B = gridDim.x / K, b = blockIdx.x / K, j = blockIdx.x % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
@@ -2498,13 +2501,20 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
   double* panel = out + 32;
   const int tid = threadIdx.x;
   const int Dn = P.Dn;
+  // Three kinds of launches (the kernel boundary is the only synchronisation between the lanes of a problem):
+  //   SFT_SPEC_INIT   state and workspace (once);
+  //   SFT_SPEC_LIN    the controller over the trials of the last round, then -- on a new iteration -- the linearisation: every
+  //                   lane evaluates all edges (the records the gathers need, the same chi2 everywhere) and assembles ITS share
+  //                   of the block rows into the H the lanes of a tile-mode-1 problem share (the other storage modes: each its own H);
+  //   SFT_SPEC_TRIAL  the lane's trial of the rejection chain on the complete H.
   if (S.done) return;
-  const int L = S.launches, par = L & 1, prev = par ^ 1;
-  if (L == 0) {
+  const int L = S.launches, par = L & 1, prev = par ^ 1;   // L: completed trial rounds
+  if (phase == SFT_SPEC_INIT) {
     init_state<NT>(P);
-    if (tid == 0) { S.lambda = -1.0; S.ni = 2.0; S.nbad = 0; S.it = 0; S.qbase = 0; S.iters = 0; S.trials = 0; S.need_lin = 1; S.last_lane = 0; S.all_ok = 1; }
-    __syncthreads();
-  } else {
+    if (tid == 0) { S.lambda = -1.0; S.ni = 2.0; S.nbad = 0; S.it = 0; S.qbase = 0; S.iters = 0; S.trials = 0; S.need_lin = 1; S.last_lane = 0; S.all_ok = 1; S.pad = 0; }
+    return;
+  }
+  if (phase == SFT_SPEC_LIN && S.pad) {   // S.pad: a trial round is waiting for its verdict
     // ---- the controller over the K trials of the previous launch, in trial order (optimization_algorithm_levenberg.cpp:102-164)
     if (tid == 0) {
       double lam = S.lambda, ni = S.ni, chi_cur = S.chi_cur, rho = 0.0;
@@ -2580,11 +2590,20 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     } else if (tid == 0) {
       S.qbase = qmax; S.need_lin = 0;
     }
+    if (tid == 0) S.pad = 0;
     __syncthreads();
   }
-  // ---- this launch's work: (new iteration: linearise) + the lane's trial of the rejection chain
-  if (S.need_lin) {
-    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+  if (phase == SFT_SPEC_LIN) {
+    if (S.need_lin == 1) {   // a new iteration: linearise (this lane's share of the assembly)
+      const bool shared_h = P.tile_mode == 1;
+      const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {}, shared_h ? j : 0, shared_h ? K : 1);
+      if (tid == 0) { S.chi_cur = chi0; S.chi_ini = chi0; S.rho = 0.0; S.accepted = 0; S.all_ok = 1; S.need_lin = 2; }
+    }
+    return;
+  }
+  // ---- SFT_SPEC_TRIAL
+  if (S.need_lin == 1) return;   // (never: a linearisation launch always precedes)
+  if (S.need_lin == 2) {         // first trial round on a fresh linearisation: H is complete now
     if (S.it == 0) {
       double mx = 0.0;
       for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
@@ -2592,9 +2611,8 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
       mx = block_max(mx, red);
       if (tid == 0) { S.lambda = 1e-5 * mx; S.ni = 2.0; S.nbad = 0; }
     }
-    if (tid == 0) { S.chi_cur = chi0; S.chi_ini = chi0; S.rho = 0.0; S.accepted = 0; S.all_ok = 1; }
     __syncthreads();
-    if (tid == 0) S.lambda_start = S.lambda;
+    if (tid == 0) { S.lambda_start = S.lambda; S.need_lin = 0; }
   }
   __syncthreads();
   double lam = S.lambda, ni = S.ni;
@@ -2620,7 +2638,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     for (int k = 0; k < 7; k++) S.pose_bak[k] = P.pose[k];
   }
   if (!in_range) for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];
-  if (tid == 0) S.launches = L + 1;
+  if (tid == 0) { S.launches = L + 1; S.pad = 1; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2848,14 +2866,14 @@ extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, i
   return hipGetLastError();
 }
 
-extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
   const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
   if (lds > *configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_spec_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     *configured = lds;
   }
-  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K), dim3(512), lds, stream, d_probs, d_spec, K);
+  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K), dim3(512), lds, stream, d_probs, d_spec, K, phase);
   return hipGetLastError();
 }
 

@@ -63,11 +63,15 @@ struct SftSc {
 // dampings lambda, lambda nu, lambda nu 2nu, ... of the Levenberg-Marquardt rejection chain at the same time.  Every lane keeps
 // the controller state (identical by construction) and publishes its trial, double buffered by launch parity.
 #define SFT_SPEC_MAXK 4
+#define SFT_SPEC_INIT 0
+#define SFT_SPEC_LIN 1
+#define SFT_SPEC_TRIAL 2
 struct SftSpecRes { double chi_new, scale, lambda, ni, pose[8]; int32_t ok, valid; };
 struct SftSpec {
   double lambda, ni, chi_cur, chi_ini, lambda_start, rho;
   double pose_bak[8];
-  int32_t it, qbase, nbad, accepted, all_ok, iters, trials, done, launches, need_lin, last_lane, pad;
+  int32_t it, qbase, nbad, accepted, all_ok, iters, trials, done, launches, need_lin, last_lane, pad;   // launches: completed trial rounds; need_lin: 1 linearise,
+                                  // 2 linearised, lambda of the first iteration still to come; pad: a trial round waits for its verdict
   SftSpecRes res[2];
 };
 
