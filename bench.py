@@ -36,10 +36,14 @@ PROFILE_ROUND = "r02"
 
 def kernel_source_hash() -> str:
     """Identifies the device code a PMC traffic figure was measured on (profiles/<round>/traffic.json stores it)."""
+    import re
     h = hashlib.sha256()
     for name in ("sft_kernels.hip", "sft_wide.h", "tile_chol.h", "sft_problem.h"):
-        with open(os.path.join(ROOT, "defslam_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "defslam_amd", "csrc", name), "r", encoding="utf-8") as f:
+            src = f.read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # comments and layout do not change the device code
+        src = re.sub(r"//[^\n]*", "", src)
+        h.update(re.sub(r"\s+", " ", src).encode())
     return h.hexdigest()[:16]
 
 

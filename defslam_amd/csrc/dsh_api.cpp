@@ -496,8 +496,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     if (c->opt.speculate >= 1 && c->opt.speculate <= SFT_SPEC_MAXK) K = c->opt.speculate;   // lab builds only
     for (int b = 0; b < B; b++) if (c->packed[b].f.max_iters < 1) K = 1;
   }
-  // LDS of the assembly (it aliases the solver workspace): one staged tile row of H per wavefront, then the records a gather
-  // touches most often, as far as the budget goes (4 wavefronts: two problems share a CU's 160 KB)
+  // LDS of the assembly (it aliases the solver workspace): the records a gather touches most often, as far as the budget goes
+  // (4 wavefronts: two problems share a CU's 160 KB)
   size_t jl_doubles = 0;
   int max_kd = 0;
   const size_t lds_budget = ((nw == 4 ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
@@ -1018,7 +1018,7 @@ int dsh_lab_sft_phase_ms(dsh_ctx* c, int b, double* out8) {
   {   // sections of the assembly (shader-clock cycles of wave 0), printed for tuning runs
     double as[6];
     HIPCHK(c, hipMemcpy(as, c->h_probs[b].dbg + 32, sizeof(as), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[lab] assembly sections of problem %d, kcycles of wave 0: corner %.0f, diagonal gather %.0f, butterfly+finish %.0f, off-diagonal %.0f, flush %.0f; rounds %.0f\n",
+    std::fprintf(stderr, "[lab] assembly sections of problem %d, kcycles of wave 0: corner %.0f, diagonal gather %.0f, butterfly+finish %.0f, off-diagonal %.0f, round overhead %.0f; rounds %.0f\n",
                  b, as[0] * 1e-3, as[1] * 1e-3, as[2] * 1e-3, as[3] * 1e-3, as[4] * 1e-3, as[5]);
   }
   return DSH_OK;

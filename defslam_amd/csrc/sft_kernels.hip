@@ -41,7 +41,7 @@
   } while (0)
 #define PH_RESET() ph_t0__ = wall_clock64()
 // sections of the assembly (shader clock, wave 0): dbg[32] corner reduction, [33] diagonal gather, [34] butterfly + diagonal finish,
-// [35] off-diagonal blocks, [36] tile flush, [37] rounds
+// [35] off-diagonal blocks, [36] round overhead (header prefetch, loop), [37] rounds
 #define AS_T0() long long as_t0__ = clock64()
 #define AS_ADD(slot) do { const long long t1__ = clock64(); if (threadIdx.x == 0) P.dbg[slot] += (double)(t1__ - as_t0__); as_t0__ = t1__; } while (0)
 #else
@@ -457,13 +457,11 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
 // ------------------------------------------------------------------------------------------
 // Normal equations: one gather per 3x3 block, fixed contribution order (no atomics: a run is bit-reproducible).
 //
-// A wavefront owns one tile row of H at a time (16 scalar rows = the 5-7 active nodes whose rows touch it): 8 lanes per
-// diagonal block (observations, curvature, stretching, reference edge, the 6x3 camera block and b of that node), one lane
-// per off-diagonal block.  In tile mode 1 the blocks land in the wavefront's private LDS tiles and leave as whole 2 KB
-// tiles in accumulator order (one coalesced 32-byte store per lane and tile; the scattered 8-byte elements of a 3x3 block
-// would each dirty a quarter of a 32-byte sector).  No workgroup barrier inside: the wavefronts of a problem drift apart
-// and cover each other's gather latency.  A node whose three rows straddle two tile rows is gathered for both.
-// Other storage modes (wide tiles, row-major band) and oversized tile rows store the blocks straight to global memory.
+// A wavefront takes seven block rows (nodes) per round: 8 lanes per diagonal block (observations, curvature, stretching, reference
+// edge, the 6x3 camera block and b of that node), one lane per off-diagonal block of those rows.  In tile mode 1 a finished block
+// is stored as the nine doubles it consists of into the compact array P.Hc -- the factorisation gathers its 16x16 tiles from
+// there, nothing is padded to tiles in memory; the other storage modes (wide tiles, row-major band) store the elements into their
+// layout.  No workgroup barrier inside: the wavefronts of a problem drift apart and cover each other's gather latency.
 // ------------------------------------------------------------------------------------------
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -1551,7 +1549,7 @@ __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double*
     const int i = I - k;                             // its tile of block column k is (I, k): X slot i in 1..BT
     lds_double* Xp = XpB + par * (BT + 1) * TILE_LDS;
     lds_int* xflag = F + 2 + 10 * par;
-    const bool memwave = wave == (k & (BT - 1));     // factored column k: its ring row is free, it takes the global-memory duties
+    const bool memwave = wave == (k & (BT - 1));     // factored column k: its ring row holds tile row k+BT now, tile (k+BT, k) waits in araw_n
     // the wave that factored column k recycled its ring row with tile row k+BT right behind its Cholesky of the previous step
     // (below): tile (k+BT, k) is raw H and waits in araw_n
     if (k >= 0) {
@@ -2311,8 +2309,8 @@ __device__ __forceinline__ void init_state(const SftDev& P) {
   }
 }
 
-// One linearisation: residuals + assembly records, then the normal equations.  The records and the staging tiles alias the
-// solver workspace (dead once H is assembled); their placement class is a template parameter (AsmRec).
+// One linearisation: residuals + assembly records, then the normal equations.  The records alias the solver workspace in LDS (dead
+// once H is assembled); their placement class is a template parameter (AsmRec).  (part, nparts): see assemble.
 template <int NW, class F>
 __device__ __forceinline__ double linearise(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, F ph_residuals, int part = 0, int nparts = 1) {
   double chi = 0.0;
