@@ -65,11 +65,33 @@ def cpu_baseline(tmpl, m, budget_s):
         probs += 1
         D = int(r.dims[0])
     dt = time.perf_counter() - t0
-    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port", "runs": 1,
+    cpu = host_cpu()
+    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port", "runs": 1, "host_cpu": cpu["model"], "host_cores": cpu["cores"],
+            "host_threads": cpu["threads"],
             "sample": f"{probs} whole problems of the same workload (ids 0..{probs - 1}), each solved ONCE (BASELINE.md asks for a median of >= 20 runs; "
                       f"one 3.4 s dense-LDLT solve per problem is what the few-minute budget allows): {iters} LM iterations, {trials} dense LDLT trials, "
                       f"D={D}, {dt:.1f} s; oracle/sft_oracle.c ldlt_mode=0, 1 thread (reference binary not buildable: Eigen/OpenCV absent)",
             "lm_trials_per_s": trials / dt, "frames_per_s": probs / dt}
+
+
+def host_cpu():
+    """Model name and core / thread counts of the box the CPU baseline ran on (from lscpu)."""
+    info = {"model": "unknown", "cores": os.cpu_count() or 0, "threads": os.cpu_count() or 0}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for ln in txt.splitlines():
+            if ":" in ln:
+                k, v = ln.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name", info["model"])
+        threads = int(kv.get("CPU(s)", info["threads"]))
+        tpc = int(kv.get("Thread(s) per core", "1") or 1)
+        info["threads"] = threads
+        info["cores"] = threads // max(tpc, 1)
+    except Exception:  # noqa: BLE001
+        pass
+    return info
 
 
 def flush_c_stdio():
@@ -90,11 +112,15 @@ def free_port() -> int:
     return port
 
 
-def spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks here.  Fails loudly when the node has fewer devices."""
+def spawn_ranks(n: int, dry: bool = False) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here.  Fails loudly when the node has fewer devices
+    (unless --dry-ranks asked for a rehearsal of the N-rank path on the devices that exist)."""
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < 1:
+        print("bench.py: no GPU visible", file=sys.stderr)
+        return 2
+    if have < n and not dry:
         print(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to report an {n}-GPU number from fewer devices", file=sys.stderr)
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -196,7 +222,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank); gloo only to exercise the multi-rank path on a single GPU")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="testing aid: every rank uses this device index instead of LOCAL_RANK")
+    ap.add_argument("--dry-ranks", type=int, default=0, help="rehearsal of the N-rank launch on however many GPUs exist: N ranks, rank r on device r mod #GPUs, the real "
+                                                             "nccl (RCCL) backend when every rank has its own GPU and gloo otherwise (RCCL refuses two ranks of one communicator "
+                                                             "on one device); a per-rank memory guard shrinks the batch to what the shared device holds; the line says dry_ranks")
+    ap.add_argument("--shared-camera", default="auto", choices=["auto", "on", "off"], help="the optional joint-problem leg (library-owned RCCL communicator): auto = on with one "
+                                                                                            "rank, off with several (a collective that has not run on this node yet must not cost the replica line)")
     args = ap.parse_args()
+    if args.dry_ranks > 0:
+        args.gpus = args.dry_ranks
     if args.batch <= 0:
         args.batch = {"C2": 16384, "C5": 16, "smoke": 512}[args.config]
     if args.gpus < 1:
@@ -204,7 +237,7 @@ def main():
         sys.exit(2)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus))
+        sys.exit(spawn_ranks(args.gpus, dry=args.dry_ranks > 0))
 
     import torch
     from defslam_amd import sft, synth
@@ -215,8 +248,16 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to mislabel the run", file=sys.stderr)
         sys.exit(2)
+    ranks_per_device = 1
     if args.all_ranks_on_device >= 0:
         local_rank = args.all_ranks_on_device
+        ranks_per_device = world
+    elif args.dry_ranks > 0:
+        ndev = max(torch.cuda.device_count(), 1)
+        ranks_per_device = -(-world // ndev)
+        local_rank = local_rank % ndev
+        if ndev < world and args.dist_backend == "nccl":
+            args.dist_backend = "gloo"      # RCCL: "duplicate GPU detected" for two ranks of one communicator on one device
     elif torch.cuda.device_count() <= local_rank:
         print(f"bench.py: rank {rank} needs GPU {local_rank} but the node exposes {torch.cuda.device_count()}", file=sys.stderr)
         sys.exit(2)
@@ -233,6 +274,14 @@ def main():
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
+    # per-rank memory guard: the batch arena is one hipMalloc (C2: 2.6 MB per problem = 42 GB at 16384); ranks that share a device share its HBM
+    batch_asked = args.batch
+    if torch.cuda.is_available():
+        free_b, _ = torch.cuda.mem_get_info(local_rank)
+        per_problem = {"C2": 2.7e6, "C5": 60e6, "smoke": 0.5e6}[args.config]
+        fit = int(0.8 * free_b / ranks_per_device / per_problem)
+        if fit < args.batch:
+            args.batch = max(1, fit)
     rows, cols, m = synth.CONFIGS[args.config]
     regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     tmpl = synth.make_grid_template(rows, cols)
@@ -265,10 +314,13 @@ def main():
     tot = torch.tensor([iters, trials, args.batch], dtype=torch.float64, device=red_dev)
     devs = torch.zeros(max(world, 1), dtype=torch.float64, device=red_dev)
     devs[rank] = 1.0 + local_rank                   # which device every rank computed on
+    rank_ms = torch.zeros(max(world, 1), dtype=torch.float64, device=red_dev)
+    rank_ms[rank] = 1e3 * wall / args.steps         # every rank's own wall clock per step
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(devs, op=dist.ReduceOp.SUM)
+        dist.all_reduce(rank_ms, op=dist.ReduceOp.SUM)
     wall = float(wall_t.item())
     g_iters, g_trials, g_problems = (float(v) for v in tot.tolist())
     n_gpus = len(set(int(v) for v in devs.tolist()))   # distinct devices behind the ranks the collective saw
@@ -277,13 +329,15 @@ def main():
     # RCCL all-reduce of the camera block (collective: every rank takes part)
     shared = None
     shared_hung = False
-    if not args.no_extra_legs and args.config == "C2" and args.dist_backend == "nccl":
+    want_shared = args.shared_camera == "on" or (args.shared_camera == "auto" and world == 1)
+    if want_shared and not args.no_extra_legs and args.config == "C2" and args.dist_backend == "nccl":
         # The leg is a collective of the library's own RCCL communicator: with several ranks it runs under a watchdog, so that a rank
         # that fails (or a communicator that cannot be formed on this node) costs this optional object, never the replica line above.
         box = {}
 
         def run_leg():
             try:
+                torch.cuda.set_device(local_rank)   # the current device is per THREAD (default 0): without this every rank's tensors land on GPU 0
                 box["r"] = shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch)
             except Exception as e:  # noqa: BLE001
                 box["r"] = {"error": f"{type(e).__name__}: {e}"}
@@ -295,6 +349,18 @@ def main():
             th.join(timeout=120.0)
             if th.is_alive():
                 box["r"] = {"error": "timeout: the shared-camera collective did not finish within 120 s on this rank"}
+                shared_hung = True
+            # every rank learns whether ANY rank hung -- through the rendezvous store (TCP), not through a collective that may sit
+            # behind the hung one -- so that all ranks take the same exit below
+            try:
+                store = dist.distributed_c10d._get_default_store()
+                store.set(f"bench_shared_hung_{rank}", "1" if shared_hung else "0")
+                for r in range(world):
+                    key = f"bench_shared_hung_{r}"
+                    store.wait([key], __import__("datetime").timedelta(seconds=150))
+                    if store.get(key) == b"1":
+                        shared_hung = True
+            except Exception:  # noqa: BLE001  (a rank that never reports is a hung rank)
                 shared_hung = True
         else:
             run_leg()
@@ -348,7 +414,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: single-frame SfT, {rows * cols}-node template ({rows}x{cols}), {m} matches, 640x480",
                        "problems_per_gpu": args.batch, "parallelism": f"{world} x independent problems (no collective)",
-                       "max_lm_iters": 50, "regularisers": list(regs), "wavefronts_per_problem": int(counts[7]), "ranks": world},
+                       "max_lm_iters": 50, "regularisers": list(regs), "wavefronts_per_problem": int(counts[7]), "ranks": world,
+                       "ranks_per_device": ranks_per_device, "dist_backend": args.dist_backend if world > 1 else None,
+                       "dry_ranks": args.dry_ranks > 0, "problems_per_gpu_asked": batch_asked},
+            "rank_ms_per_step": [float(v) for v in rank_ms.tolist()],
             "frames_per_s": g_problems * args.steps / wall,
             "lm_trials_per_s": g_trials * args.steps / wall,
             "iters_per_frame": g_iters / g_problems,
@@ -377,7 +446,8 @@ def main():
             ms1 = ctx.batch_run_timed(5) / 5
             it1, tr1 = ctx.batch_counts()
             out["latency"] = {"single_problem_iters_per_s": it1 / (ms1 * 1e-3), "ms_per_frame": ms1, "iters": it1, "trials": tr1,
-                              "what": "kernel only, inputs resident (HIP events); the end-to-end frame is in `e2e`"}
+                              "what": "device timeline of the latency mode, inputs resident (HIP events on the library's stream): the speculative-lane launches "
+                                      "INCLUDING the host's read-backs of the done flags between groups of launches; the end-to-end frame is in `e2e`"}
             if args.config == "C2":
                 out["e2e"] = e2e_legs(ctx, tmpl, m, frames, regs)
             # the Jacobian assembly on its own: launches that do one linearisation + normal-equation assembly per problem (measurement

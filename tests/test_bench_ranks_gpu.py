@@ -39,3 +39,23 @@ def test_asking_for_more_gpus_than_the_node_has_fails_loudly():
     assert r.returncode == 2
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_dry_ranks_rehearses_the_n_rank_launch_on_the_devices_that_exist():
+    """`--dry-ranks N`: the script spawns N ranks itself, rank r on device r mod #GPUs, RCCL when every rank has its own GPU and gloo
+    otherwise; the line carries the ranks, the distinct devices, the per-rank step times and says that it was a rehearsal."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-ranks", "2", "--steps", "1", "--warmup", "1", "--batch", "128",
+                        "--no-cpu-baseline", "--no-extra-legs"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    import torch
+    ndev = torch.cuda.device_count()
+    assert d["config"]["ranks"] == 2 and d["config"]["dry_ranks"] is True
+    assert d["n_gpus"] == min(2, ndev)
+    assert d["config"]["ranks_per_device"] == -(-2 // ndev)
+    assert d["config"]["dist_backend"] == ("nccl" if ndev >= 2 else "gloo")
+    assert len(d["rank_ms_per_step"]) == 2 and all(v > 0 for v in d["rank_ms_per_step"])
+    assert abs(max(d["rank_ms_per_step"]) - d["ms_per_step"]) < 0.25 * d["ms_per_step"]
