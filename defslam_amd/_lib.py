@@ -10,9 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DSH_LIB_PATH: development override to A/B two builds of the same library on one GPU box
-LIB_PATH = os.environ.get("DSH_LIB_PATH") or os.path.join(_HERE, "lib", "libdefslam_hip.so")
-LAB_LIB_PATH = os.environ.get("DSH_LAB_LIB_PATH") or os.path.join(_HERE, "lib", "libdefslam_hip_lab.so")
+# The in-tree libraries, always: neither this binding nor the .so reads environment variables (tools that A/B two builds assign
+# _lib.LIB_PATH / _lib.LAB_LIB_PATH before the first load()).
+LIB_PATH = os.path.join(_HERE, "lib", "libdefslam_hip.so")
+LAB_LIB_PATH = os.path.join(_HERE, "lib", "libdefslam_hip_lab.so")
 
 DSH_OK = 0
 DSH_TRACE_STRIDE = 8

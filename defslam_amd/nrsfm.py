@@ -202,6 +202,28 @@ def WarpInitialize(ctx: Context, bbs: Bbs, kp1, kp2, lam: float):
     return bool(ok.value), x
 
 
+def CalculateInitialSchwarp(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx, fy, lam: float):
+    """DefORBmatcher::CalculateInitialSchwarp (DefORBmatcher.cc:111-187): Warp::initialize, NaN control points of the first
+    2 NCu NCu entries -> 0, then the residuals the reference reads from ceres::Problem::Evaluate -- loss-corrected by HuberLoss(5.77)
+    (Corrector with rho'' <= 0: the one 2P-residual block times sqrt(rho'(|r|^2))) -- and its test residuals[2i]^2 + residuals[2i+1]^2 > 20.
+    Returns (x[2N], outlier[P] bool, corrected residuals[2P])."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    P = kp1.shape[0]
+    _, x = WarpInitialize(ctx, bbs, kp1, kp2, lam)
+    nz = min(x.size, 2 * bbs.nptsu * bbs.nptsu)
+    x[:nz][np.isnan(x[:nz])] = 0.0
+    res, _ = schwarp_eval(ctx, bbs, kp1, kp2, invsig, fx, fy, 0.0, x, want_jacobian=False)
+    r = res[:2 * P].copy()
+    s = 0.0
+    for v in r:                       # index-order sum, like the shim
+        s += v * v
+    if s > 5.77 * 5.77:
+        r *= np.sqrt(5.77 / np.sqrt(s))
+    i = np.arange(P)
+    err = r[2 * i] ** 2 + r[2 * i + 1] ** 2 if P else np.zeros(0)
+    return x, err > 20, r
+
+
 def searchBySchwarp(ctx: Context, bbs: Bbs, x, kp1, desc1, cam2, bounds2, kp2, desc2, has_mp2, radius: float = 2.0, th_low: int = 50, grid=(64, 48)):
     """DefORBmatcher::searchBySchwarp: returns match[Q] (index into keyframe 2 or -1)."""
     x = np.ascontiguousarray(x, np.float64)

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <set>
 #include <vector>
 
@@ -37,6 +38,7 @@ class TemplateBinding {
     if (tmpl == bound_ && ctx == ctx_) return DSH_OK;
     nodes_.clear();
     index_.clear();
+    facet_ids_.clear();
     for (NodeT* n : tmpl->getNodes()) {                        // Template.h:87
       index_[n] = (int32_t)nodes_.size();
       nodes_.push_back(n);
@@ -52,12 +54,27 @@ class TemplateBinding {
   }
   const std::vector<NodeT*>& nodes() const { return nodes_; }
   int32_t index_of(NodeT* n) const { return index_.at(n); }
+  // node ids of a facet in the order its std::set<Node*> iterates (the order the barycentrics b1..b3 refer to, DefOptimizer.cc:315-333),
+  // looked up once per facet and template instead of three std::map searches per observation and frame
+  template <class FacetT>
+  const int32_t* facet_nodes(FacetT* f) {
+    auto it = facet_ids_.find(f);
+    if (it == facet_ids_.end()) {
+      FacetIds ids{{0, 0, 0}};
+      int k = 0;
+      for (NodeT* nd : f->getNodes()) ids.v[k++] = index_.at(nd);
+      it = facet_ids_.emplace(f, ids).first;
+    }
+    return it->second.v;
+  }
 
  private:
+  struct FacetIds { int32_t v[3]; };
   TemplateT* bound_ = nullptr;
   dsh_ctx* ctx_ = nullptr;
   std::vector<NodeT*> nodes_;
   std::map<NodeT*, int32_t> index_;
+  std::map<const void*, FacetIds> facet_ids_;
 };
 
 // Shape-from-template with camera motion estimation for one frame.  `binding` lives as long as the tracker (one per map).
@@ -70,6 +87,9 @@ int DefPoseOptimizationHIP(dsh_ctx* ctx, TemplateBinding<TemplateT, NodeT>& bind
   const int n = (int)nodes.size();
   // setMeshNodes (DefOptimizer.cc:926-952): vertex ids 1..n in set order; our node id is the vertex id minus one
   for (int i = 0; i < n; i++) nodes[i]->setIndex((unsigned)(i + 1));   // Node.h:68
+  // The reference holds MapPoint::mGlobalMutex from here to the end of the function (DefOptimizer.cc:287): map points are read
+  // (facets, barycentrics) and moved (RecalculatePosition) below while the mapping thread may be creating or culling them.
+  std::unique_lock<decltype(DefMapPointT::mGlobalMutex)> lock(DefMapPointT::mGlobalMutex);
   // ---- observations (DefOptimizer.cc:293-361): key points that are not flagged, with a map point that is not bad and lies on a facet
   const int N = pFrame->N;
   std::vector<int32_t> obs_nodes;
@@ -86,10 +106,11 @@ int DefPoseOptimizationHIP(dsh_ctx* ctx, TemplateBinding<TemplateT, NodeT>& bind
     nInitialCorrespondences++;
     pFrame->mvbOutlier[i] = false;
     const double bary[3] = {dMP->b1, dMP->b2, dMP->b3};        // DefMapPoint.h:96, in the order the facet's node set iterates (:315-333)
-    int k = 0;
-    for (NodeT* nd : dMP->getFacet()->getNodes()) {
-      obs_nodes.push_back(binding.index_of(nd));
-      obs_bary.push_back(bary[k++]);
+    const int32_t* ids = binding.facet_nodes(dMP->getFacet());
+    for (int k = 0; k < 3; k++) {
+      NodeT* nd = nodes[ids[k]];
+      obs_nodes.push_back(ids[k]);
+      obs_bary.push_back(bary[k]);
       ViewedNodes.insert(nd);
       nd->setViewed();                                         // Node.h:102 (DefOptimizer.cc:332)
     }

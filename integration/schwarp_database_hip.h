@@ -83,7 +83,7 @@ class SchwarpDatabaseHIP : public Base {
     DefKeyFrameT* KF2 = static_cast<DefKeyFrameT*>(Kf2);
     const dsh_bbs bbs = bbs_of(KF, KF->valdim);
     // ---- CalculateInitialSchwarp (DefORBmatcher.cc:111-187): Warp::initialize, NaN control points -> 0, then the matches whose
-    // squared reprojection residual (Warp cost function with (fx, fy), unrobustified) exceeds 20 are removed
+    // squared (loss-corrected, see below) reprojection residual of the Warp cost function with (fx, fy) exceeds 20 are removed
     std::vector<float> k1, k2, isg;
     gather(KF, KF2, vMatchedIndices, k1, k2, isg);
     const int P = (int)vMatchedIndices.size();
@@ -99,6 +99,17 @@ class SchwarpDatabaseHIP : public Base {
     std::vector<double> res(2 * (size_t)P + 4 * (size_t)Nc);
     status_ = dsh_schwarp_eval(ctx_, &bbs, P, k1.data(), k2.data(), isg.data(), (double)KF->fx, (double)KF->fy, 0.0, x.data(), res.data(), nullptr);
     if (status_ != DSH_OK) return;
+    // The reference reads the residuals from ceres::Problem::Evaluate with default EvaluateOptions (DefORBmatcher.cc:155-166):
+    // apply_loss_function is true, so the ONE residual block of 2P entries comes back loss-corrected by HuberLoss(5.77) -- Ceres'
+    // Corrector with rho'' <= 0 scales the block by sqrt(rho'(s)), s = |r|^2: 1 for s <= 5.77^2, sqrt(5.77 / |r|) beyond.
+    {
+      double s = 0.0;
+      for (int i = 0; i < 2 * P; i++) s += res[i] * res[i];
+      if (s > 5.77 * 5.77) {
+        const double sc = std::sqrt(5.77 / std::sqrt(s));
+        for (int i = 0; i < 2 * P; i++) res[i] *= sc;
+      }
+    }
     // Warp::Evaluate lays the residuals out as [x_0 .. x_{P-1}, y_0 .. y_{P-1}] (Schwarp.cc:277-282) and the reference tests
     // residuals[2 i]^2 + residuals[2 i + 1]^2 for match i (DefORBmatcher.cc:167-175): entries 2i and 2i+1 of that array, i.e. two
     // neighbouring x- (or y-) residuals, not the two components of match i.  Which matches go is observable behaviour: reproduced.

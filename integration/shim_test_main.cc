@@ -13,6 +13,7 @@
 #include "standin_types.h"
 
 using namespace standin;
+CountingMutex standin::MapPoint::mGlobalMutex;
 
 int main(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: %s in out matches [device]\n", argv[0]); return 2; }
@@ -80,7 +81,9 @@ int main(int argc, char** argv) {
   const int inliers = defslam_hip::DefPoseOptimizationHIP<Frame, DefMap, Template, Node, DefMapPoint>(ctx, binding, &frame, &map, RegLap, RegInex, RegTemp, layers);
   std::ofstream out(argv[2]);
   out << std::setprecision(17);
-  out << inliers << " " << frame.repError << " " << frame.pose_sets << "\n";
+  int under_lock = 0;
+  for (auto* p : map.points) under_lock += static_cast<DefMapPoint*>(p)->recalculated_under_lock;
+  out << inliers << " " << frame.repError << " " << frame.pose_sets << " " << MapPoint::mGlobalMutex.locks << " " << (int)MapPoint::mGlobalMutex.held << " " << under_lock << "\n";
   for (int i = 0; i < 16; i++) out << frame.mTcw[i] << (i == 15 ? "\n" : " ");
   for (int i = 0; i < n; i++) {
     double x, y, z;

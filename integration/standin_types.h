@@ -50,11 +50,25 @@ class Template {                               // Modules/Template/Template.h
   std::set<Facet*> facets;
 };
 
+// std::mutex that counts its lock() calls and can tell whether it is held: lets the CI check that the shim takes
+// MapPoint::mGlobalMutex once per call and holds it while map points are moved (DefOptimizer.cc:287)
+class CountingMutex {
+ public:
+  void lock() { m_.lock(); locks++; held = true; }
+  void unlock() { held = false; m_.unlock(); }
+  bool try_lock() { if (!m_.try_lock()) return false; locks++; held = true; return true; }
+  int locks = 0;
+  bool held = false;
+ private:
+  std::mutex m_;
+};
+
 class MapPoint {                               // ORB_SLAM2 MapPoint
  public:
   virtual ~MapPoint() = default;
   bool isBad() { return bad; }
   bool bad = false;
+  static CountingMutex mGlobalMutex;           // MapPoint.h:115 (static std::mutex mGlobalMutex)
 };
 
 class DefMapPoint : public MapPoint {          // Modules/Common/DefMapPoint.h
@@ -72,11 +86,12 @@ class DefMapPoint : public MapPoint {          // Modules/Common/DefMapPoint.h
     }
     for (int c = 0; c < 3; c++) mWorldPos[c] = (float)p[c];
     recalculated++;
+    if (mGlobalMutex.held) recalculated_under_lock++;
   }
   Facet* facet = nullptr;
   double b1 = 0, b2 = 0, b3 = 0;                                         // :96
   float mWorldPos[3] = {0, 0, 0};
-  int recalculated = 0;
+  int recalculated = 0, recalculated_under_lock = 0;
 };
 
 struct Point2f { float x, y; };

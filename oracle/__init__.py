@@ -327,6 +327,24 @@ def schwarp_eval(bbs, kp1, kp2, invsig, fxs, fys, lam, x, want_jacobian=True):
     return r, J
 
 
+def schwarp_eval_initial(bbs, kp1, kp2, invsig, fx, fy, x):
+    """The residuals DefORBmatcher::CalculateInitialSchwarp reads (DefORBmatcher.cc:155-175): ceres::Problem::Evaluate of the Warp block
+    under HuberLoss(5.77) with the default apply_loss_function = true, i.e. loss-corrected.  Returns (residuals[2P], cost)."""
+    L = lib()
+    umin, umax, nu, vmin, vmax, nv, _ = bbs
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    invsig = np.ascontiguousarray(invsig, np.float32)
+    x = np.ascontiguousarray(x, np.float64)
+    P = kp1.shape[0]
+    r = np.zeros(2 * P)
+    D = C.c_double
+    L.schwarp_oracle_eval_initial.restype = D
+    cost = L.schwarp_oracle_eval_initial(D(umin), D(umax), int(nu), D(vmin), D(vmax), int(nv), P, _p(kp1, C.c_float), _p(kp2, C.c_float), _p(invsig, C.c_float),
+                                         D(fx), D(fy), _p(x, D), _p(r, D))
+    return r, float(cost)
+
+
 def schwarp_fit(bbs, kp1, kp2, invsig, fxs, fys, lam, fx, fy, x0, max_iters=3):
     L = lib()
     umin, umax, nu, vmin, vmax, nv, _ = bbs

@@ -9,7 +9,7 @@
  *   tensor-product evaluation ............ Thirdparty/BBS/bbs.cc:155-195
  *   colocation weights (16 taps / site) .. Thirdparty/BBS/bbs.cc:214-355
  *
- * PARITY PINNED: tests/test_oracle_bbs.py checks this file bit-for-bit against the
+ * PARITY PINNED: tests/test_oracle_nrsfm.py (test_bbs_oracle_*) checks this file bit-for-bit against the
  * reference's own bbs.cc compiled into oracle/_ref/libbbs_ref.so (built by oracle/Makefile
  * from /root/reference, never copied) and against the golden vectors generated from it
  * (tests/golden/bbs_*.npz, tests/golden/make_golden_bbs.py).

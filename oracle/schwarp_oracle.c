@@ -145,6 +145,26 @@ void schwarp_oracle_eval(double umin, double umax, int nu, double vmin, double v
 
 #define HUBER_A 5.77 /* SchwarpDatabase.cc:208 */
 
+/* ceres::Problem::Evaluate(EvaluateOptions(), &cost, &residuals, ...) of the problem CalculateInitialSchwarp builds
+ * (DefORBmatcher.cc:155-166): ONE residual block (Warps::Warp, 2P residuals) under HuberLoss(5.77), apply_loss_function = true
+ * (the default), so the residuals come back loss-corrected.  Ceres' Corrector (corrector.cc): for rho'' <= 0 -- Huber beyond its
+ * threshold has rho'' = -a / (2 s^1.5) -- the block is scaled by sqrt(rho'(s)), s = |r|^2; rho' = 1 up to s = a^2, a / sqrt(s) beyond.
+ * out[0 .. 2P): the corrected residuals; returns the cost 1/2 rho(s). */
+double schwarp_oracle_eval_initial(double umin, double umax, int nu, double vmin, double vmax, int nv, int P, const float* kp1, const float* kp2,
+                                   const float* invsig, double fxs, double fys, const double* x, double* out) {
+  swp_t s = {umin, umax, vmin, vmax, nu, nv, nu * nv, P, kp1, kp2, invsig, fxs, fys, 0.0};
+  double* r = (double*)malloc(sizeof(double) * (2 * (size_t)P + 4 * (size_t)s.N));
+  swp_eval(&s, x, r, 0);
+  double sq = 0.0;
+  for (int i = 0; i < 2 * P; i++) sq += r[i] * r[i];
+  double rho0 = sq, rho1 = 1.0;
+  if (sq > HUBER_A * HUBER_A) { const double rt = sqrt(sq); rho0 = 2 * HUBER_A * rt - HUBER_A * HUBER_A; rho1 = HUBER_A / rt; }
+  const double sc = sqrt(rho1);
+  for (int i = 0; i < 2 * P; i++) out[i] = sc * r[i];
+  free(r);
+  return 0.5 * rho0;
+}
+
 /* cost = 1/2 (rho(|r_warp|^2) + |r_schw|^2); optionally the loss-corrected, column-scaled normal equations */
 static double swp_normal(const swp_t* s, const double* x, const double* cs, double* r, double* J, double* A, double* g) {
   const int n2 = 2 * s->N, m = 2 * s->P + 4 * s->N, P2 = 2 * s->P;

@@ -67,7 +67,7 @@ def test_writers_produce_what_twiddle_reads(tmp_path):
 
 
 @pytest.mark.gpu
-def test_def_pose_optimization_hip_mutates_frame_map_and_template_like_the_reference(gpu_ctx, tmp_path):
+def test_def_pose_optimization_hip_mutates_frame_map_and_template_like_the_reference(gpu_ctx, oracle_mod, tmp_path):
     from defslam_amd import sft, synth
     exe = _build()
     tmpl, fr = synth.make_problem("smoke", 3)
@@ -104,7 +104,7 @@ def test_def_pose_optimization_hip_mutates_frame_map_and_template_like_the_refer
     assert r.returncode == 0, r.stderr
     tok = open(tmp_path / "out.txt").read().split()
     it = iter(tok)
-    inliers, rep, pose_sets = int(next(it)), float(next(it)), int(next(it))
+    inliers, rep, pose_sets, locks, held_after, moved_under_lock = int(next(it)), float(next(it)), int(next(it)), int(next(it)), int(next(it)), int(next(it))
     Tcw = np.array([float(next(it)) for _ in range(16)], np.float32).reshape(4, 4)
     node_rows = np.array([[float(next(it)) for _ in range(7)] for _ in range(tmpl.n)])
     outl = np.array([int(next(it)) for _ in range(N)], bool)
@@ -117,6 +117,17 @@ def test_def_pose_optimization_hip_mutates_frame_map_and_template_like_the_refer
     gpu_ctx.template_build(tmpl.xyz0, facets_sorted)
     inl = sft.DefPoseOptimization(gpu_ctx, f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     assert inliers == inl and pose_sets == 1                                 # return value; SetPose called once
+    # MapPoint::mGlobalMutex (DefOptimizer.cc:287): taken once, held while every map point is moved, released on return
+    assert locks == 1 and held_after == 0 and moved_under_lock == int((kinds[kinds != 0] != 3).sum())
+    # the same frame through the ORACLE (the CPU restatement of the reference's g2o path): what the compiled shim wrote into the
+    # stand-in Frame / Node objects is what the reference algorithm computes
+    tc = oracle_mod.template_build(tmpl.xyz0, facets_sorted)
+    ro = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, N, facets_sorted[fr.obs_facet[src[taken]]].astype(np.int32), fr.obs_bary[src[taken]], fr.obs_uv[src[taken]],
+                              levels[octave[src[taken]]].astype(np.float64), xyz_now, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    assert inliers == ro.ret
+    np.testing.assert_allclose(node_rows[:, :3], ro.xyz, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(Tcw, ro.Tcw, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(outl[taken], ro.outlier.astype(bool))
     np.testing.assert_array_equal(Tcw, f.Tcw)                                # pFrame->mTcw
     assert np.float32(rep) == np.float32(f.repError)                         # pFrame->repError
     np.testing.assert_array_equal(node_rows[:, :3], f.nodes_xyz)            # Node::x,y,z of every node
@@ -142,7 +153,7 @@ def test_def_pose_optimization_hip_mutates_frame_map_and_template_like_the_refer
 
 
 @pytest.mark.gpu
-def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow(gpu_ctx, tmp_path):
+def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow(gpu_ctx, oracle_mod, tmp_path):
     """SchwarpDatabaseHIP::add for three keyframes and ObtainK1K2HIP through the compiled shim (stand-in KeyFrame / MapPoint /
     WarpDatabase classes) against the same sequence of C-ABI calls issued from Python with the reference's bookkeeping:
     which matches are removed after the initial warp (including the residual-index quirk of DefORBmatcher.cc:167-175), which are
@@ -208,13 +219,22 @@ def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow
         assert len(m) >= 20
         i1, i2 = np.array([a for a, _ in m]), np.array([b for _, b in m])
         isg = np.sqrt(levels[kfs[0]["octave"][i1]])
-        ok, x = nrsfm.WarpInitialize(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], lam)
-        res, _ = nrsfm.schwarp_eval(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], isg, fx, fy, 0.0, x, want_jacobian=False)
-        err = res[2 * np.arange(len(m))] ** 2 + res[2 * np.arange(len(m)) + 1] ** 2
-        assert (err > 20).sum() >= 1                                # the scene makes the initial-warp test bite
-        for j in np.nonzero(err > 20)[0]:
+        x, out_g, res_g = nrsfm.CalculateInitialSchwarp(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], isg, fx, fy, lam)
+        # the ORACLE's CalculateInitialSchwarp (independent code: dense Cholesky initialisation, CPU B-spline evaluation, Ceres' Corrector
+        # of the Huber block): the same control points, the same loss-corrected residuals, the same matches removed
+        ok_o, x_o = oracle_mod.warp_initialize(bb, kfs[0]["norm"][i1], kf["norm"][i2], lam)
+        assert ok_o
+        np.testing.assert_allclose(x, x_o, rtol=0, atol=1e-8)
+        res_o, _ = oracle_mod.schwarp_eval_initial(bb, kfs[0]["norm"][i1], kf["norm"][i2], isg, fx, fy, x_o)
+        np.testing.assert_allclose(res_g, res_o, rtol=1e-7, atol=1e-7)
+        raw, _ = oracle_mod.schwarp_eval(bb, kfs[0]["norm"][i1], kf["norm"][i2], isg, fx, fy, 0.0, x_o, want_jacobian=False)
+        assert np.sum(raw[:2 * len(m)] ** 2) > 5.77 ** 2 and np.abs(res_o).max() < np.abs(raw[:2 * len(m)]).max()   # the loss correction is active here
+        err_o = res_o[2 * np.arange(len(m))] ** 2 + res_o[2 * np.arange(len(m)) + 1] ** 2
+        np.testing.assert_array_equal(out_g, err_o > 20)
+        assert out_g.sum() >= 1                                     # the scene makes the initial-warp test bite
+        for j in np.nonzero(out_g)[0]:
             kf_mp[k][i2[j]] = -1                                    # EraseMapPointMatch (the map point keeps its observation)
-        m = [mm for mm, e in zip(m, err) if not e > 20]
+        m = [mm for mm, e in zip(m, out_g) if not e]
         cand = [i for i in range(kfs[0]["N"]) if kf_mp[0][i] >= 0 and k not in obs[kf_mp[0][i]]]
         mg = nrsfm.searchBySchwarp(gpu_ctx, b2, x, kfs[0]["norm"][cand], kfs[0]["desc"][cand], cam, np.array([0, 640, 0, 480], np.float32), kf["pix"], kf["desc"],
                                    (kf_mp[k] >= 0).astype(np.uint8), radius=2.0)
@@ -227,6 +247,12 @@ def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow
         i1, i2 = np.array([a for a, _ in m]), np.array([b for _, b in m])
         isg = np.sqrt(levels[kfs[0]["octave"][i1]])
         xg, dg, drop, info, costs = nrsfm.calculateSchwarps(gpu_ctx, b2, kfs[0]["norm"][i1], kf["norm"][i2], isg, fy, fx, lam, fx, fy, x, 3)
+        # the fit the shim stores records from, against the oracle's restated Ceres LM on the same matches
+        xo, do, drop_o, info_o, costs_o = oracle_mod.schwarp_fit(bb, kfs[0]["norm"][i1], kf["norm"][i2], isg, fy, fx, lam, fx, fy, x, 3)
+        np.testing.assert_array_equal(info, info_o)
+        np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-8)
+        np.testing.assert_array_equal(drop.astype(bool), drop_o)
+        np.testing.assert_allclose(dg, do, rtol=2e-5, atol=2e-6)
         for j, (a, b) in enumerate(m):
             p1, p2 = kf_mp[0][a], kf_mp[k][b]
             if p1 < 0 or p2 < 0:
@@ -254,6 +280,13 @@ def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow
     ng = nrsfm.ObtainK1K2(gpu_ctx, rec_ptr, recs, np.ones(R, np.uint8), np.zeros((R, 2), np.float32), np.zeros(R, np.uint8), np.zeros((len(pts), 2), np.float32),
                           np.zeros(len(pts), np.uint8), kfs[0]["norm"][pts])
     assert solved == int((ng.status == 0).sum()) and pending == 0
+    # the normals the compiled shim wrote into the surfaces, against the oracle's per-point solve of the same records
+    no = oracle_mod.normals(rec_ptr, recs, np.ones(R, np.uint8), np.zeros((R, 2), np.float32), np.zeros(R, np.uint8), np.zeros((len(pts), 2), np.float32),
+                            np.zeros(len(pts), np.uint8), kfs[0]["norm"][pts])
+    np.testing.assert_array_equal(ng.status, no["status"])
+    okp = ng.status == 0
+    np.testing.assert_allclose(ng.k1k2[okp], no["k1k2"][okp], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ng.normal_ref[okp], no["normal_ref"][okp], rtol=2e-6, atol=1e-7)
     w0, s0 = surf[0]
     assert w0 == solved
     for q, p in enumerate(pts):

@@ -155,6 +155,28 @@ def test_schwarp_oracle_schwarzian_jacobian_is_exact_and_warp_rows_follow_the_re
     assert np.abs(ra[2 * P:]).max() < 1e-9
 
 
+def test_initial_schwarp_residuals_are_loss_corrected_like_ceres_evaluate(oracle_mod):
+    """DefORBmatcher::CalculateInitialSchwarp reads its residuals from ceres::Problem::Evaluate with apply_loss_function = true: the one
+    2P-residual block under HuberLoss(5.77) comes back scaled by sqrt(rho'(s)) (Corrector, rho'' <= 0).  Known answers of the scaling."""
+    from defslam_amd import synth
+    pr = synth.make_warp_problem(60, 2)
+    P = 60
+    xbad = pr["x0"] + np.random.default_rng(8).normal(scale=2e-2, size=pr["x0"].size)     # a poor warp: residuals of many pixels
+    raw, _ = oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fx"], pr["fy"], 0.0, xbad, want_jacobian=False)
+    s = float(np.sum(raw[:2 * P] ** 2))
+    assert s > 5.77 ** 2                                         # the block is beyond the Huber threshold
+    r, cost = oracle_mod.schwarp_eval_initial(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fx"], pr["fy"], xbad)
+    np.testing.assert_allclose(r, raw[:2 * P] * np.sqrt(5.77 / np.sqrt(s)), rtol=1e-14)
+    assert cost == pytest.approx(0.5 * (2 * 5.77 * np.sqrt(s) - 5.77 ** 2), rel=1e-14)
+    assert np.sum(r ** 2) == pytest.approx(5.77 * np.sqrt(s), rel=1e-12)        # |r'|^2 = rho'(s) s
+    # below the threshold nothing changes: the fitted warp of the scene
+    raw2, _ = oracle_mod.schwarp_eval(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fx"], pr["fy"], 0.0, pr["x0"], want_jacobian=False)
+    assert np.sum(raw2[:2 * P] ** 2) < 5.77 ** 2
+    r2, cost2 = oracle_mod.schwarp_eval_initial(pr["bbs"], pr["kp1"], pr["kp2"], pr["invsig"], pr["fx"], pr["fy"], pr["x0"])
+    np.testing.assert_array_equal(r2, raw2[:2 * P])
+    assert cost2 == pytest.approx(0.5 * np.sum(raw2[:2 * P] ** 2), rel=1e-14)
+
+
 def test_schwarp_fit_never_increases_the_cost(oracle_mod):
     from defslam_amd import synth
     for seed, lam, outl in [(3, 0.1, 0.0), (3, 1.0, 0.05), (6, 2.0, 0.0)]:
