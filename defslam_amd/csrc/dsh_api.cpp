@@ -133,7 +133,8 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 1; } opt;
+  bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
 namespace {
@@ -296,6 +297,7 @@ int run_once(dsh_ctx* c) {
   while (true) {
     for (int i = 0; i < group && rounds < worst; i++, rounds++) {
       HIPCHK(c, launch(SFT_SPEC_LIN));
+      if (c->any_split) HIPCHK(c, launch(SFT_SPEC_FACTOR));   // two workgroups per lane: the two parts of the two-sided factorisation
       HIPCHK(c, launch(SFT_SPEC_TRIAL));
     }
     HIPCHK(c, launch(SFT_SPEC_LIN));   // the verdict on the last round (and, unless the problem is finished, the next linearisation)
@@ -504,6 +506,23 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   for (int b = 0; b < B; b++) {
     SftDev& hh = c->packed[b].h;
     hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);   // the barrier version of the factor steps exists in lab builds only
+    // Two-sided factorisation (SftPart in sft_problem.h): in latency mode a wide-band problem is cut at a separator of one bandwidth and
+    // its two halves are factored by two workgroups at the same time.  Needs room for two parts of at least four tile columns.
+    hh.split = 0;
+    if (K > 1 && hh.tile_mode == 2 && c->opt.split) {
+      const int sT = hh.wbt, sp = kTS * sT;
+      const int c0 = ((hh.Dn - sp) / 2 / kTS) * kTS, n1 = hh.Dn - sp - c0;
+      if (sT >= 2 && c0 >= 4 * kTS && n1 >= 4 * kTS) {
+        const int n1p = ((n1 + kTS - 1) / kTS) * kTS;
+        hh.split = 1; hh.sp_c0 = c0; hh.sp_s = sp; hh.sp_n1p = n1p; hh.sp_pad = n1p - n1;
+        SftPart& p0 = hh.part[0]; SftPart& p1 = hh.part[1]; SftPart& p2 = hh.part[2];
+        p0 = SftPart{}; p1 = SftPart{}; p2 = SftPart{};
+        p0.nS = c0 / kTS; p0.nT = p0.nS + sT; p0.tpr = hh.tpr; p0.wbt = hh.wbt; p0.b_base = 0; p0.b_sign = 1; p0.b_lo = 0; p0.b_hi = c0 + sp;
+        p1.nS = n1p / kTS; p1.nT = p1.nS + sT; p1.tpr = hh.tpr; p1.wbt = hh.wbt; p1.b_base = hh.Dn - 1 + hh.sp_pad; p1.b_sign = -1; p1.b_lo = hh.sp_pad; p1.b_hi = n1p;
+        p2.nS = sT; p2.nT = sT; p2.wbt = sT - 1; p2.tpr = sT;
+        hh.sp_xl = sT * p2.tpr * kTS * kTS + 8 * kTS * sT + 64;
+      }
+    }
     size_t used = 0;
     // placement class of the records (sft_kernels.hip: AsmRec): 1 = observation weights + curvature records, 2 = + node matrices + stretch records
     const size_t need1 = (((size_t)hh.M + 1) & ~(size_t)1) + 4 * (size_t)hh.S, need2 = need1 + 6 * (size_t)hh.nA + 4 * (size_t)hh.Es;
@@ -545,7 +564,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     r.mp = a.take(4 * 3 * (size_t)h.M) - c->res_off; r.outl = a.take((size_t)h.M) - c->res_off;
   }
   c->res_bytes = a.size - c->res_off;
-  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hc, Hb, Hbord, Hcn, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; };
+  struct POffs { size_t Hb, Lb, Lt, LbT, Lbord, Linv, x, xchg; };
+  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hc, Hb, Hbord, Hcn, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; POffs part[3]; };
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
@@ -571,6 +591,15 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.Linv = a.take(8 * (Dnp / kTS) * (size_t)kTS * kTS);
     w.Lt = a.take(h.tile_mode == 2 ? 8 * band_elems : 0); w.LbT = a.take(h.tile_mode == 2 ? 8 * (Dnp / kTS) * (size_t)kTS * kTS : 0);
     w.x = a.take(8 * (Dnp + 8)); w.dbg = a.take(1024);
+    if (h.split)
+      for (int g = 0; g < 3; g++) {   // the band matrices of the two parts and of the reduced problem (H of a part: one copy, lane 0's, shared by the lanes)
+        const SftPart& q = h.part[g];
+        const size_t tiles = 8 * (size_t)q.nT * q.tpr * kTS * kTS, col = 8 * (size_t)q.nT * kTS * kTS;
+        POffs& po = w.part[g];
+        po.Hb = a.take(g < 2 && lane == 0 ? tiles : 0);
+        po.Lb = a.take(tiles); po.Lt = a.take(tiles); po.LbT = a.take(col); po.Linv = a.take(col);
+        po.Lbord = a.take(8 * 8 * (size_t)kTS * q.nT); po.x = a.take(8 * ((size_t)kTS * q.nT + 8)); po.xchg = a.take(8 * (size_t)h.sp_xl);
+      }
   }
   if (sft_lm_kernel_lds_bytes(max_kd, jl_doubles) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
     return fail(c, DSH_ERR_ARG, "half-bandwidth too large for the LDS panel / workgroup");
@@ -629,11 +658,19 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.Lt = (double*)(base + w.Lt); h.LbT = (double*)(base + w.LbT);
     h.x = (double*)(base + w.x); h.dbg = (double*)(base + w.dbg);
     h.spec_xyz[0] = (double*)(base + w.sx0); h.spec_xyz[1] = (double*)(base + w.sx1);
+    if (h.split)
+      for (int g = 0; g < 3; g++) {
+        const POffs& po = w.part[g];
+        SftPart& q = h.part[g];
+        q.Hb = g < 2 ? (double*)(base + (lane ? wo[b].part[g].Hb : po.Hb)) : (double*)(base + po.xchg);   // reduced problem: H = the summed exchange buffer
+        q.Lb = (double*)(base + po.Lb); q.Lt = (double*)(base + po.Lt); q.LbT = (double*)(base + po.LbT); q.Linv = (double*)(base + po.Linv);
+        q.Lbord = (double*)(base + po.Lbord); q.x = (double*)(base + po.x); q.xchg = (double*)(base + po.xchg);
+      }
     if (lane) {
       h.xyz = (double*)(base + w.shadow_xyz); h.chi2_obs = (double*)(base + w.shadow_chi2);
       h.res = (SftResHdr*)(base + w.shadow_hdr); h.pose = ((SftResHdr*)(base + w.shadow_hdr))->pose;
       h.trace = nullptr; h.mappoint = nullptr; h.outlier = nullptr;
-      if (h.tile_mode == 1) {   // the lanes of a problem assemble one H together (each its share of the block rows) and all factor from it
+      if (h.tile_mode == 1 || h.split) {   // the lanes of a problem assemble one H together (each its share of the block rows) and all factor from it
         const SftDev& h0 = c->h_probs[b];
         h.Hc = h0.Hc; h.Hbord = h0.Hbord; h.Hcorner = h0.Hcorner;
       }
@@ -654,6 +691,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->d_spec = (SftSpec*)(base + o_spec);
   c->spec_bytes = sizeof(SftSpec) * (size_t)B * K;
   c->spec_k = K;
+  c->any_split = false;
+  for (int b = 0; b < B; b++) c->any_split = c->any_split || c->packed[b].h.split != 0;
   c->max_iters_batch = max_iters;
   c->B = B;
   c->max_kd = max_kd;
@@ -963,8 +1002,16 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   if (k == "waves") { if (value != 0 && value != 4 && value != 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: waves is 0 (automatic), 4 or 8"); c->opt.waves = value; }
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
+  else if (k == "split") c->opt.split = value != 0;
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
+  return DSH_OK;
+}
+
+int dsh_lab_sft_solver_info(dsh_ctx* c, int b, int32_t* out8) {
+  if (!c || !out8 || b < 0 || b >= c->B) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_solver_info: bad argument");
+  const SftDev& h = c->h_probs[b];
+  out8[0] = h.split; out8[1] = h.sp_c0; out8[2] = h.sp_s; out8[3] = h.sp_n1p; out8[4] = h.sp_pad; out8[5] = c->spec_k; out8[6] = h.tile_mode; out8[7] = c->nw;
   return DSH_OK;
 }
 
@@ -1047,13 +1094,15 @@ int dsh_lab_sft_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, do
   SftDev h = c->h_probs[b];
   if (D != 6 + h.Dn) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_system: D mismatch");
   // flip the mode of this one problem, run it alone, restore
-  const int32_t mode_saved = h.mode;
+  const int32_t mode_saved = h.mode, split_saved = h.split;
   h.mode = 1;
+  h.split = 0;   // the one-workgroup kernel assembles into the undivided band matrix
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ran = false;   // the state of problem b was reset: a download would not return the results of the last run
   h.mode = mode_saved;
+  h.split = split_saved;
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
   const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
   const size_t band_elems = h.tile_mode ? (Dnp / kTS) * (size_t)h.tpr * kTS * kTS : Dnp * (size_t)h.ldh;

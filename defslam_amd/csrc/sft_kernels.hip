@@ -87,10 +87,36 @@ __device__ __forceinline__ size_t h_index(const PT& P, int r, int c) {
   if (P.tile_mode == 2) return ((size_t)(r >> 4) * P.tpr + ((r >> 4) - (c >> 4))) * (TS * TS) + tile_elem(c & 15, r & 15);   // wide mode: tiles hold H(I,J)^T
   return (size_t)r * P.ldh + (c - r + P.kd);
 }
+// Two-sided factorisation (SftPart in sft_problem.h): where element (r, c), c <= r, of the natural band ordering lives -- part 0 keeps
+// its own rows, the separator rows and the separator block; part 1 is stored in reversed order behind its identity padding, its
+// separator rows (reversed as well) behind its own.  (rr, cc), cc <= rr: the element's position in that part's band matrix.
+struct SplitMap {
+  int on, c0, s, n1p, pad, Dn, tpr0, tpr1;
+  SFT_G double *H0, *H1;
+};
+template <class PT>
+__device__ __forceinline__ SplitMap split_map(const PT& P) {
+  return SplitMap{P.split, P.sp_c0, P.sp_s, P.sp_n1p, P.sp_pad, P.Dn, P.part[0].tpr, P.part[1].tpr, P.part[0].Hb, P.part[1].Hb};
+}
+__device__ __forceinline__ void split_target(const SplitMap& S, int r, int c, SFT_G double*& H, int& tpr, int& rr, int& cc) {
+  if (r < S.c0 + S.s) { H = S.H0; tpr = S.tpr0; rr = r; cc = c; return; }
+  const int rp = S.pad + (S.Dn - 1 - r);
+  H = S.H1; tpr = S.tpr1; cc = rp;
+  rr = (c >= S.c0 + S.s) ? S.pad + (S.Dn - 1 - c) : S.n1p + (S.s - 1 - (c - S.c0));
+}
+__device__ __forceinline__ size_t wide_elem(int tpr, int rr, int cc) {   // wide tile layout: tile (I,J) holds H(I,J)^T
+  return ((size_t)(rr >> 4) * tpr + ((rr >> 4) - (cc >> 4))) * (TS * TS) + tile_elem(cc & 15, rr & 15);
+}
+
 // diagonal element r of H (tile mode 1: from the compact 3x3 blocks)
 template <class PT>
 __device__ __forceinline__ double h_diag(const PT& P, int r) {
   if (P.tile_mode == 1) { const int a = r / 3, e = r - 3 * a; return P.Hc[9 * (size_t)(a + P.off_ptr[a]) + 4 * e]; }
+  if (P.tile_mode == 2 && P.split) {
+    SFT_G double* H; int tpr, rr, cc;
+    split_target(split_map(P), r, r, H, tpr, rr, cc);
+    return H[wide_elem(tpr, rr, cc)];
+  }
   return P.Hb[h_index(P, r, r)];
 }
 
@@ -494,6 +520,7 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const SplitMap SM = split_map(P_);
   AS_T0();
   AS_ADD(32);
   // Tile mode 1 keeps H as compact 3x3 blocks (P.Hc; the factorisation gathers its tiles from them): a lane that finishes a
@@ -541,6 +568,14 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
     nxt = load_hdr(I + dI);
     // element (r, c), c <= r, of H in the band / wide-tile layouts (and its mirror inside a diagonal tile, which is stored symmetric)
     auto put = [&](int r, int c, double v) {
+      if (P.tile_mode == 2 && SM.on) {   // two-sided factorisation: the element goes into the band matrix of its part
+        SFT_G double* H; int tpr, rr, cc;
+        split_target(SM, r, c, H, tpr, rr, cc);
+        const size_t idx = wide_elem(tpr, rr, cc);
+        H[idx] = v;
+        if (cc < rr && (rr >> 4) == (cc >> 4)) H[idx + (tile_elem(rr & 15, cc & 15) - tile_elem(cc & 15, rr & 15))] = v;
+        return;
+      }
       const size_t idx = h_index(P, r, c);
       Hg[idx] = v;
       if (P.tile_mode && c < r && (r >> 4) == (c >> 4)) {
@@ -2217,7 +2252,7 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 // (sparse_optimizer.cpp:477-491), scale = sum_j x_j (lambda x_j + b_j) (optimization_algorithm_levenberg.cpp:166-176) and the robust
 // chi2 at the trial state.  The caller has pushed the state and pops it on rejection.
 template <int NW>
-__device__ __forceinline__ double damping_trial(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, int& ok, double& scale) {
+__device__ __forceinline__ double damping_trial(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, int& ok, double& scale, bool prefactored = false) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   const int Dn = P.Dn;
@@ -2225,10 +2260,39 @@ __device__ __forceinline__ double damping_trial(const SftDev& P, Ctl* ctl, doubl
   PH_T0();
   if (P.tile_mode == 2) {
     if constexpr (NW == 8) {   // wide band: always the 512-thread kernel
-      factor_wide(P, ctl, panel);
-      PH_ADD(5);
-      backsub_wide(P, ctl, panel);
-      PH_ADD(6);
+      if (P.split && prefactored) {
+        // two-sided factorisation: both parts were factored by their own workgroups (sft_spec_kernel, SFT_SPEC_FACTOR).  Their Schur
+        // contributions are summed into the reduced (separator + camera) problem, which is solved here; then the parts back-substitute.
+        const int xl = P.sp_xl;
+        const auto x0 = P.part[0].xchg, x1 = P.part[1].xchg, xs = P.part[2].xchg;
+        for (int i = tid; i < xl; i += NT) xs[i] = x0[i] + x1[i];
+        __syncthreads();
+        const int nTr = P.part[2].nT;
+        const bool parts_ok = xs[(size_t)nTr * P.part[2].tpr * (TS * TS) + (size_t)8 * TS * nTr + 56] == 0.0;
+        __syncthreads();
+        if (parts_ok) factor_wide(P, 2, ctl, panel);
+        else if (tid == 0) ctl->fact_ok = 0;
+        __syncthreads();
+        PH_ADD(5);
+        backsub_wide(P, 2, ctl, panel);
+        backsub_wide(P, 0, ctl, panel);
+        backsub_wide(P, 1, ctl, panel);
+        if (ctl->fact_ok) {   // the solution in the natural ordering
+          const int c0 = P.sp_c0, sp = P.sp_s, pad = P.sp_pad, n1p = P.sp_n1p;
+          const auto xa = P.part[0].x, xb = P.part[1].x, xr = P.part[2].x;
+          for (int j = tid; j < c0; j += NT) P.x[j] = xa[j];
+          for (int k = tid; k < sp; k += NT) P.x[c0 + k] = xr[k];
+          for (int j = pad + tid; j < n1p; j += NT) P.x[Dn - 1 - (j - pad)] = xb[j];
+          if (tid < 6) P.x[Dnp + tid] = xr[TS * nTr + tid];
+        }
+        __syncthreads();
+        PH_ADD(6);
+      } else {
+        factor_wide(P, -1, ctl, panel);
+        PH_ADD(5);
+        backsub_wide(P, -1, ctl, panel);
+        PH_ADD(6);
+      }
     }
   } else if (P.tile_mode) {
 #ifdef DSH_LAB
@@ -2285,6 +2349,16 @@ __device__ __forceinline__ void init_state(const SftDev& P) {
     // compact blocks: the assembly rewrites every block of every linearisation; behind them the 0.0 and the 1.0 the gather lists point
     // structurally empty elements and the identity padding at
     if (tid == 0) { const size_t z = 9 * (size_t)(P.nA + P.noff); P.Hc[z] = 0.0; P.Hc[z + 1] = 1.0; }
+  } else if (P.tile_mode == 2 && P.split) {
+    // two-sided factorisation: the band matrices of the two parts (the assembly writes the structural non-zeros of every linearisation),
+    // identity on the padding scalars in front of part 1
+    for (int g = 0; g < 2; g++) {
+      const auto H = P.part[g].Hb;
+      const size_t nel = (size_t)P.part[g].nT * P.part[g].tpr * TS * TS;
+      for (size_t i = tid; i < nel; i += NT) H[i] = 0.0;
+    }
+    __syncthreads();
+    for (int j = tid; j < P.sp_pad; j += NT) P.part[1].Hb[wide_elem(P.part[1].tpr, j, j)] = 1.0;
   } else if (P.tile_mode) {
     // zero tiles + identity padding
     const int tpr = P.tpr;
@@ -2489,7 +2563,10 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K, int phase) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int B = gridDim.x / K, b = blockIdx.x / K, j = blockIdx.x % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
+  // SFT_SPEC_FACTOR runs two workgroups per (problem, lane): one per part of the two-sided factorisation
+  const int wgs = phase == SFT_SPEC_FACTOR ? 2 : 1, fpart = blockIdx.x % wgs;
+  const int bx = blockIdx.x / wgs;
+  const int B = gridDim.x / (K * wgs), b = bx / K, j = bx % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
   const SftDev& P = probs[(size_t)j * B + b];
   SftSpec& S = specs[(size_t)j * B + b];
   auto peer = [&](int jj) -> const SftSpec& { return specs[(size_t)jj * B + b]; };
@@ -2593,10 +2670,30 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
   }
   if (phase == SFT_SPEC_LIN) {
     if (S.need_lin == 1) {   // a new iteration: linearise (this lane's share of the assembly)
-      const bool shared_h = P.tile_mode == 1;
+      const bool shared_h = P.tile_mode == 1 || (P.tile_mode == 2 && P.split);
       const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {}, shared_h ? j : 0, shared_h ? K : 1);
       if (tid == 0) { S.chi_cur = chi0; S.chi_ini = chi0; S.rho = 0.0; S.accepted = 0; S.all_ok = 1; S.need_lin = 2; }
     }
+    return;
+  }
+  if (phase == SFT_SPEC_FACTOR) {
+    // ---- two-sided factorisation of the lane's trial: this workgroup factors part `fpart` at the lane's damping.  The controller state is
+    // only READ here (the trial launch behind this one updates it): on a fresh linearisation of the first iteration the initial damping is
+    // recomputed from H -- the same number the trial launch stores.
+    if (!(P.tile_mode == 2 && P.split) || S.need_lin == 1) return;
+    double lam = S.lambda, ni = S.ni;
+    if (S.need_lin == 2 && S.it == 0) {
+      double mx = 0.0;
+      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+      if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+      mx = block_max(mx, red);
+      lam = 1e-5 * mx; ni = 2.0;
+    }
+    for (int t = 0; t < j; t++) { lam *= ni; ni *= 2.0; }
+    if (S.qbase + j >= 10) return;
+    if (tid == 0) ctl->lambda = lam;
+    __syncthreads();
+    factor_wide(P, fpart, ctl, panel);
     return;
   }
   // ---- SFT_SPEC_TRIAL
@@ -2623,7 +2720,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     __syncthreads();
     int ok;
     double scale;
-    const double chi_new = damping_trial<NW>(P, ctl, red, out, panel, ok, scale);
+    const double chi_new = damping_trial<NW>(P, ctl, red, out, panel, ok, scale, P.tile_mode == 2 && P.split);
     const auto dst = P.spec_xyz[par];
     for (int i = tid; i < 3 * P.n; i += NT) dst[i] = P.xyz[i];
     if (tid == 0) {
@@ -2871,7 +2968,7 @@ extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, in
     if (e != hipSuccess) return e;
     *configured = lds;
   }
-  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K), dim3(512), lds, stream, d_probs, d_spec, K, phase);
+  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K * (phase == SFT_SPEC_FACTOR ? 2 : 1)), dim3(512), lds, stream, d_probs, d_spec, K, phase);
   return hipGetLastError();
 }
 

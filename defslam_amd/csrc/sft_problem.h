@@ -66,6 +66,7 @@ struct SftSc {
 #define SFT_SPEC_INIT 0
 #define SFT_SPEC_LIN 1
 #define SFT_SPEC_TRIAL 2
+#define SFT_SPEC_FACTOR 3       // split problems: the two parts of the factorisation, one workgroup each, in front of SFT_SPEC_TRIAL
 struct SftSpecRes { double chi_new, scale, lambda, ni, pose[8]; int32_t ok, valid; };
 struct SftSpec {
   double lambda, ni, chi_cur, chi_ini, lambda_start, rho;
@@ -73,6 +74,24 @@ struct SftSpec {
   int32_t it, qbase, nbad, accepted, all_ok, iters, trials, done, launches, need_lin, last_lane, pad;   // launches: completed trial rounds; need_lin: 1 linearise,
                                   // 2 linearised, lambda of the first iteration still to come; pad: a trial round waits for its verdict
   SftSpecRes res[2];
+};
+
+// Two-sided factorisation of a wide-band problem (sft_wide.h, latency mode; the connected-mesh mode across two GPUs uses the same cut).
+// The band ordering is cut into  [ part 0 : scalars 0 .. c0 ) [ separator : c0 .. c0+s ) [ part 1 : c0+s .. Dn ).  With s >= the scalar
+// half-bandwidth no element of H joins the two parts, so both can be eliminated at the same time -- part 0 top-down, part 1 in
+// REVERSED order (bottom-up), each as a band factorisation that simply continues into the separator rows but stops after its own
+// columns: what it leaves in the separator block is its Schur contribution.  The separator (+ camera) system is the sum of the two
+// contributions, is solved once, and the parts back-substitute independently.
+//   part g as a band matrix: nS eliminated tile columns (part 1: pad identity scalars first, so that the separator starts on a tile
+//   boundary), then the sT separator tile rows; its border columns are read from the natural border rows through (base, sign).
+//   part[2] = the reduced (separator) problem: dense band of sT tile columns, border = camera + right-hand side.
+struct SftPart {
+  int32_t nT, nS, tpr, wbt;            // tile rows (eliminated + separator), eliminated tile columns, tile pitch of a row, most sub-diagonal tiles
+  int32_t b_base, b_sign, b_lo, b_hi;  // column j of the part (b_lo <= j < b_hi) is natural border column b_base + b_sign * j; others are zero
+  SFT_G double* Hb;                    // H of the part, wide tile layout (tile (I,J) at (I*tpr + I-J)*256, transposed tiles); shared by the lanes of a problem
+  SFT_G double *Lb, *Lt, *LbT, *Lbord, *Linv, *x;
+  SFT_G double* xchg;                  // parts 0/1: the part's Schur contribution in the layout of the reduced problem's input
+                                       //   [H tiles sT*tpr_r*256 | border 8 x 16 sT | corner 56 | failed flag 8]; part[2]: the sum (its Hb points into it)
 };
 
 struct SftDev {
@@ -154,4 +173,10 @@ struct SftDev {
   SFT_G float* mappoint;          // M*3 DefMapPoint::RecalculatePosition of every observation's point (DefMapPoint.cc:129-147)
   SFT_G double* dbg;              // lab builds: [0] robust chi2 of dsh_lab_sft_system, phase timers, step stamps
   SFT_G double* spec_xyz[2];      // speculative trials: n*3 each, the lane's state after its trial (by launch parity)
+  // two-sided factorisation (tile mode 2, latency mode): see SftPart
+  int32_t split;                  // 0: one factorisation of the whole band; 1: parts 0 / 1 + the separator problem
+  int32_t sp_c0, sp_s, sp_n1p, sp_pad;   // cut: part 0 = scalars [0, c0), separator [c0, c0+s), part 1 = the rest, reversed behind sp_pad identity scalars (n1p = pad + count)
+  int32_t sp_xl;                  // doubles of one exchange buffer
+  int32_t pad2[2];
+  SftPart part[3];
 };

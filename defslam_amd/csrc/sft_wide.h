@@ -20,31 +20,84 @@
 
 __device__ __forceinline__ size_t wtile_off(int tpr, int I, int d) { return ((size_t)I * tpr + d) * (TS * TS); }
 
-__device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) {
+// What one call factors / back-substitutes: the whole node block of a problem (which = -1), or -- two-sided factorisation, SftPart in
+// sft_problem.h -- part 0 or 1 (a band matrix whose LAST rows are the separator: the elimination stops after the part's own nS tile
+// columns and the rest of the loop only forms the part's Schur contribution to the separator block, the separator x camera border and
+// the camera corner, written to the part's exchange buffer in the layout of the reduced problem), or the reduced problem itself
+// (which = 2: the summed contributions, a dense band).  Every field is wave-uniform (scalar registers).
+struct WideView {
+  int nT, nS, tpr, wb;               // tile rows, eliminated tile columns (== nT unless a part), pitch of a tile row, most sub-diagonal tiles
+  int lam_lo, lam_hi;                // the damping is added to the diagonal entries lam_lo <= index < lam_hi (identity padding keeps its 1)
+  int bstride, b_base, b_sign, b_lo, b_hi;   // border column j of this matrix = Hbord[row * bstride + b_base + b_sign * j] for b_lo <= j < b_hi, else 0
+  int xr_tpr, xr_nT;                 // parts: layout of the reduced problem
+  bool reversed, corner_from_H, finish;
+  const SFT_G double *Hb, *Hbord, *Hcorner;
+  SFT_G double *Lb, *Lt, *LbT, *Lbord, *Linv, *x, *xchg;
+};
+__device__ __forceinline__ WideView wide_view(const SftDev& P, int which) {
+  WideView v;
+  const int Dn = uni(P.Dn), Dnp = ((Dn + NB - 1) / NB) * NB;
+  if (which < 0) {
+    v.nT = Dnp / TS; v.nS = v.nT; v.tpr = uni(P.tpr); v.wb = uni(P.wbt);
+    v.lam_lo = 0; v.lam_hi = Dn;
+    v.bstride = Dnp; v.b_base = 0; v.b_sign = 1; v.b_lo = 0; v.b_hi = Dnp;
+    v.xr_tpr = 0; v.xr_nT = 0; v.reversed = false; v.corner_from_H = true; v.finish = true;
+    v.Hb = uni(P.Hb); v.Hbord = uni(P.Hbord); v.Hcorner = uni(P.Hcorner);
+    v.Lb = uni(P.Lb); v.Lt = uni(P.Lt); v.LbT = uni(P.LbT); v.Lbord = uni(P.Lbord); v.Linv = uni(P.Linv); v.x = uni(P.x); v.xchg = nullptr;
+    return v;
+  }
+  const auto& q = P.part[which];
+  v.nT = uni(q.nT); v.nS = uni(q.nS); v.tpr = uni(q.tpr); v.wb = uni(q.wbt);
+  v.Hb = uni(q.Hb); v.Lb = uni(q.Lb); v.Lt = uni(q.Lt); v.LbT = uni(q.LbT); v.Lbord = uni(q.Lbord); v.Linv = uni(q.Linv); v.x = uni(q.x); v.xchg = uni(q.xchg);
+  v.xr_tpr = uni(P.part[2].tpr); v.xr_nT = uni(P.part[2].nT);
+  if (which == 2) {   // the reduced problem: its input is the summed exchange buffer
+    v.lam_lo = 0; v.lam_hi = uni(P.sp_s);
+    v.bstride = TS * v.nT; v.b_base = 0; v.b_sign = 1; v.b_lo = 0; v.b_hi = TS * v.nT;
+    v.reversed = false; v.corner_from_H = true; v.finish = true;
+    v.Hbord = v.xchg + (size_t)v.nT * v.tpr * (TS * TS);
+    v.Hcorner = v.Hbord + (size_t)8 * TS * v.nT;
+    return v;
+  }
+  v.lam_lo = which == 1 ? uni(P.sp_pad) : 0; v.lam_hi = TS * v.nS;
+  v.bstride = Dnp; v.b_base = uni(q.b_base); v.b_sign = uni(q.b_sign); v.b_lo = uni(q.b_lo); v.b_hi = uni(q.b_hi);
+  v.reversed = which == 1; v.corner_from_H = which == 0; v.finish = false;
+  v.Hbord = uni(P.Hbord); v.Hcorner = uni(P.Hcorner);
+  return v;
+}
+
+// lam_corner: damping of the 6x6 camera block (a part that does not start from H_cc adds none; the reduced problem's corner carries it already)
+__device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, double* ws) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Dn = uni(P.Dn);
-  const int Dnp = ((Dn + NB - 1) / NB) * NB;
-  const int nT = Dnp / TS;
-  const int tpr = uni(P.tpr), wb = uni(P.wbt);
+  const WideView V = wide_view(P, which);
+  const int nT = V.nT, nS = V.nS;
+  const int tpr = V.tpr, wb = V.wb;
+  const int Dnp = TS * nT;
   lds_double* Lrow = to_lds(ws);                       // 2 x WB tiles, native layout (lane, 4 doubles): row-J tiles, dist 1..wb
   lds_double* LinvK = Lrow + 2 * WB * TS * TS;         // W_J, k-major padded: LinvK[k*TP + j] = W[j][k]
   lds_double* Cn = LinvK + TILE_LDS;                   // 8 partial 7x7 corners, then the corner itself
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;
-  const auto Hg = uni(P.Hb);
-  const auto Hbord = uni(P.Hbord);
-  const auto Lg = uni(P.Lb);
-  const auto Ltg = uni(P.Lt);
-  const auto LbTg = uni(P.LbT);
-  const auto Lbord = uni(P.Lbord);
-  const auto Linv_g = uni(P.Linv);
+  const auto Hg = V.Hb;
+  const auto Hbord = V.Hbord;
+  const auto Lg = V.Lb;
+  const auto Ltg = V.Lt;
+  const auto LbTg = V.LbT;
+  const auto Lbord = V.Lbord;
+  const auto Linv_g = V.Linv;
+  // border element (row, column j of this matrix) of H
+  auto bord_h = [&](int row, int j) -> double {
+    const int jj = (j >= V.b_lo && j < V.b_hi) ? j : V.b_lo;
+    const double v = Hbord[(size_t)row * V.bstride + V.b_base + V.b_sign * jj];
+    return (j >= V.b_lo && j < V.b_hi) ? v : 0.0;
+  };
   v4d cacc = {0.0, 0.0, 0.0, 0.0};     // this wave's share of the corner updates; wave 0 starts from H_cc + lambda I
-  if (wave == 0) {
+  if (wave == 0 && V.corner_from_H) {
+    const double lam_c = which == 2 ? 0.0 : lambda;   // the reduced corner already carries the damping (part 0 added it)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int r = crow + 4 * q;
-      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = P.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
+      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = V.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lam_c : 0.0);
     }
   }
   if (tid == 0) ctl->fact_ok = 1;
@@ -75,12 +128,13 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s0, 0, 0, 0);
     s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s1, 0, 0, 0);
   };
-  auto products_n = [&](auto nch_c, int J, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
+  // (Kend: the products run over block columns K0 .. Kend-1 -- Kend = J for an eliminated column, the part's nS for a separator column)
+  auto products_n = [&](auto nch_c, int J, int Kend, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
     // brow: tile of block column K0 for this row; the tile of block column K0 + i sits i * bstride doubles further
     constexpr int NCH = decltype(nch_c)::value;
     v4d s0 = zero4, s1 = zero4;
     v4d buf[2][U];
-    const int last = max(J - 1 - K0, 0);
+    const int last = max(Kend - 1 - K0, 0);
 #pragma unroll
     for (int u = 0; u < U; u++) buf[0][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(u, last) * bstride + 4 * lane);
 #pragma unroll
@@ -93,7 +147,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int K = K0 + U * c + u;
-        if (K < J) mfma4(lds_tile_read(rowJ + (size_t)(J - K - 1) * TS * TS), buf[c & 1][u], s0, s1);
+        if (K < Kend) mfma4(lds_tile_read(rowJ + (size_t)(J - K - 1) * TS * TS), buf[c & 1][u], s0, s1);
       }
     }
     return s0 + s1;
@@ -120,10 +174,26 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     return s0 + s1;
   };
   auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
-    const int n = J - K0;
+    const int Kend = min(J, nS);
+    const int n = Kend - K0;
     if (n <= 0) return zero4;
-    if (n <= 2 * U) return products_n(std::integral_constant<int, 2>{}, J, rowJ, brow, bstride, K0);
-    return products_n(std::integral_constant<int, 4>{}, J, rowJ, brow, bstride, K0);
+    if (n <= 2 * U) return products_n(std::integral_constant<int, 2>{}, J, Kend, rowJ, brow, bstride, K0);
+    return products_n(std::integral_constant<int, 4>{}, J, Kend, rowJ, brow, bstride, K0);
+  };
+  // Schur contribution of a part: tile (I, J) of the separator block, transposed tile in accumulator layout like H's tiles, into the
+  // exchange buffer (layout of the reduced problem's H).  Part 1 runs in reversed order: element (i, j) of its separator block is
+  // element (s-1-j, s-1-i) of the natural one.
+  auto schur_store = [&](int I, int J, const v4d& t) {
+    const int Ir = I - nS, Jr = J - nS;
+    if (!V.reversed) {
+      *reinterpret_cast<SFT_G v4d*>(V.xchg + wtile_off(V.xr_tpr, Ir, Ir - Jr) + 4 * lane) = t;
+      return;
+    }
+    // t[q] = T[b][a] with a = crow + 4 q (column index inside tile J), b = ccol (row index inside tile I)
+    const int It = V.xr_nT - 1 - Jr, Jt = V.xr_nT - 1 - Ir;          // natural tile (It, Jt), It >= Jt
+    const auto dst = V.xchg + wtile_off(V.xr_tpr, It, It - Jt);
+#pragma unroll
+    for (int q = 0; q < 4; q++) dst[tile_elem(15 - ccol, 15 - (crow + 4 * q))] = t[q];
   };
   const long kstride = (long)(tpr - 1) * TS * TS;        // tile (I, K+1) sits (tpr - 1) tiles after tile (I, K)
   // Look-ahead: the diagonal tile of column J+1 minus its products with block columns <= J-1 is formed during column J by the
@@ -156,26 +226,31 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
       staged[h] = dist <= wb && K >= 0 && J + 1 < nT;
       if (staged[h]) stage[h] = *reinterpret_cast<const SFT_G v4d*>(Ltg + wtile_off(tpr, K, dist) + 4 * lane);
     }
+    const bool elim = J < nS;          // a separator column of a part is not eliminated: its tiles are the Schur contribution
     if (d == 0) {
       // the diagonal tile: look-ahead tile minus the product with block column J-1 (the staged tile (J, J-1) twice), Cholesky
       __builtin_amdgcn_s_setprio(3);
       v4d dt = dlook;
-      if (J >= 1) {
+      if (J >= 1 && J - 1 < nS) {
         const v4d a = lds_tile_read(rowJ);
         v4d s0 = zero4, s1 = zero4;
         mfma4(a, a, s0, s1);
         dt -= s0 + s1;
       }
+      if (elim) {
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (crow + 4 * q == ccol && TS * J + ccol < Dn) dt[q] += lambda;
-      v4d w = dt;
-      const bool ok = chol_inv_blocked(dt, w);
-      if (!ok && lane == 0) ctl->fact_ok = 0;
-      lds_double* dst = LinvK + ccol * TP + crow;
+        for (int q = 0; q < 4; q++)
+          if (crow + 4 * q == ccol && TS * J + ccol >= V.lam_lo && TS * J + ccol < V.lam_hi) dt[q] += lambda;
+        v4d w = dt;
+        const bool ok = chol_inv_blocked(dt, w);
+        if (!ok && lane == 0) ctl->fact_ok = 0;
+        lds_double* dst = LinvK + ccol * TP + crow;
 #pragma unroll
-      for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
-      *reinterpret_cast<SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane) = w;
+        for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
+        *reinterpret_cast<SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane) = w;
+      } else {
+        schur_store(J, J, dt);
+      }
       __builtin_amdgcn_s_setprio(0);
     }
     v4d accT[3];
@@ -195,7 +270,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
       // in the next column, when tile (J+1, J) exists)
       const int I = J + 1, K0 = max(0, I - wb);
       const v4d h = *reinterpret_cast<const SFT_G v4d*>(Hg + wtile_off(tpr, I, 0) + 4 * lane);
-      dlook = h - squares(Ltg + wtile_off(tpr, K0, I - K0), kstride, J - K0);
+      dlook = h - squares(Ltg + wtile_off(tpr, K0, I - K0), kstride, min(J, nS) - K0);
     }
     // border: accTb[j][i] = Hbord[i][16 J + j] - sum_K (L(J,K) Lb(K)^T)[j][i], i < 7
     v4d accTb = zero4;
@@ -204,7 +279,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
       v4d h = zero4;
       if (ccol < SFT_BORDER) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) h[q] = Hbord[(size_t)ccol * Dnp + TS * J + crow + 4 * q];
+        for (int q = 0; q < 4; q++) h[q] = bord_h(ccol, TS * J + crow + 4 * q);
       }
       const int K0 = max(0, J - wb);
       accTb = h - products(J, nT, rowJ, LbTg + (size_t)K0 * TS * TS, (long)TS * TS, K0);
@@ -214,6 +289,21 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
       if (staged[h]) lds_tile_write(rowN + (size_t)(1 + wave + 8 * h) * TS * TS, stage[h]);
     lds_barrier();                                       // W_J is published
     // ---- TRSM: X^T = W accT (kept for the factor), X = acc W^T (kept for the back substitution) ----
+    if (!elim) {
+      // separator column of a part: the raw tiles are its Schur contribution (separator block, separator x camera/rhs border)
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+        if (have[t] && Irow[t] != J) schur_store(Irow[t], J, accT[t]);
+      if (bwave && ccol < SFT_BORDER) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int jl = TS * (J - nS) + crow + 4 * q;                    // column inside the separator block, this part's order
+          V.xchg[(size_t)V.xr_nT * V.xr_tpr * (TS * TS) + (size_t)ccol * (TS * V.xr_nT) + (V.reversed ? TS * V.xr_nT - 1 - jl : jl)] = accTb[q];
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     double wv[4];
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) wv[kk] = LinvK[(4 * kk + crow) * TP + ccol];     // lane (x = ccol, k = crow): W[x][4kk + k]
@@ -258,6 +348,13 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     Cn[512 + tid] = s;
   }
   __syncthreads();
+  if (!V.finish) {   // a part: its corner contribution (part 0 started from H_cc + lambda I) and whether its factorisation failed
+    const auto xc = V.xchg + (size_t)V.xr_nT * V.xr_tpr * (TS * TS) + (size_t)8 * TS * V.xr_nT;
+    if (tid < 49) xc[tid] = Cn[512 + tid];
+    if (tid == 0) xc[56] = ctl->fact_ok ? 0.0 : 1.0;
+    __syncthreads();
+    return;
+  }
   if (tid == 0) {
     lds_double* C = Cn + 512;
     bool bad = false;
@@ -277,8 +374,8 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
     if (ctl->fact_ok)
       for (int k = 5; k >= 0; k--) {
         double v = C[6 * 7 + k];
-        for (int r = k + 1; r < 6; r++) v -= C[r * 7 + k] * P.x[Dnp + r];
-        P.x[Dnp + k] = v / C[k * 7 + k];
+        for (int r = k + 1; r < 6; r++) v -= C[r * 7 + k] * V.x[Dnp + r];
+        V.x[Dnp + k] = v / C[k * 7 + k];
       }
   }
   __syncthreads();
@@ -286,26 +383,37 @@ __device__ __noinline__ void factor_wide(const SftDev& P, Ctl* ctl, double* ws) 
 
 // Back substitution for the wide band: x_J = W_J^T (y_J - sum_{I > J} X(I,J)^T x_I - L_cJ^T x_cam), block columns from the
 // last to the first; wave w forms the partial products of tiles (J + d, J), d = w + 1 and w + 9; wave 0 finishes the block.
-__device__ __noinline__ void backsub_wide(const SftDev& P, Ctl* ctl, double* ws) {
+// which: see WideView.  A part (0 / 1) starts behind its eliminated columns: the separator rows of its band matrix take the solution of
+// the reduced problem (part 1 in reversed order), the camera update comes from there as well.
+__device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, double* ws) {
   constexpr int NW = 8, RPW = WB / NW, RING = 32;
   if (!ctl->fact_ok) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Dnp = ((uni(P.Dn) + NB - 1) / NB) * NB;
-  const int nT = Dnp / TS;
-  const int tpr = uni(P.tpr), wb = uni(P.wbt);
+  const WideView V = wide_view(P, which);
+  const int nT = V.nT, nS = V.nS;
+  const int Dnp = TS * nT;
+  const int tpr = V.tpr, wb = V.wb;
   lds_double* xw = to_lds(ws);                 // ring of RING x-tiles
   lds_double* part = xw + TS * RING;           // slot 0: camera rows, slots 1..WB: sub-diagonal tiles
   const int crow = lane >> 4, ccol = lane & 15;
-  const double xc = (lane < 6) ? P.x[Dnp + lane] : 0.0;
+  const bool is_part = which == 0 || which == 1;
+  const auto xred = is_part ? uni(P.part[2].x) : V.x;        // where the camera update (and, for a part, the separator solution) is
+  const int sred = is_part ? TS * V.xr_nT : Dnp;
+  const double xc = (lane < 6) ? xred[sred + lane] : 0.0;
   double xcr[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) xcr[r] = bcast_lane(xc, r);
-  const auto Lg = uni(P.Lb);
-  const auto Lbord = uni(P.Lbord);
-  const auto Linv_g = uni(P.Linv);
-  const auto xg = uni(P.x);
+  const auto Lg = V.Lb;
+  const auto Lbord = V.Lbord;
+  const auto Linv_g = V.Linv;
+  const auto xg = V.x;
   for (int i = tid; i < TS * (WB + 1); i += 64 * NW) part[i] = 0.0;   // slots beyond wb stay zero
+  if (is_part)
+    for (int i = tid; i < TS * (nT - nS); i += 64 * NW) {             // separator rows nS .. nT-1 of the part
+      const int I = nS + (i >> 4), l = i & 15;
+      xw[(I & (RING - 1)) * TS + l] = xred[V.reversed ? sred - 1 - i : i];
+    }
   __syncthreads();
   struct Pre { v4d t[RPW]; double aux[6]; };
   auto fetch = [&](int J) -> Pre {
@@ -334,9 +442,9 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, Ctl* ctl, double* ws)
   constexpr int PF = 4;
   Pre ring[PF];
 #pragma unroll
-  for (int j = 0; j < PF; j++) ring[j] = fetch(nT - 1 - j);
+  for (int j = 0; j < PF; j++) ring[j] = fetch(nS - 1 - j);
 #pragma unroll 1
-  for (int base = nT - 1; base >= 0; base -= PF) {
+  for (int base = nS - 1; base >= 0; base -= PF) {
 #pragma unroll
     for (int j = 0; j < PF; j++) {
       const int J = base - j;

@@ -203,6 +203,13 @@ class Context:
         self._need_lab("dsh_lab_set_option")
         self._check(self._L.dsh_lab_set_option(self._h, name.encode(), int(value)), "dsh_lab_set_option")
 
+    def solver_info(self, b: int = 0) -> dict:
+        """How problem b of the uploaded batch is solved (lab build): two-sided factorisation and its cut, lanes, tile mode."""
+        self._need_lab("dsh_lab_sft_solver_info")
+        o = (C.c_int32 * 8)()
+        self._check(self._L.dsh_lab_sft_solver_info(self._h, int(b), o), "dsh_lab_sft_solver_info")
+        return dict(split=int(o[0]), c0=int(o[1]), s=int(o[2]), n1p=int(o[3]), pad=int(o[4]), lanes=int(o[5]), tile_mode=int(o[6]), waves=int(o[7]))
+
     def lab_run_timed(self, launches: int = 1) -> float:
         self._need_lab("dsh_lab_sft_run_timed")
         ms = C.c_double()

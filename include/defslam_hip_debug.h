@@ -24,8 +24,14 @@ extern "C" {
  *   "dataflow" 1 = barrier-free factor steps (default), 0 = the barrier version (only compiled into the lab library)
  *   "wide_off" 1 = half-bandwidths 128 < kd <= 256 use the row-major band solver instead of the wide tile solver
  *   "speculate"  0 = automatic, 1 = off (the one-workgroup persistent kernel), 2..4 = that many workgroups per problem try
- *                consecutive dampings of an iteration side by side (latency mode; results are bit-identical either way) */
+ *                consecutive dampings of an iteration side by side (latency mode; results are bit-identical either way)
+ *   "split"    1 = in latency mode a wide-band problem (128 < kd <= 256) is factored from both ends by two workgroups with a
+ *              separator of one bandwidth in between (default), 0 = one factorisation of the whole band (same Cholesky in another
+ *              elimination order: trajectories agree, numbers to rounding) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
+/* How problem b of the uploaded batch is solved: out[8] = {two-sided factorisation on?, first separator scalar c0, separator
+ * scalars s, scalars of part 1 incl. padding, its padding, workgroups (lanes) per problem, tile mode, wavefronts per workgroup}. */
+int dsh_lab_sft_solver_info(dsh_ctx* ctx, int b, int32_t* out8);
 
 /* `launches` back-to-back runs of the uploaded batch bracketed by HIP events recorded on dsh_stream; elapsed device
  * milliseconds between the two events. */

@@ -459,6 +459,7 @@ def test_speculative_damping_trials_are_bit_identical(lab_ctx, cfg, pids, iters)
     from defslam_amd import sft, synth
     ctx = lab_ctx
     runs = {}
+    ctx.set_option("split", 0)     # the two-sided factorisation of wide bands eliminates in another order: its own test below
     try:
         for K in (1, 2, 3, 4):
             ctx.set_option("speculate", K)
@@ -472,6 +473,7 @@ def test_speculative_damping_trials_are_bit_identical(lab_ctx, cfg, pids, iters)
             runs[K] = (frames, inl)
     finally:
         ctx.set_option("speculate", 0)
+        ctx.set_option("split", 1)
     f1, i1 = runs[1]
     assert sum(f.trials for f in f1) > sum(f.iters for f in f1) or iters == 1   # the cases do reject trials
     for K in (2, 3, 4):
@@ -486,6 +488,53 @@ def test_speculative_damping_trials_are_bit_identical(lab_ctx, cfg, pids, iters)
             np.testing.assert_array_equal(a.mvbOutlier, b.mvbOutlier)
             np.testing.assert_array_equal(a.mappoints, b.mappoints)
             assert a.rep_error_f64 == b.rep_error_f64
+
+
+@pytest.mark.parametrize("cfg,pids,iters", [("W16", (0, 3), 50), ("W12", (1, 4), 50), ("C5", (0,), 6)])
+def test_two_sided_factorisation_follows_the_undivided_one_and_the_oracle(lab_ctx, oracle_mod, cfg, pids, iters):
+    """Latency mode, wide band (128 < kd <= 256): the band ordering is cut at a separator of one bandwidth, two workgroups eliminate the two
+    halves at the same time (the second one in reversed order), the separator + camera system is the sum of their Schur contributions
+    (sft_wide.h, SftPart).  The same Cholesky factorisation in another elimination order: the Levenberg-Marquardt trajectory (iterations,
+    damping trials, accepted steps) is the undivided solver's and the oracle's, numbers agree to rounding.  A CONNECTED mesh: every
+    curvature, stretching and observation edge that crosses the cut is in the system (nothing is dropped at the cut)."""
+    from defslam_amd import sft, synth
+    ctx = lab_ctx
+    res = {}
+    try:
+        for split in (1, 0):
+            ctx.set_option("split", split)
+            frames = []
+            for pid in pids:
+                tmpl, fr = synth.make_problem(cfg, pid)
+                if not frames:
+                    ctx.template_build(tmpl.xyz0, tmpl.facets)
+                frames.append((sft.frame_from_synth(fr), fr, tmpl))
+            inl = sft.DefPoseOptimizationBatch(ctx, [f for f, _, _ in frames], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, max_iters=iters)
+            info = ctx.solver_info(0)
+            assert info["tile_mode"] == 2 and info["lanes"] >= 2 and info["split"] == split
+            if split:
+                _, counts = ctx.problem_info(0)
+                Dn, kd = counts[5] - 6, counts[6]
+                assert info["s"] >= kd and info["s"] % 16 == 0 and info["c0"] % 16 == 0 and info["c0"] > 0
+                assert info["n1p"] - info["pad"] == Dn - info["c0"] - info["s"] and 0 <= info["pad"] < 16     # the three pieces tile the unknowns
+            res[split] = (frames, inl)
+    finally:
+        ctx.set_option("split", 1)
+    (fs, inl_s), (fu, inl_u) = res[1], res[0]
+    assert inl_s == inl_u
+    for (a, fr, tmpl), (b, _, _) in zip(fs, fu):
+        assert a.status == 0 and b.status == 0
+        assert (a.iters, a.trials) == (b.iters, b.trials)
+        np.testing.assert_allclose(a.trace[:a.iters, :6], b.trace[:b.iters, :6], rtol=1e-7)
+        np.testing.assert_array_equal(a.trace[:a.iters, 6:], b.trace[:b.iters, 6:])
+        np.testing.assert_allclose(a.nodes_xyz, b.nodes_xyz, rtol=0, atol=1e-9 * np.abs(b.nodes_xyz).max())
+        np.testing.assert_allclose(a.pose7, b.pose7, rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(a.mvbOutlier, b.mvbOutlier)
+    if cfg != "C5":   # (the oracle's dense LDLT of the 2000-node problem takes minutes: its golden fixtures cover C5)
+        for k, (a, fr, tmpl) in enumerate(fs):
+            tc, args = oracle_args(oracle_mod, tmpl, fr)
+            r = oracle_mod.sft_solve(*args)
+            _compare(a, inl_s[k], r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
 
 
 def test_changing_view_sequence_through_the_graph_cache(gpu_ctx, oracle_mod):
