@@ -505,6 +505,13 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   const size_t lds_budget = ((nw == 4 ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
   for (int b = 0; b < B; b++) {
     SftDev& hh = c->packed[b].h;
+    // A narrow band (kd <= 128) that is long enough for two parts also takes the two-sided factorisation in latency mode: it runs on the
+    // left-looking wide-tile code (tile mode 2 works for any half-bandwidth up to 256), two workgroups per damping trial instead of one.
+    if (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS)) {
+      hh.tile_mode = 2;
+      hh.wbt = (hh.kd + kTS - 1) / kTS;
+      hh.tpr = hh.wbt + 1;
+    }
     hh.mode = (hh.mode & ~2) | ((hh.tile_mode == 1 && c->opt.dataflow) ? 2 : 0);   // the barrier version of the factor steps exists in lab builds only
     // Two-sided factorisation (SftPart in sft_problem.h): in latency mode a wide-band problem is cut at a separator of one bandwidth and
     // its two halves are factored by two workgroups at the same time.  Needs room for two parts of at least four tile columns.
@@ -529,7 +536,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     hh.lds_class = (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
     used += hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
     jl_doubles = std::max(jl_doubles, used);
-    max_kd = std::max(max_kd, hh.kd);
+    max_kd = std::max(max_kd, hh.tile_mode == 2 ? std::max(hh.kd, kTS * kBT + 1) : hh.kd);   // (LDS of the wide-tile solver whenever a problem runs on it)
   }
   if (c->host_only) {  // packed on the host only; dsh_sft_batch_problem_info works, running does not
     c->h_probs.resize(B);
@@ -1002,7 +1009,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   if (k == "waves") { if (value != 0 && value != 4 && value != 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: waves is 0 (automatic), 4 or 8"); c->opt.waves = value; }
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
-  else if (k == "split") c->opt.split = value != 0;
+  else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;

@@ -27,7 +27,8 @@ extern "C" {
  *                consecutive dampings of an iteration side by side (latency mode; results are bit-identical either way)
  *   "split"    1 = in latency mode a wide-band problem (128 < kd <= 256) is factored from both ends by two workgroups with a
  *              separator of one bandwidth in between (default), 0 = one factorisation of the whole band (same Cholesky in another
- *              elimination order: trajectories agree, numbers to rounding) */
+ *              elimination order: trajectories agree, numbers to rounding), 2 = narrower bands take the two-sided wide-tile path as
+ *              well (measured slower than their register-window solver: C2 4.67 vs 4.49 ms per frame) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
 /* How problem b of the uploaded batch is solved: out[8] = {two-sided factorisation on?, first separator scalar c0, separator
  * scalars s, scalars of part 1 incl. padding, its padding, workgroups (lanes) per problem, tile mode, wavefronts per workgroup}. */
