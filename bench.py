@@ -209,6 +209,34 @@ def shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch):
                     "all-reduce of the camera block between them -- latency-bound by design, the default for independent problems is the replica batch above"}
 
 
+def connected_leg(local_rank, tmpl, fr, regs):
+    """ONE connected template cut across two ranks (dsh_sft_connected_solve_group: two contexts on this GPU, the two all-reduces per damping
+    trial done by a summation kernel; between two GPUs the same driver runs them over RCCL): wall clock of the call, best of three."""
+    from defslam_amd import sft
+    ctxs = [sft.Context(local_rank), sft.Context(local_rank)]
+    try:
+        for c in ctxs:
+            c.template_build(tmpl.xyz0, tmpl.facets)
+        ts = []
+        fs = None
+        for _ in range(3):
+            fs = [sft.frame_from_synth(fr), sft.frame_from_synth(fr)]
+            t0 = time.perf_counter()
+            sft.ConnectedPoseOptimizationGroup(ctxs[0], ctxs[1], fs, *regs)
+            ts.append(time.perf_counter() - t0)
+        _, counts = ctxs[0].problem_info(0)
+        cut = sft.two_sided_cut(int(counts[5]) - 6, int(counts[6]))
+        dt = min(ts)
+        return {"ranks": 2, "devices": 1, "iters": int(fs[0].iters), "trials": int(fs[0].trials), "ms_per_frame": 1e3 * dt, "iters_per_s": fs[0].iters / dt,
+                "separator_scalars": cut[1], "part0_scalars": cut[0], "part1_scalars": cut[2] - cut[3],
+                "doubles_per_trial": {"schur_allreduce": (cut[1] // 16) ** 2 * 256 + 8 * cut[1] + 64, "update_allreduce": int(counts[5])},
+                "what": "optional mode (SURVEY 8e, connected mesh): one problem, the band cut at a separator of one bandwidth, one part per rank, host-sequenced "
+                        "phase kernels; here both ranks share this GPU and the all-reduce is a kernel -- latency-bound by design"}
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -450,6 +478,11 @@ def main():
                                       "INCLUDING the host's read-backs of the done flags between groups of launches; the end-to-end frame is in `e2e`"}
             if args.config == "C2":
                 out["e2e"] = e2e_legs(ctx, tmpl, m, frames, regs)
+            if world == 1:
+                try:
+                    out["connected_mesh"] = connected_leg(local_rank, tmpl, synth.make_frame(tmpl, m, 0), regs)
+                except Exception as e:  # noqa: BLE001
+                    out["connected_mesh"] = {"error": f"{type(e).__name__}: {e}"}
             # the Jacobian assembly on its own: launches that do one linearisation + normal-equation assembly per problem (measurement
             # kernel of the LAB build, same device functions as the product kernel), rank 0's GPU
             ctx.close()

@@ -89,7 +89,7 @@ EXPORTED_SYMBOLS = [
     "dsh_bbs_eval", "dsh_bbs_coloc", "dsh_normals_estimate", "dsh_schwarp_eval", "dsh_schwarp_fit", "dsh_schwarp_fit_batch",
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
     "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
-    "dsh_comm_unique_id", "dsh_comm_create", "dsh_comm_destroy", "dsh_sft_shared_solve", "dsh_sft_shared_solve_group",
+    "dsh_comm_unique_id", "dsh_comm_create", "dsh_comm_destroy", "dsh_sft_shared_solve", "dsh_sft_shared_solve_group", "dsh_sft_connected_solve", "dsh_sft_connected_solve_group",
 ]
 DSH_COMM_ID_BYTES = 128
 
@@ -168,6 +168,8 @@ def _bind(path: str, lab: bool) -> C.CDLL:
     L.dsh_comm_destroy.argtypes = [vp]
     L.dsh_sft_shared_solve.argtypes = [vp, vp, C.POINTER(SftFrameC), C.POINTER(SftResultC)]
     L.dsh_sft_shared_solve_group.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(SftFrameC), C.POINTER(SftResultC)]
+    L.dsh_sft_connected_solve.argtypes = [vp, vp, C.POINTER(SftFrameC), C.POINTER(SftResultC)]
+    L.dsh_sft_connected_solve_group.argtypes = [vp, vp, C.POINTER(SftFrameC), C.POINTER(SftResultC)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("dsh_last_error", "dsh_stream"):

@@ -28,6 +28,8 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
+extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
+extern "C" hipError_t sft_vec_sum2(const double* a, const double* b, double* out_a, double* out_b, int n, hipStream_t stream);
 #ifdef DSH_LAB
 extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 #endif
@@ -129,6 +131,8 @@ struct dsh_ctx : dsh_ctx_base {
   HostBuf spec_done;                   // page-locked: lane 0's SftSpec of every problem (the done flag)
   SftSc* d_sc = nullptr;               // shared-camera mode: LM state between the phase kernels
   int force_waves = 0;                 // set while the shared-camera mode packs its problem (always the 8-wavefront shape)
+  bool force_split = false;            // set while the connected-mesh mode packs its problem: the two-sided cut with one workgroup (rank) per part
+  size_t lds_configured_cn = 0;
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
@@ -507,7 +511,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     SftDev& hh = c->packed[b].h;
     // A narrow band (kd <= 128) that is long enough for two parts also takes the two-sided factorisation in latency mode: it runs on the
     // left-looking wide-tile code (tile mode 2 works for any half-bandwidth up to 256), two workgroups per damping trial instead of one.
-    if (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS)) {
+    if ((c->force_split && hh.tile_mode == 1) || (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS))) {
       hh.tile_mode = 2;
       hh.wbt = (hh.kd + kTS - 1) / kTS;
       hh.tpr = hh.wbt + 1;
@@ -516,7 +520,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     // Two-sided factorisation (SftPart in sft_problem.h): in latency mode a wide-band problem is cut at a separator of one bandwidth and
     // its two halves are factored by two workgroups at the same time.  Needs room for two parts of at least four tile columns.
     hh.split = 0;
-    if (K > 1 && hh.tile_mode == 2 && c->opt.split) {
+    if ((c->force_split || (K > 1 && c->opt.split)) && hh.tile_mode == 2) {
       const int sT = hh.wbt, sp = kTS * sT;
       const int c0 = ((hh.Dn - sp) / 2 / kTS) * kTS, n1 = hh.Dn - sp - c0;
       if (sT >= 2 && c0 >= 4 * kTS && n1 >= 4 * kTS) {
@@ -872,27 +876,50 @@ int sc_phase(std::vector<ScRank>& R, int phase, std::string& err) {
 // the same decisions; the host only reads "again" / "done" of its first local rank.
 int sc_solve(std::vector<ScRank>& R, ScReducer& red, int rank0, int nranks, const dsh_sft_frame* frames, dsh_sft_result* results, std::string& err) {
   const int G = (int)R.size();
+  if (nranks > SFT_SC_XCHG - 13) { err = "too many ranks for the exchange vector"; return DSH_ERR_ARG; }   // (the same verdict on every rank)
+  // A failure that only THIS rank sees (a bad frame, a template the mode cannot take, no memory) must not leave the other ranks inside a
+  // collective: it is carried through the first all-reduce (slot 2 of the exchange vector) and every rank returns together.
+  int local_rc = DSH_OK;
+  std::string local_err;
   for (int g = 0; g < G; g++) {
     dsh_ctx* c = R[g].c;
     if (c->host_only) { err = "host-only context, no GPU (there is no CPU fallback)"; return DSH_ERR_NO_DEVICE; }
-    if (frames[g].max_iters < 1) { err = "max_iters must be >= 1"; return DSH_ERR_ARG; }
     (void)hipSetDevice(c->device);
-    c->force_waves = 8;
-    const int rc = dsh_sft_batch_upload(c, 1, &frames[g]);
-    c->force_waves = 0;
-    if (rc != DSH_OK) { err = c->err; return rc; }
-    if (c->packed[0].h.tile_mode != 1) { err = "the shared-camera mode needs a template with half-bandwidth <= 128 (register-window solver)"; return DSH_ERR_ARG; }
-    if (!c->d_sc && hipMalloc((void**)&c->d_sc, sizeof(SftSc)) != hipSuccess) { err = "out of device memory"; return DSH_ERR_HIP; }
+    if (!c->d_sc && hipMalloc((void**)&c->d_sc, sizeof(SftSc)) != hipSuccess) { err = "out of device memory"; return DSH_ERR_HIP; }   // (nothing to exchange with)
     SftSc init{};
     init.rank = rank0 + g;
     init.nranks = nranks;
-    init.send[0] = (double)c->packed[0].h.nA;     // the regulariser weights divide by the JOINT counts (DefOptimizer.cc:458,497)
-    init.send[1] = (double)c->packed[0].h.Es;
+    int rc = frames[g].max_iters < 1 ? DSH_ERR_ARG : DSH_OK;
+    if (rc != DSH_OK && local_rc == DSH_OK) { local_rc = rc; local_err = "max_iters must be >= 1"; }
+    if (rc == DSH_OK) {
+      c->force_waves = 8;
+      rc = dsh_sft_batch_upload(c, 1, &frames[g]);
+      c->force_waves = 0;
+      if (rc != DSH_OK && local_rc == DSH_OK) { local_rc = rc; local_err = c->err; }
+    }
+    if (rc == DSH_OK && c->packed[0].h.tile_mode != 1) {
+      rc = DSH_ERR_ARG;
+      if (local_rc == DSH_OK) { local_rc = rc; local_err = "the shared-camera mode needs a template with half-bandwidth <= 128 (register-window solver); dsh_sft_connected_solve takes wider ones"; }
+    }
+    if (rc == DSH_OK) {
+      init.send[0] = (double)c->packed[0].h.nA;     // the regulariser weights divide by the JOINT counts (DefOptimizer.cc:458,497)
+      init.send[1] = (double)c->packed[0].h.Es;
+    }
+    init.send[2] = rc == DSH_OK ? 0.0 : 1.0;
     if (hipMemcpyAsync(c->d_sc, &init, sizeof(SftSc), hipMemcpyHostToDevice, c->stream) != hipSuccess) { err = "state upload failed"; return DSH_ERR_HIP; }
   }
-  if (nranks > SFT_SC_XCHG - 13) { err = "too many ranks for the exchange vector"; return DSH_ERR_ARG; }
   int rc = red.reduce(R, err);
   if (rc != DSH_OK) return rc;
+  {
+    double tot3[3];
+    dsh_ctx* c = R[0].c;
+    if (hipMemcpyAsync(tot3, c->d_sc->recv, sizeof(tot3), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { err = "read-back failed"; return DSH_ERR_HIP; }
+    if (tot3[2] != 0.0) {   // some rank could not set its patch up: every rank leaves here
+      if (local_rc != DSH_OK) { err = local_err; return local_rc; }
+      err = "another rank failed to set its patch up";
+      return DSH_ERR_STATE;
+    }
+  }
   for (int g = 0; g < G; g++) {   // joint counts -> weights of every rank's problem record
     dsh_ctx* c = R[g].c;
     double tot[2];
@@ -992,6 +1019,128 @@ int dsh_sft_shared_solve_group(int G, dsh_ctx* const* ctxs, const dsh_sft_frame*
   return rc == DSH_OK ? rc : fail(c0, rc, "dsh_sft_shared_solve_group: " + err);
 }
 
+
+// ---- connected-mesh mode: one problem, one connected template, the factorisation cut in two (sft_kernels.hip: sft_cn_kernel) ----------
+namespace {
+
+// all-reduce (sum) of n doubles: send -> recv on every rank.  RCCL between two processes, a summation kernel between two contexts of one process.
+int cn_allreduce(std::vector<ScRank>& R, dsh_comm* comm, double* const* send, double* const* recv, int n, std::string& err) {
+  if (comm) {
+    dsh_ctx* c = R[0].c;
+    const int rc = g_rccl.AllReduce(send[0], recv[0], (size_t)n, kNcclDouble, kNcclSum, comm->comm, c->stream);
+    if (rc != 0) { err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return DSH_ERR_HIP; }
+    return DSH_OK;
+  }
+  for (auto& r : R)
+    if (hipStreamSynchronize(r.c->stream) != hipSuccess) { err = "stream synchronise failed"; return DSH_ERR_HIP; }
+  if (sft_vec_sum2(send[0], send[1], recv[0], recv[1], n, R[0].c->stream) != hipSuccess || hipStreamSynchronize(R[0].c->stream) != hipSuccess) { err = "local reduce failed"; return DSH_ERR_HIP; }
+  return DSH_OK;
+}
+
+int cn_phase(std::vector<ScRank>& R, int phase, std::string& err) {
+  for (auto& r : R) {
+    dsh_ctx* c = r.c;
+    (void)hipSetDevice(c->device);
+    if (sft_cn_launch(c->d_probs, c->d_sc, phase, c->max_kd, c->jl_doubles, &c->lds_configured_cn, c->stream) != hipSuccess) { err = "phase kernel launch failed"; return DSH_ERR_HIP; }
+  }
+  return DSH_OK;
+}
+
+// R: the local ranks (one with RCCL, two in the in-process group); every rank packs the SAME frame.
+int cn_solve(std::vector<ScRank>& R, dsh_comm* comm, int rank0, const dsh_sft_frame* frame, dsh_sft_result* results, std::string& err) {
+  const int G = (int)R.size();
+  int local_rc = DSH_OK;
+  std::string local_err;
+  for (int g = 0; g < G; g++) {
+    dsh_ctx* c = R[g].c;
+    if (c->host_only) { err = "host-only context, no GPU (there is no CPU fallback)"; return DSH_ERR_NO_DEVICE; }
+    (void)hipSetDevice(c->device);
+    if (!c->d_sc && hipMalloc((void**)&c->d_sc, sizeof(SftSc)) != hipSuccess) { err = "out of device memory"; return DSH_ERR_HIP; }
+    int rc = frame->max_iters < 1 ? DSH_ERR_ARG : DSH_OK;
+    if (rc != DSH_OK && local_rc == DSH_OK) { local_rc = rc; local_err = "max_iters must be >= 1"; }
+    if (rc == DSH_OK) {
+      c->force_waves = 8;
+      c->force_split = true;
+      rc = dsh_sft_batch_upload(c, 1, frame);
+      c->force_waves = 0;
+      c->force_split = false;
+      if (rc != DSH_OK && local_rc == DSH_OK) { local_rc = rc; local_err = c->err; }
+    }
+    if (rc == DSH_OK && !c->packed[0].h.split) {
+      rc = DSH_ERR_ARG;
+      if (local_rc == DSH_OK) { local_rc = rc; local_err = "the connected-mesh mode needs a band of at most 256 that is long enough to cut (two parts of four tile columns next to a separator of one bandwidth)"; }
+    }
+    SftSc init{};
+    init.rank = rank0 + g;
+    init.nranks = 2;
+    init.send[0] = rc == DSH_OK ? 0.0 : 1.0;
+    if (hipMemcpyAsync(c->d_sc, &init, sizeof(SftSc), hipMemcpyHostToDevice, c->stream) != hipSuccess) { err = "state upload failed"; return DSH_ERR_HIP; }
+  }
+  // rank-local failures are agreed on before the first phase (nobody is left inside a collective)
+  {
+    double* snd[2]; double* rcv[2];
+    for (int g = 0; g < G; g++) { snd[g] = R[g].c->d_sc->send; rcv[g] = R[g].c->d_sc->recv; }
+    int rc = cn_allreduce(R, comm, snd, rcv, 4, err);
+    if (rc != DSH_OK) return rc;
+    double bad = 0.0;
+    dsh_ctx* c = R[0].c;
+    if (hipMemcpyAsync(&bad, c->d_sc->recv, sizeof(bad), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { err = "read-back failed"; return DSH_ERR_HIP; }
+    if (bad != 0.0) {
+      if (local_rc != DSH_OK) { err = local_err; return local_rc; }
+      err = "the other rank failed to set the problem up";
+      return DSH_ERR_STATE;
+    }
+  }
+  int rc;
+  double* xs[2]; double* xr[2]; double* vx[2];
+  int xl = 0, nx = 0;
+  for (int g = 0; g < G; g++) {
+    const SftDev& h = R[g].c->h_probs[0];
+    xs[g] = h.part[rank0 + g].xchg; xr[g] = h.part[2].xchg; vx[g] = h.x;
+    xl = h.sp_xl;
+    nx = ((h.Dn + kNB - 1) / kNB) * kNB + 6;
+  }
+  for (int guard = 0; guard < DSH_MAX_ITERS + 1; guard++) {
+    if ((rc = cn_phase(R, SFT_CN_LIN, err)) != DSH_OK) return rc;
+    int again = 0, done = 0;
+    do {
+      if ((rc = cn_phase(R, SFT_CN_FAC, err)) != DSH_OK || (rc = cn_allreduce(R, comm, xs, xr, xl, err)) != DSH_OK) return rc;
+      if ((rc = cn_phase(R, SFT_CN_SOL, err)) != DSH_OK || (rc = cn_allreduce(R, comm, vx, vx, nx, err)) != DSH_OK) return rc;
+      if ((rc = cn_phase(R, SFT_CN_CTL, err)) != DSH_OK) return rc;
+      int32_t flags[2];
+      dsh_ctx* c = R[0].c;
+      if (hipMemcpyAsync(flags, &c->d_sc->again, sizeof(flags), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { err = "flag read-back failed"; return DSH_ERR_HIP; }
+      again = flags[0];
+      done = flags[1];
+    } while (again);
+    if (done) break;
+  }
+  for (int g = 0; g < G; g++) {
+    R[g].c->ran = true;
+    rc = dsh_sft_batch_download(R[g].c, 1, &results[g]);
+    if (rc != DSH_OK) { err = R[g].c->err; return rc; }
+  }
+  return DSH_OK;
+}
+
+}  // namespace
+
+int dsh_sft_connected_solve(dsh_ctx* c, dsh_comm* cm, const dsh_sft_frame* frame, dsh_sft_result* result) {
+  if (!c || !cm || !frame || !result || cm->ctx != c) return fail(c, DSH_ERR_ARG, "dsh_sft_connected_solve: bad argument");
+  if (cm->nranks != 2) return fail(c, DSH_ERR_ARG, "dsh_sft_connected_solve: the cut has two parts: the communicator must have exactly two ranks");
+  std::vector<ScRank> R{ScRank{c}};
+  std::string err;
+  const int rc = cn_solve(R, cm, cm->rank, frame, result, err);
+  return rc == DSH_OK ? rc : fail(c, rc, "dsh_sft_connected_solve: " + err);
+}
+
+int dsh_sft_connected_solve_group(dsh_ctx* c0, dsh_ctx* c1, const dsh_sft_frame* frame, dsh_sft_result* results) {
+  if (!c0 || !c1 || c0 == c1 || !frame || !results) return DSH_ERR_ARG;
+  std::vector<ScRank> R{ScRank{c0}, ScRank{c1}};
+  std::string err;
+  const int rc = cn_solve(R, nullptr, 0, frame, results, err);
+  return rc == DSH_OK ? rc : fail(c0, rc, "dsh_sft_connected_solve_group: " + err);
+}
 
 #ifdef DSH_LAB
 // ---- lab entry points (include/defslam_hip_debug.h): libdefslam_hip_lab.so only ----------------------------------------

@@ -2893,6 +2893,152 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_sc_kernel(const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Connected-mesh mode across two GPUs: ONE problem on ONE connected template, cut like the two-sided factorisation (SftPart): rank g
+// factors part g of the band, the ranks all-reduce their Schur contributions to the separator + camera system (the "halo": the
+// separator is one bandwidth of unknowns, so every curvature / stretching / observation edge that crosses the cut lives in it or in
+// its coupling rows), every rank solves that reduced system, back-substitutes its own part, and a second all-reduce assembles the
+// update.  Residuals, Jacobians and the Levenberg-Marquardt control are replicated (every rank holds the whole state and evaluates all
+// edges: identical numbers, identical decisions, no collective for the control); what is partitioned is the factorisation, i.e. where
+// the time goes.  Phases, sequenced by the host between the collectives (dsh_api.cpp: cn_solve):
+//   LIN  linearise (both parts' band matrices), initial damping        FAC  push, factor the rank's part -> its exchange buffer
+//   -- all-reduce of the exchange buffers into the reduced problem --
+//   SOL  reduced factor + solve, back substitution of the rank's part, its piece of the update in the natural ordering (zeros elsewhere)
+//   -- all-reduce of the update --
+//   CTL  state update, trial evaluation, accept / reject, termination, classification
+// ------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_cn_kernel(const SftDev* __restrict__ probs, SftSc* __restrict__ scs, int phase) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  SftSc& S = scs[blockIdx.x];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);
+  double* out = red + 16 * 27 + 5;
+  double* panel = out + 32;
+  const int tid = threadIdx.x;
+  const int Dn = P.Dn;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  const int part = S.rank;
+  if (phase == SFT_CN_LIN) {
+    if (S.it == 0) {
+      init_state<NT>(P);
+      if (tid == 0) { S.lambda = -1.0; S.ni = 2.0; S.nbad = 0; S.iters = 0; S.trials = 0; S.done = 0; }
+      __syncthreads();
+    }
+    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+    if (S.it == 0) {
+      double mx = 0.0;
+      for (int r = tid; r < Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+      if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+      mx = block_max(mx, red);
+      if (tid == 0) { S.lambda = 1e-5 * mx; S.ni = 2.0; S.nbad = 0; }
+    }
+    __syncthreads();
+    if (tid == 0) { S.chi_cur = chi0; S.chi_ini = chi0; S.qmax = 0; S.rho = 0.0; S.accepted = 0; S.all_ok = 1; S.lambda_start = S.lambda; }
+  } else if (phase == SFT_CN_FAC) {
+    for (int i = tid; i < 3 * P.n; i += NT) P.xyz_bak[i] = P.xyz[i];   // push
+    if (tid < 7) S.pose_bak[tid] = P.pose[tid];
+    if (tid == 0) ctl->lambda = S.lambda;
+    __syncthreads();
+    if constexpr (NW == 8) factor_wide(P, part, ctl, panel);
+  } else if (phase == SFT_CN_SOL) {
+    // P.part[2].xchg holds the all-reduced sum of the two exchange buffers
+    const int nTr = P.part[2].nT;
+    const bool parts_ok = P.part[2].xchg[(size_t)nTr * P.part[2].tpr * (TS * TS) + (size_t)8 * TS * nTr + 56] == 0.0;
+    if (tid == 0) ctl->lambda = S.lambda;
+    __syncthreads();
+    if constexpr (NW == 8) {
+      if (parts_ok) factor_wide(P, 2, ctl, panel);
+      else if (tid == 0) ctl->fact_ok = 0;
+      __syncthreads();
+      backsub_wide(P, 2, ctl, panel);
+      backsub_wide(P, part, ctl, panel);
+    }
+    for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
+    __syncthreads();
+    if (ctl->fact_ok) {   // this rank's piece of the update, natural ordering (rank 0 also carries the separator and the camera)
+      const int c0 = P.sp_c0, sp = P.sp_s, pad = P.sp_pad, n1p = P.sp_n1p;
+      const auto xa = P.part[part].x, xr = P.part[2].x;
+      if (part == 0) {
+        for (int j = tid; j < c0; j += NT) P.x[j] = xa[j];
+        for (int k = tid; k < sp; k += NT) P.x[c0 + k] = xr[k];
+        if (tid < 6) P.x[Dnp + tid] = xr[TS * nTr + tid];
+      } else {
+        for (int j = pad + tid; j < n1p; j += NT) P.x[Dn - 1 - (j - pad)] = xa[j];
+      }
+    }
+    if (tid == 0) S.fact_ok = ctl->fact_ok;
+  } else {   // SFT_CN_CTL: P.x holds the complete update on every rank
+    for (int i = tid; i < 3 * P.n; i += NT) {
+      const int a = P.act[i / 3];
+      if (a >= 0) P.xyz[i] += P.x[3 * a + (i % 3)];
+    }
+    if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
+    double sc = 0.0;
+    const double lam = S.lambda;
+    for (int r = tid; r < Dn; r += NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
+    if (tid < 6) { const double xv = P.x[Dnp + tid]; sc += xv * (lam * xv + P.Hcorner[42 + tid]); }
+    __syncthreads();
+    block_sum<1>(&sc, red, out);
+    const double scale = out[0];
+    __syncthreads();
+    const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+    if (tid == 0) {
+      const int ok = S.fact_ok;
+      S.all_ok &= ok;
+      const double tempChi = ok ? chi_new : DBL_MAX;
+      double rho = (S.chi_cur - tempChi);
+      rho /= (scale + 1e-3);
+      S.rho = rho;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        const double sf = fmax(1. / 3., alpha);
+        S.lambda *= sf; S.ni = 2.0; S.chi_cur = tempChi; S.accepted = 1;
+        ctl->stop = 0;
+      } else {
+        S.lambda *= S.ni; S.ni *= 2.0;
+        ctl->stop = 1;
+      }
+      S.qmax++;
+    }
+    __syncthreads();
+    if (ctl->stop) {  // pop
+      for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
+      if (tid < 7) P.pose[tid] = S.pose_bak[tid];
+    }
+    __syncthreads();
+    const bool again = (S.rho < 0) && (S.qmax < 10);
+    bool finished = false;
+    if (!again) {
+      if (tid == 0) {
+        S.trials += S.qmax;
+        S.iters++;
+        if (P.trace) {
+          double* t = P.trace + S.it * 8;
+          t[0] = S.chi_ini; t[1] = S.lambda_start; t[2] = S.qmax; t[3] = S.chi_cur; t[4] = S.lambda; t[5] = S.rho; t[6] = S.accepted; t[7] = S.all_ok;
+        }
+        if (!S.all_ok) P.res->status |= 1;
+        bool term = (S.qmax == 10) || (S.rho == 0);
+        if (!term) {
+          if ((S.chi_ini - S.chi_cur) * 1e3 < S.chi_ini) S.nbad++; else S.nbad = 0;
+          term = S.nbad >= 3;
+        }
+        S.it++;
+        if (S.it >= P.max_iters) term = true;
+        S.done = term ? 1 : 0;
+        ctl->qmax = term ? 1 : 0;
+      }
+      __syncthreads();
+      finished = ctl->qmax != 0;
+    }
+    if (tid == 0) S.again = again ? 1 : 0;
+    if (finished) classify<NT>(P, ctl, panel, S.iters, S.trials);
+  }
+}
+
 #ifdef DSH_LAB
 // Measurement kernel of the Jacobian-assembly roofline: one linearisation (residuals + Jacobian records) and one
 // normal-equation assembly per problem at its uploaded initial state, nothing else.  H and the border keep the zero pattern
@@ -2958,6 +3104,30 @@ extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, i
     *configured = lds;
   }
   hipLaunchKernelGGL(sft_sc_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs, d_sc, phase);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+  if (lds > *configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_cn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    *configured = lds;
+  }
+  hipLaunchKernelGGL(sft_cn_kernel<8>, dim3(1), dim3(512), lds, stream, d_probs, d_sc, phase);
+  return hipGetLastError();
+}
+
+// out_a[i] = out_b[i] = a[i] + b[i]: the in-process stand-in of a two-rank all-reduce (dsh_sft_connected_solve_group); in place is fine
+__global__ void sft_vec_sum2_kernel(const double* a, const double* b, double* out_a, double* out_b, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = a[i] + b[i];
+    out_a[i] = v;
+    out_b[i] = v;
+  }
+}
+extern "C" hipError_t sft_vec_sum2(const double* a, const double* b, double* out_a, double* out_b, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(sft_vec_sum2_kernel, dim3(64), dim3(256), 0, stream, a, b, out_a, out_b, n);
   return hipGetLastError();
 }
 

@@ -51,6 +51,11 @@ struct SftResHdr {
 #define SFT_SC_FAC 1
 #define SFT_SC_SOL 2
 #define SFT_SC_CTL 3
+// Connected-mesh mode across two ranks (sft_kernels.hip: sft_cn_kernel): the same phase structure; the controller state lives in SftSc.
+#define SFT_CN_LIN 0
+#define SFT_CN_FAC 1
+#define SFT_CN_SOL 2
+#define SFT_CN_CTL 3
 struct SftSc {
   double send[SFT_SC_XCHG], recv[SFT_SC_XCHG];   // local partials / their sum over the ranks
   double lambda, ni, chi_cur, chi_ini, rho, lambda_start;

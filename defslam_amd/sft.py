@@ -431,6 +431,47 @@ def SharedCameraPoseOptimizationGroup(ctxs: Sequence[Context], frames: Sequence[
     return [_write_back(frames[g], bufs[g], res[g]) for g in range(G)]
 
 
+def ConnectedPoseOptimization(ctx: Context, comm: Comm, pFrame: Frame, RegLap: float = 5000, RegInex: float = 5000, RegTemp: float = 0,
+                              NeighboursLayers: int = 1, max_iters: int = 50) -> int:
+    """Collective over a two-rank communicator: ONE problem on ONE connected template (both ranks pass the same frame); rank g factors
+    part g of the band, the separator + camera system is all-reduced (include/defslam_hip.h: dsh_sft_connected_solve)."""
+    keep: list = []
+    fc = ctx._frame_c(pFrame, RegLap, RegInex, RegTemp, NeighboursLayers, max_iters, keep)
+    b, r = _result_buffers(pFrame, max_iters)
+    ctx._check(ctx._L.dsh_sft_connected_solve(ctx._h, comm._h, C.byref(fc), C.byref(r)), "dsh_sft_connected_solve")
+    return _write_back(pFrame, b, r)
+
+
+def ConnectedPoseOptimizationGroup(ctx0: Context, ctx1: Context, frames: Sequence[Frame], RegLap: float = 5000, RegInex: float = 5000, RegTemp: float = 0,
+                                   NeighboursLayers: int = 1, max_iters: int = 50) -> List[int]:
+    """The connected-mesh protocol inside one process over two contexts (the all-reduces are summation kernels).  frames: two Frame objects
+    holding the SAME problem (one per context, each receives its context's copy of the result)."""
+    keep: list = []
+    fc = ctx0._frame_c(frames[0], RegLap, RegInex, RegTemp, NeighboursLayers, max_iters, keep)
+    res = (_lib.SftResultC * 2)()
+    bufs = []
+    for g in range(2):
+        b, r = _result_buffers(frames[g], max_iters)
+        bufs.append(b)
+        res[g] = r
+    ctx0._check(ctx0._L.dsh_sft_connected_solve_group(ctx0._h, ctx1._h, C.byref(fc), res), "dsh_sft_connected_solve_group")
+    return [_write_back(frames[g], bufs[g], res[g]) for g in range(2)]
+
+
+def two_sided_cut(Dn: int, kd: int):
+    """The cut of the two-sided factorisation / the connected-mesh mode (dsh_api.cpp, SftPart): (c0, s, n1p, pad) -- part 0 = scalars
+    [0, c0), separator [c0, c0 + s) with s = 16 ceil(kd / 16) >= the half-bandwidth, part 1 = the rest (reversed, behind `pad` identity
+    scalars that align its separator rows to a tile boundary).  None when the band is too short to cut."""
+    sT = -(-kd // 16)
+    s = 16 * sT
+    c0 = ((Dn - s) // 2 // 16) * 16
+    n1 = Dn - s - c0
+    if sT < 2 or c0 < 64 or n1 < 64:
+        return None
+    n1p = -(-n1 // 16) * 16
+    return c0, s, n1p, n1p - n1
+
+
 def frame_from_synth(fr) -> Frame:
     return Frame(Tcw=fr.Tcw.copy(), K=fr.K.copy(), N=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary, obs_uv=fr.obs_uv,
                  obs_invsig2=fr.obs_invsig2, nodes_xyz=fr.xyz.copy())

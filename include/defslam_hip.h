@@ -153,6 +153,22 @@ int dsh_sft_shared_solve(dsh_ctx* ctx, dsh_comm* comm, const dsh_sft_frame* fram
  * how the protocol is validated against the single-GPU solve where only one GPU is available. */
 int dsh_sft_shared_solve_group(int G, dsh_ctx* const* ctxs, const dsh_sft_frame* frames, dsh_sft_result* results);
 
+/* ---- one CONNECTED template across two GPUs --------------------------------------------------------------------------------
+ * The shared-camera mode above joins patches that only share the camera.  A connected mesh also couples across any cut through its
+ * curvature, stretching and observation edges (DefOptimizer.cc:408-507): the band ordering of the unknowns is therefore cut at a
+ * SEPARATOR of one bandwidth (the 2-ring halo of the cut), rank 0 factors the part in front of it, rank 1 the part behind it (in
+ * reversed order), both all-reduce their Schur contributions to the separator + camera system (one all-reduce of about
+ * (kd^2 / 2 + 8 kd) doubles per damping trial), solve that reduced system redundantly, back-substitute their own part, and a second
+ * all-reduce (6 + 3 n_active doubles) assembles the update.  Residuals, Jacobians and the Levenberg-Marquardt control are replicated
+ * (every rank passes the SAME frame and holds the whole state), so the ranks take identical decisions without further collectives.
+ * The result equals dsh_sft_solve of the same frame (the same Cholesky factorisation in another elimination order; tested against
+ * the oracle).  Needs half-bandwidth <= 256 and a band long enough to cut; exactly two ranks -- a further cut along the same
+ * ordering would make an inner part carry the fill of a whole separator through every column. */
+int dsh_sft_connected_solve(dsh_ctx* ctx, dsh_comm* comm, const dsh_sft_frame* frame, dsh_sft_result* result);
+/* The same protocol inside one process over two contexts (normally on one GPU), the all-reduces done by a summation kernel: how the
+ * protocol is validated where only one GPU is available.  results[2]: one per context (identical). */
+int dsh_sft_connected_solve_group(dsh_ctx* ctx0, dsh_ctx* ctx1, const dsh_sft_frame* frame, dsh_sft_result* results);
+
 /* ---- NRSfM mapping side ----------------------------------------------------------------------- */
 /* Uniform bicubic B-spline (BBS::bbs_t, Thirdparty/BBS/bbs.h:41-50). */
 typedef struct dsh_bbs {

@@ -152,3 +152,81 @@ def test_shared_camera_exchange_protocol_between_two_processes():
     assert [g[0] for g in got] == [0, 1]
     for _, err_cam, err_nodes, err_chi in got:
         assert err_cam < 1e-9 and err_nodes < 1e-9 and err_chi < 1e-12
+
+
+# ---- the connected-mesh protocol between two real processes ---------------------------------------------------------------------
+# dsh_sft_connected_solve: ONE connected template, the band ordering cut at a separator of one bandwidth; rank g eliminates part g, the
+# ranks all-reduce their Schur contributions to the separator + camera system, solve it, back-substitute their part, and all-reduce the
+# pieces of the update.  Here the normal equations of the connected mesh come from the oracle (no GPU in this container), the two
+# all-reduces are gloo, and the result must be the solution of the undivided system.
+def _connected_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import oracle
+    from defslam_amd import sft, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tmpl = synth.make_grid_template(14, 9)            # connected 14 x 9 grid: nothing is dropped at the cut
+        fr = synth.make_frame(tmpl, 500, 11)
+        fr.xyz = fr.xyz + np.random.default_rng(5).normal(scale=0.002, size=fr.xyz.shape)
+        tc = oracle.template_build(tmpl.xyz0, tmpl.facets)
+        regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        H, b, chi = oracle.sft_system(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs)
+        D = H.shape[0]
+        Dn = D - 6
+        Hn = H[6:, 6:]
+        rr, cc = np.nonzero(Hn)
+        kd = int(np.abs(rr - cc).max())                   # scalar half-bandwidth of the node block (all nodes active: natural order)
+        c0, s, n1p, pad = sft.two_sided_cut(Dn, kd)
+        assert s >= kd
+        lam = 1e-3 * np.abs(np.diag(H)).max()
+        Hd = H + lam * np.eye(D)
+        cam = np.arange(6)
+        sep = 6 + np.arange(c0, c0 + s)
+        mine = 6 + (np.arange(0, c0) if rank == 0 else np.arange(c0 + s, Dn))
+        other = 6 + (np.arange(c0 + s, Dn) if rank == 0 else np.arange(0, c0))
+        assert np.abs(H[np.ix_(mine, other)]).max() == 0.0          # the separator decouples the two parts
+        red = np.concatenate([sep, cam])                  # the reduced unknowns: separator, then camera
+        Hgg = Hd[np.ix_(mine, mine)]
+        Hrg = Hd[np.ix_(red, mine)]
+        Sg = -Hrg @ np.linalg.solve(Hgg, Hrg.T)
+        rg = -Hrg @ np.linalg.solve(Hgg, b[mine])
+        if rank == 0:                                     # rank 0 carries the separator block, the camera corner (with their damping) and their right-hand side
+            Sg = Sg + Hd[np.ix_(red, red)]
+            rg = rg + b[red]
+        buf = torch.from_numpy(np.concatenate([Sg[np.tril_indices(red.size)], rg]))
+        dist.all_reduce(buf)                              # first collective: the Schur contributions
+        nt = red.size * (red.size + 1) // 2
+        S = np.zeros((red.size, red.size))
+        S[np.tril_indices(red.size)] = buf[:nt].numpy()
+        S = S + np.tril(S, -1).T
+        xr = np.linalg.solve(S, buf[nt:].numpy())
+        xg = np.linalg.solve(Hgg, b[mine] - Hrg.T @ xr)   # back substitution of the rank's own part
+        x = np.zeros(D)
+        x[mine] = xg
+        if rank == 0:
+            x[red] = xr
+        xt = torch.from_numpy(x)
+        dist.all_reduce(xt)                               # second collective: the pieces of the update
+        xj = np.linalg.solve(Hd, b)
+        q.put((rank, float(np.abs(xt.numpy() - xj).max() / np.abs(xj).max()), int(kd), int(s), int(c0)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_connected_mesh_exchange_protocol_between_two_processes():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_connected_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1]
+    for _, err, kd, s, c0 in got:
+        assert err < 1e-9 and s >= kd and c0 > 0

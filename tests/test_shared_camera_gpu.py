@@ -115,3 +115,64 @@ def test_rccl_communicator_of_one_rank(gpu_ctx):
     assert (f.iters, f.trials) == (ref.iters, ref.trials) and f.iters > 2
     np.testing.assert_array_equal(f.nodes_xyz, ref.nodes_xyz)
     np.testing.assert_array_equal(f.pose7, ref.pose7)
+
+
+# ---- one CONNECTED template cut across two ranks (dsh_sft_connected_solve*) -----------------------------------------------------
+@pytest.mark.parametrize("cfg,pid", [("smoke", 2), ("C2", 1), ("W12", 2), ("W16", 5)])
+def test_connected_mesh_cut_across_two_ranks_equals_the_oracle_solve_of_the_whole_mesh(oracle_mod, cfg, pid):
+    """No facet is dropped at the cut: the template is the connected grid, every curvature / stretching / observation edge that crosses
+    the cut is in the system through the separator (one bandwidth of unknowns, the 2-ring halo of the cut).  Two ranks (two contexts,
+    the all-reduces are summation kernels), rank g factors part g: the Levenberg-Marquardt trajectory, pose and vertices are the
+    oracle's solve of the whole connected mesh; both ranks end with bit-identical results.  Narrow bands (kd <= 128: smoke, C2) and wide
+    ones (kd = 182, 248) alike."""
+    from defslam_amd import sft, synth
+    tmpl, fr = synth.make_problem(cfg, pid)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+    ctxs = [sft.Context(0), sft.Context(0)]
+    try:
+        for c in ctxs:
+            c.template_build(tmpl.xyz0, tmpl.facets)
+        frames = [sft.frame_from_synth(fr), sft.frame_from_synth(fr)]
+        inl = sft.ConnectedPoseOptimizationGroup(ctxs[0], ctxs[1], frames, *regs)
+        _, counts = ctxs[0].problem_info(0)
+        cut = sft.two_sided_cut(int(counts[5]) - 6, int(counts[6]))
+        assert cut is not None and cut[1] >= counts[6]                       # the separator is at least one half-bandwidth wide
+        for f, i in zip(frames, inl):
+            assert f.status == 0 and i == r.ret and f.iters == r.iters and f.trials == r.trials
+            np.testing.assert_array_equal(f.trace[:, [2, 6]], r.trace[:, [2, 6]])
+            np.testing.assert_allclose(f.trace[:, [0, 1, 3, 4]], r.trace[:, [0, 1, 3, 4]], rtol=1e-8)
+            assert np.abs(f.nodes_xyz - r.xyz).max() <= 1e-7 * np.abs(r.xyz).max()
+            assert np.abs(f.pose7 - r.pose7).max() <= 1e-8
+            np.testing.assert_array_equal(f.mvbOutlier, r.outlier.astype(bool))
+            np.testing.assert_allclose(f.chi2_obs, r.chi2_obs, rtol=1e-7, atol=1e-12)
+        np.testing.assert_array_equal(frames[0].nodes_xyz, frames[1].nodes_xyz)      # replicated control: bit-identical on both ranks
+        np.testing.assert_array_equal(frames[0].pose7, frames[1].pose7)
+        np.testing.assert_array_equal(frames[0].trace, frames[1].trace)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_connected_mode_refuses_what_it_cannot_cut_on_every_rank():
+    """A band too short for two parts next to a separator, and a half-bandwidth beyond 256: both contexts get the same error code and
+    nobody is left waiting inside a collective."""
+    from defslam_amd import sft, synth
+    ctxs = [sft.Context(0), sft.Context(0)]
+    try:
+        for rows, cols, m in [(6, 6, 120), (5, 45, 400)]:
+            tmpl = synth.make_grid_template(rows, cols)
+            fr = synth.make_frame(tmpl, m, 0)
+            for c in ctxs:
+                c.template_build(tmpl.xyz0, tmpl.facets)
+            with pytest.raises(sft.DshError):
+                sft.ConnectedPoseOptimizationGroup(ctxs[0], ctxs[1], [sft.frame_from_synth(fr), sft.frame_from_synth(fr)], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+        # the contexts are still usable
+        tmpl, fr = synth.make_problem("smoke", 0)
+        ctxs[0].template_build(tmpl.xyz0, tmpl.facets)
+        f = sft.frame_from_synth(fr)
+        assert sft.DefPoseOptimization(ctxs[0], f, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP) > 0
+    finally:
+        for c in ctxs:
+            c.close()
