@@ -169,6 +169,20 @@ def e2e_legs(ctx, tmpl, m, frames, regs):
                      "trials_per_frame": trials / n_frames, "iters_per_s": iters / tot, "max_vertex_error_vs_gt_last_frame": errs[-1],
                      "what": "synthetic 100-frame sequence (smooth bend + camera loop), warm start frame to frame with the float32 pose round trip; "
                              "sum of dsh_sft_solve wall clocks (frame synthesis excluded)"}
+    # (3) SEQMAP: tracking AND mapping interleaved (BASELINE configs[2] substitute, whole): 40 tracked frames on a 168-node template, every 10th
+    # frame a keyframe whose mapping work (Schwarp initialisation + search + fit, normals, Shape-from-Normals, registration, new template +
+    # embedding) runs between two frames; the frame after it is solved on the new template with RegTemp = 0 (DefTracking.cc:109-115)
+    from defslam_amd import seqmap
+    seq = synth.make_interleaved_sequence(**synth.SEQMAP)
+    seqmap.run(ctx, seq)                                    # warm-up (graph cache, scratch)
+    st = seqmap.run(ctx, seq)
+    tot = st["t_track"] + st["t_map"]
+    out["seq_mapping"] = {"frames": st["frames"], "keyframes": st["keyframes"], "templates": st["templates"], "frames_e2e_per_s": st["frames"] / tot,
+                          "ms_tracking_per_frame": 1e3 * st["t_track"] / st["frames"], "ms_mapping_per_keyframe": 1e3 * st["t_map"] / max(st["keyframes"], 1),
+                          "iters_per_frame": st["iters"] / st["frames"], "min_inlier_fraction": float(min(st["inliers"])),
+                          "what": "synth.SEQMAP: wall clock inside the C-ABI calls of defslam_amd/seqmap.py (tracking every frame, the whole mapping chain every "
+                                  "10th frame, template switch on the next one); synthetic data generation excluded; tests/test_seqmap_gpu.py checks every stage "
+                                  "of this loop against its oracle"}
     return out
 
 

@@ -433,3 +433,96 @@ def make_mapping_scene(n_points: int = 520, n_tracked: int = 380, n_kf: int = 3,
                 invsig=invsig, depth=depth, X=X, kfs=kfs, n_tracked=n_tracked, cam=np.array([fx, fy, cx, cy], np.float32),
                 bounds=np.array([0.0, 640.0, 0.0, 480.0], np.float32), Twc=Twc, map_pts=map_pts, scale_true=scale_true,
                 u_stream=rng.random(n_points + n_points * n_points))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SEQMAP (BASELINE.json configs[2] substitute, whole: deformable tracking AND NRSfM mapping in one sequence).
+# The reference interleaves the two (DefTracking.cc:109-115,175; DefLocalMapping.cc:138-153,172-234): every
+# 10th frame becomes a keyframe, the mapping side fits a Schwarzian warp from the anchor keyframe to it,
+# re-estimates the normals of the anchor's map points, integrates them to a surface, registers the surface to
+# the map and hands tracking a NEW template; the next frame is solved against it with RegTemp = 0.
+# Scene: the anchor keyframe sees a smooth surface; it deforms slowly (a travelling bump along the normal
+# direction) while the camera moves; all keyframes observe the same physical points.
+# ---------------------------------------------------------------------------------------------------------
+SEQMAP = dict(n_frames=41, kf_every=10, n_points=520, n_tracked=380, seed=17, scale_true=1.3, mesh=(12, 14))
+
+
+def make_interleaved_sequence(n_frames: int = 41, kf_every: int = 10, n_points: int = 520, n_tracked: int = 380, seed: int = 17, scale_true: float = 1.3,
+                              mesh=(12, 14)):
+    """Everything the tracking + mapping loop consumes, frame by frame (ground truth included for plausibility checks only)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 520.0, 515.0, 322.5, 241.25
+    u = rng.uniform(-0.5, 0.5, n_points)
+    v = rng.uniform(-0.38, 0.38, n_points)
+
+    def depth_of(uu, vv):
+        return 1.0 + 0.12 * uu - 0.08 * vv + 0.05 * np.sin(2.0 * uu) * np.cos(1.5 * vv)
+
+    depth = depth_of(u, v)
+    X0 = np.stack([u * depth, v * depth, depth], 1)                     # anchor keyframe's camera frame, unit scale
+    desc0 = rng.integers(0, 256, (n_points, 32), dtype=np.uint8)
+    octave = rng.integers(0, 6, n_points)
+    invsig = np.sqrt((1.2 ** (-2.0 * octave)).astype(np.float32)).astype(np.float32)
+    Rwc = _rodrigues(np.array([0.06, 0.03, -0.04]))
+    Twc = np.eye(4, dtype=np.float32)
+    Twc[:3, :3] = Rwc.astype(np.float32)
+    Twc[:3, 3] = np.array([0.1, -0.05, 0.2], np.float32)
+    twc = Twc[:3, 3].astype(np.float64)
+
+    def to_world(Xa):                                                   # anchor frame (unit scale) -> world (map scale)
+        return scale_true * (Xa @ Rwc.T) + twc
+
+    def deformed(Xa, uu, vv, k):                                        # the surface at frame k: a slow travelling bump along the optical axis
+        a = 0.012 * k / max(n_frames - 1, 1)
+        out = Xa.copy()
+        out[:, 2] += a * np.sin(3.0 * uu + 0.08 * k) * np.cos(2.0 * vv)
+        return out
+
+    Rcw0 = Rwc.T
+    tcw0 = -Rcw0 @ twc
+    frames = []
+    for k in range(n_frames):
+        dR = _rodrigues(np.array([0.004 * k, -0.006 * k, 0.002 * k]))
+        Rk = dR @ Rcw0
+        tk = dR @ tcw0 + scale_true * np.array([0.006 * k, -0.004 * k, 0.003 * k])
+        T = np.eye(4)
+        T[:3, :3] = Rk
+        T[:3, 3] = tk
+        Xw = to_world(deformed(X0, u, v, k))
+        Xc = Xw @ Rk.T + tk
+        frames.append(dict(Tcw_gt=T, Xw=Xw, Xc=Xc))
+    kfs = {}
+    # key -1: the keyframe the map was bootstrapped with before the sequence starts (a second view of the undeformed surface with a
+    # decent baseline: one warp alone leaves the normals of the anchor poorly constrained); keys k = kf_every, 2 kf_every, ...: the sequence's own
+    Rb = _rodrigues(np.array([0.06, -0.10, 0.02]))
+    Xc_boot = X0 @ Rb.T + np.array([0.10, -0.06, 0.04])
+    for k in [-1] + list(range(kf_every, n_frames, kf_every)):          # the keyframes' own measurements of the anchor's points
+        Xc = Xc_boot if k < 0 else frames[k]["Xc"]
+        kp = Xc[:, :2] / Xc[:, 2:3] + rng.normal(scale=3e-4, size=(n_points, 2))
+        pix = kp * np.array([fx, fy]) + np.array([cx, cy])
+        desc = desc0.copy()
+        for i in range(n_points):
+            for f in rng.integers(0, 256, int(rng.integers(0, 24))):
+                desc[i, f // 8] ^= np.uint8(1 << (f % 8))
+        n_extra = 300
+        pix_all = np.vstack([pix, np.stack([rng.uniform(0, 640, n_extra), rng.uniform(0, 480, n_extra)], 1)])
+        desc_all = np.vstack([desc, rng.integers(0, 256, (n_extra, 32), dtype=np.uint8)])
+        perm = rng.permutation(pix_all.shape[0])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.shape[0])
+        has_mp = np.zeros(pix_all.shape[0], np.uint8)
+        has_mp[inv[:n_tracked]] = 1
+        kfs[k] = dict(kp_norm=kp.astype(np.float32), pix=pix_all[perm].astype(np.float32), desc=desc_all[perm], index_of_point=inv[:n_points], has_mp=has_mp,
+                      u_stream=rng.random(n_points + n_points * n_points))
+    umin, umax = float(u.min() - 0.10), float(u.max() + 0.10)
+    vmin, vmax = float(v.min() - 0.10), float(v.max() + 0.10)
+    # the first template (what MonocularInitialization + the first mapping pass leave behind): the anchor's true surface on a regular grid
+    rows, cols = mesh
+    gu, gv = np.meshgrid(np.linspace(u.min(), u.max(), cols), np.linspace(v.min(), v.max(), rows))
+    gd = depth_of(gu.ravel(), gv.ravel())
+    nodes0 = to_world(np.stack([gu.ravel() * gd, gv.ravel() * gd, gd], 1))
+    noise = rng.normal(scale=0.4, size=(n_frames, n_points, 2))        # pixel noise of the tracked observations
+    return dict(bbs2=(umin, umax, 13, vmin, vmax, 15, 2), bbs1=(umin, umax, 13, vmin, vmax, 15, 1), kp0=np.stack([u, v], 1).astype(np.float32), desc0=desc0,
+                invsig=invsig, depth=depth, X0=X0, frames=frames, kfs=kfs, n_tracked=n_tracked, cam=np.array([fx, fy, cx, cy], np.float32),
+                bounds=np.array([0.0, 640.0, 0.0, 480.0], np.float32), Twc=Twc, scale_true=scale_true, nodes0=nodes0, mesh=mesh, grid_uv=(gu, gv),
+                facets=regular_triangulation(rows, cols), noise=noise, n_frames=n_frames, kf_every=kf_every)

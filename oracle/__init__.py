@@ -89,6 +89,21 @@ def template_build(xyz0: np.ndarray, facets: np.ndarray) -> TemplateConsts:
                           inc_ptr, inc_edge[:inc_ptr[n]].copy(), boundary, k0, lap0, med.value)
 
 
+def template_embed(tc: TemplateConsts, pts):
+    """TriangularMesh::calculateFeaturesCoordinates (TriangularMesh.cc:133-236) of float32 points: (facet id or -1, facet nodes, float32
+    barycentrics)."""
+    L = lib()
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    n_pts = pts.shape[0]
+    fid = np.zeros(n_pts, np.int32)
+    b = np.zeros((n_pts, 3), np.float32)
+    xyz0 = np.ascontiguousarray(tc.xyz0, np.float64)
+    fs = np.ascontiguousarray(tc.facets, np.int32)
+    L.tmpl_oracle_embed(tc.n, _p(xyz0, C.c_double), int(fs.shape[0]), _p(fs, C.c_int32), n_pts, _p(pts, C.c_float), _p(fid, C.c_int32), _p(b, C.c_float))
+    nodes = np.where((fid >= 0)[:, None], fs[np.maximum(fid, 0)], 0).astype(np.int32)
+    return fid, nodes, b
+
+
 @dataclass
 class SftResult:
     ret: int
