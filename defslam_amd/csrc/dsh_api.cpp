@@ -535,8 +535,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
       }
     }
     size_t used = 0;
-    // placement class of the records (sft_kernels.hip: AsmRec): 1 = observation weights + curvature records, 2 = + node matrices + stretch records
-    const size_t need1 = (((size_t)hh.M + 1) & ~(size_t)1) + 4 * (size_t)hh.S, need2 = need1 + 6 * (size_t)hh.nA + 4 * (size_t)hh.Es;
+    // placement class of the records (sft_kernels.hip: AsmRec): 1 = node positions + observation weights + curvature records, 2 = + node matrices + stretch records
+    const size_t need1 = ((3 * (size_t)hh.n + 1) & ~(size_t)1) + (((size_t)hh.M + 1) & ~(size_t)1) + 4 * (size_t)hh.S, need2 = need1 + 6 * (size_t)hh.nA + 4 * (size_t)hh.Es;
     hh.lds_class = (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
     used += hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
     jl_doubles = std::max(jl_doubles, used);

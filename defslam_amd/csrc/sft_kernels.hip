@@ -17,6 +17,7 @@
 // Every sum is evaluated in a fixed order (no atomics), so a run is bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -275,11 +276,42 @@ __device__ __forceinline__ lds_double* to_lds(double* p) { return (lds_double*)p
 // would put a branch and a wait of its own around every load -- the gathers then cannot batch their loads -- and a generic
 // pointer compiles to flat_* instructions, which count on the LDS counter AND the memory counter.)
 using gdouble = SFT_G double;
+using lds_int = __attribute__((address_space(3))) int;
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// The 2x3 matrix A of a node at world position p: -(1/z) [[fx, 0, -x/z fx], [0, fy, -y/z fy]] R at the node's own camera-frame position
+// (sft_types.h:176-205).  ONE definition: the residual pass (which stores it where there is room) and the assembly (which recomputes it
+// from the LDS copy of the positions where there is not) must produce the same bits.
+__device__ __forceinline__ void node_A(const double* R, const double* t, double fx, double fy, double p0, double p1, double p2, double* A) {
+  const double xs = (R[0] * p0 + R[1] * p1 + R[2] * p2) + t[0];
+  const double ys = (R[3] * p0 + R[4] * p1 + R[5] * p2) + t[1];
+  const double zs = (R[6] * p0 + R[7] * p1 + R[8] * p2) + t[2];
+  const double sc = -1. / zs;
+  const double t00 = sc * fx, t02 = sc * (-xs / zs * fx), t11 = sc * fy, t12 = sc * (-ys / zs * fy);
+#pragma unroll
+  for (int cc = 0; cc < 3; cc++) {
+    A[cc] = (t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc];
+    A[3 + cc] = (0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc];
+  }
+}
+// Stretching record of mesh edge (a, b) with rest length L0: unit gradient / L0 and the residual (sft_types.h:351-377); returns the residual.
+__device__ __forceinline__ void stretch_record(double d0, double d1, double d2, double L0, double* o) {
+  const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  const double er = nrm * (1.0 / L0) - 1.0;
+  const double ddo = 1.0 / (nrm * L0);
+  o[0] = d0 * ddo; o[1] = d1 * ddo; o[2] = d2 * ddo; o[3] = er;
+}
+
+// Placement class of the records of one linearisation (P.lds_class, chosen by the host from the LDS budget of the launch shape):
+//   0: everything in the workspace (global memory)
+//   1: node positions (every residual gathers three to seven of them), observation weights and curvature records in LDS
+//   2: also the node matrices and the stretching records
 template <int CLS>
 struct AsmRec {
-  static constexpr bool WT_L = CLS >= 1, STAR_L = CLS >= 1, A_L = CLS >= 2, STR_L = CLS >= 2;
-  lds_double *wt_l, *A_l, *star_l, *str_l;
-  gdouble *wt_g, *A_g, *star_g, *str_g;
+  static constexpr bool XYZ_L = CLS >= 1, WT_L = CLS >= 1, STAR_L = CLS >= 1, A_L = CLS >= 2, STR_L = CLS >= 2;
+  lds_double *xyz_l, *wt_l, *A_l, *star_l, *str_l;
+  gdouble *xyz_g, *wt_g, *A_g, *star_g, *str_g;
+  __device__ __forceinline__ double xyz(size_t i) const { if constexpr (XYZ_L) return xyz_l[i]; else return xyz_g[i]; }
   __device__ __forceinline__ double wt(int m) const { if constexpr (WT_L) return wt_l[m]; else return wt_g[m]; }
   __device__ __forceinline__ void set_wt(int m, double v) const { if constexpr (WT_L) wt_l[m] = v; else wt_g[m] = v; }
   __device__ __forceinline__ double A(size_t i) const { if constexpr (A_L) return A_l[i]; else return A_g[i]; }
@@ -311,11 +343,12 @@ __device__ __forceinline__ AsmRec<CLS> asm_records(const SftDev& P, double* lds)
   AsmRec<CLS> r;
   lds_double* base = to_lds(lds);
   size_t off = 0;
+  r.xyz_l = base + off; if (AsmRec<CLS>::XYZ_L) off += ((size_t)3 * P.n + 1) & ~(size_t)1;
   r.wt_l = base + off; if (AsmRec<CLS>::WT_L) off += (size_t)(P.M + 1) & ~(size_t)1;
   r.star_l = base + off; if (AsmRec<CLS>::STAR_L) off += 4 * (size_t)P.S;
   r.A_l = base + off; if (AsmRec<CLS>::A_L) off += 6 * (size_t)P.nA;
   r.str_l = base + off; if (AsmRec<CLS>::STR_L) off += 4 * (size_t)P.Es;
-  r.wt_g = P.wtv; r.A_g = P.Anode; r.star_g = P.Jstar; r.str_g = P.Jstr;
+  r.xyz_g = P.xyz; r.wt_g = P.wtv; r.A_g = P.Anode; r.star_g = P.Jstar; r.str_g = P.Jstr;
   return r;
 }
 
@@ -327,12 +360,15 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
     quat_to_R(P.pose + 3, ctl->R);
     ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2];
   }
+  if constexpr (AsmRec<CLS>::XYZ_L) {   // the node positions once, coalesced; every gather below is an LDS read
+    const auto src = P.xyz;
+    for (int i = threadIdx.x; i < 3 * P.n; i += blockDim.x) ar.xyz_l[i] = src[i];
+  }
   __syncthreads();
   double R[9], t[3];
 #pragma unroll
   for (int i = 0; i < 9; i++) R[i] = ctl->R[i];
   t[0] = ctl->t[0]; t[1] = ctl->t[1]; t[2] = ctl->t[2];
-  const auto xyz = P.xyz;
   double chi = 0.0;
   // camera corner of the normal equations, H_cc (lower 21) and b_c (6): accumulated while the camera Jacobian of an observation is
   // in registers, reduced over the block in a fixed tree below (the assembly used to re-read every record for it)
@@ -347,7 +383,7 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
       const double b0 = P.obs_bary[3 * m], b1 = P.obs_bary[3 * m + 1], b2 = P.obs_bary[3 * m + 2];
       double p[3][3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) { p[0][k] = xyz[3 * n0 + k]; p[1][k] = xyz[3 * n1 + k]; p[2][k] = xyz[3 * n2 + k]; }
+      for (int k = 0; k < 3; k++) { p[0][k] = ar.xyz(3 * n0 + k); p[1][k] = ar.xyz(3 * n1 + k); p[2][k] = ar.xyz(3 * n2 + k); }
       double pw[3], pc[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) pw[k] = (b0 * p[0][k] + b1 * p[1][k]) + b2 * p[2][k];
@@ -373,15 +409,14 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
         const double y = (c[0][1] * b0 + c[1][1] * b1) + c[2][1] * b2;
         const double z = (c[0][2] * b0 + c[1][2] * b1) + c[2][2] * b2;
         const double z2 = z * z, fx = P.fx, fy = P.fy;
-        const auto rec = P.camrec + (size_t)m * SFT_CAM_STRIDE;
         const double wt = rho1 * w;
         // row 0: columns 0, 1, 2, 3, 5 (column 4 is zero); row 1: columns 0, 1, 2, 4, 5 (column 3 is zero)
         const double j0[6] = {x * y / z2 * fx, -(1 + (x * x / z2)) * fx, y / z * fx, -1. / z * fx, 0.0, x / z2 * fx};
         const double j1[6] = {(1 + y * y / z2) * fy, -x * y / z2 * fy, -x / z * fy, 0.0, -1. / z * fy, y / z2 * fy};
-        rec[0] = wt; rec[1] = e0; rec[2] = e1;
-        rec[3] = j0[0]; rec[4] = j0[1]; rec[5] = j0[2]; rec[6] = j0[3]; rec[7] = j0[5];
-        rec[8] = j1[0]; rec[9] = j1[1]; rec[10] = j1[2]; rec[11] = j1[4]; rec[12] = j1[5];
-        rec[13] = c2;
+        // the record is one 128-byte line (SFT_CAM_STRIDE = 16): eight 16-byte stores here, one line per gather in the assembly
+        const auto rec = reinterpret_cast<SFT_G v2d*>(P.camrec + (size_t)m * SFT_CAM_STRIDE);
+        rec[0] = (v2d){wt, e0}; rec[1] = (v2d){e1, j0[0]}; rec[2] = (v2d){j0[1], j0[2]}; rec[3] = (v2d){j0[3], j0[5]};
+        rec[4] = (v2d){j1[0], j1[1]}; rec[5] = (v2d){j1[2], j1[4]}; rec[6] = (v2d){j1[5], c2}; rec[7] = (v2d){0.0, 0.0};
         ar.set_wt(m, wt);
         if constexpr (WANT_J) {
           int q = 0;
@@ -397,23 +432,16 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
       const int nd = idx - P.M;
       const int a = P.act[nd];
       if (a >= 0) {
-        const double p0 = xyz[3 * nd], p1 = xyz[3 * nd + 1], p2 = xyz[3 * nd + 2];
+        const double p0 = ar.xyz(3 * nd), p1 = ar.xyz(3 * nd + 1), p2 = ar.xyz(3 * nd + 2);
         if (P.viewed[a]) {   // reference (temporal) edge, EdgesReference: e = v - v_ref (sft_types.h:401-408)
           const double e0 = p0 - P.xyz0[3 * nd], e1 = p1 - P.xyz0[3 * nd + 1], e2 = p2 - P.xyz0[3 * nd + 2];
           chi += (e0 * (P.w_ref * e0) + e1 * (P.w_ref * e1)) + e2 * (P.w_ref * e2);
         }
-        if (WANT_J) {
-          // A_a = -(1/z) [[fx, 0, -x/z fx], [0, fy, -y/z fy]] R at the node's own camera-frame position (sft_types.h:176-205)
-          const double xs = (R[0] * p0 + R[1] * p1 + R[2] * p2) + t[0];
-          const double ys = (R[3] * p0 + R[4] * p1 + R[5] * p2) + t[1];
-          const double zs = (R[6] * p0 + R[7] * p1 + R[8] * p2) + t[2];
-          const double sc = -1. / zs;
-          const double t00 = sc * P.fx, t02 = sc * (-xs / zs * P.fx), t11 = sc * P.fy, t12 = sc * (-ys / zs * P.fy);
+        if constexpr (WANT_J) {
+          double A6[6];
+          node_A(R, t, P.fx, P.fy, p0, p1, p2, A6);
 #pragma unroll
-          for (int cc = 0; cc < 3; cc++) {
-            ar.set_A(6 * (size_t)a + cc, (t00 * R[cc] + 0.0 * R[3 + cc]) + t02 * R[6 + cc]);
-            ar.set_A(6 * (size_t)a + 3 + cc, (0.0 * R[cc] + t11 * R[3 + cc]) + t12 * R[6 + cc]);
-          }
+          for (int k = 0; k < 6; k++) ar.set_A(6 * (size_t)a + k, A6[k]);
         }
       }
     } else if (idx < P.M + P.n + P.S) {
@@ -436,14 +464,14 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
 #pragma unroll
           for (int i = 0; i < NCH; i++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) xx[i][k] = xyz[3 * jj[i] + k];
+            for (int k = 0; k < 3; k++) xx[i][k] = ar.xyz(3 * jj[i] + k);
 #pragma unroll
           for (int i = 0; i < NCH; i++)
             if (qb + i < q1) { a0 = a0 + ww[i] * xx[i][0]; a1 = a1 + ww[i] * xx[i][1]; a2 = a2 + ww[i] * xx[i][2]; }
         }
       }
       const double sw = P.nbr_sumw[nd];
-      const double m0 = xyz[3 * nd] - a0 / sw, m1 = xyz[3 * nd + 1] - a1 / sw, m2 = xyz[3 * nd + 2] - a2 / sw;
+      const double m0 = ar.xyz(3 * nd) - a0 / sw, m1 = ar.xyz(3 * nd + 1) - a1 / sw, m2 = ar.xyz(3 * nd + 2) - a2 / sw;
       const double nrm = sqrt(m0 * m0 + m1 * m1 + m2 * m2);
       const double r = nrm - P.k0[nd];
       chi += (P.w_curv * P.star_sL[s]) * (r * r);
@@ -454,15 +482,12 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
     } else {
       const int e = idx - P.M - P.n - P.S;
       const int a = P.str_nodes[2 * e], b = P.str_nodes[2 * e + 1];
-      const double d0 = xyz[3 * a] - xyz[3 * b], d1 = xyz[3 * a + 1] - xyz[3 * b + 1], d2 = xyz[3 * a + 2] - xyz[3 * b + 2];
-      const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-      const double L0 = P.str_L0[e];
-      const double er = nrm * (1.0 / L0) - 1.0;
+      const double d0 = ar.xyz(3 * a) - ar.xyz(3 * b), d1 = ar.xyz(3 * a + 1) - ar.xyz(3 * b + 1), d2 = ar.xyz(3 * a + 2) - ar.xyz(3 * b + 2);
+      double sr[4];
+      stretch_record(d0, d1, d2, P.str_L0[e], sr);
+      const double er = sr[3];
       chi += er * (P.w_str * er);
-      if (WANT_J) {
-        const double ddo = 1.0 / (nrm * L0);
-        ar.set_str(e, d0 * ddo, d1 * ddo, d2 * ddo, er);
-      }
+      if constexpr (WANT_J) ar.set_str(e, sr[0], sr[1], sr[2], sr[3]);
     }
   }
   if constexpr (WANT_J) {
@@ -489,7 +514,6 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
 // there, nothing is padded to tiles in memory; the other storage modes (wide tiles, row-major band) store the elements into their
 // layout.  No workgroup barrier inside: the wavefronts of a problem drift apart and cover each other's gather latency.
 // ------------------------------------------------------------------------------------------
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 // Sum over the 8 lanes of a group into its first lane with data-parallel-primitive moves (row_shl: lane i reads lane i + n of its
 // 16-lane row; no LDS crossbar, no wait): only the lanes that feed lane 0 of a group matter, and they read inside the group.
@@ -627,7 +651,7 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       if (on) {
         const int ob0 = cur.dob0, ob1 = cur.dob1, sh0 = cur.dsh0, sh1 = cur.dsh1;
         constexpr int DCH = 2, HCH = 3;   // per lane and round trip: 8 lanes x 2 = 16 observations, 8 x 3 = 24 curvature / stretch contributions
-        auto add_obs = [&](const double (&rr)[13], double b) {
+        auto add_obs = [&](const double (&rr)[14], double b) {
           const double om = rr[0] * b;
           sii += om * b;
 #pragma unroll
@@ -664,12 +688,12 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
           c1[i] = in ? P.sh_cf[2 * p + 1] : 0.0;
         }
         {
-          double rr[DCH][13], r[HCH][4];
+          double rr[DCH][14], r[HCH][4];
 #pragma unroll
-          for (int i = 0; i < DCH; i++) {
-            const auto rec = P.camrec + (size_t)mm[i] * SFT_CAM_STRIDE;
+          for (int i = 0; i < DCH; i++) {   // the record is one 128-byte line: seven 16-byte loads
+            const auto rec = reinterpret_cast<const SFT_G v2d*>(P.camrec + (size_t)mm[i] * SFT_CAM_STRIDE);
 #pragma unroll
-            for (int k = 0; k < 13; k++) rr[i][k] = rec[k];
+            for (int k = 0; k < 7; k++) { const v2d v = rec[k]; rr[i][2 * k] = v.x; rr[i][2 * k + 1] = v.y; }
           }
 #pragma unroll
           for (int i = 0; i < HCH; i++) ar.rec4((rc[i] >> 30) == SFT_KIND_STAR, rc[i] & 0x3FFFFFu, rc[i] != 0xFFFFFFFFu, r[i]);
@@ -681,10 +705,10 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
             if (rc[i] != 0xFFFFFFFFu) add_sh(rc[i], c0[i], c1[i], r[i]);
         }
         for (int p = ob0 + sub + 8 * DCH; p < ob1; p += 8) {   // nodes seen by more than 16 observations
-          const auto rec = P.camrec + (size_t)P.ob_m[p] * SFT_CAM_STRIDE;
-          double rr[13];
+          const auto rec = reinterpret_cast<const SFT_G v2d*>(P.camrec + (size_t)P.ob_m[p] * SFT_CAM_STRIDE);
+          double rr[14];
 #pragma unroll
-          for (int k = 0; k < 13; k++) rr[k] = rec[k];
+          for (int k = 0; k < 7; k++) { const v2d v = rec[k]; rr[2 * k] = v.x; rr[2 * k + 1] = v.y; }
           add_obs(rr, P.ob_c[p]);
         }
         for (int p = sh0 + sub + 8 * HCH; p < sh1; p += 8) {   // more than 24 curvature / stretch contributions
@@ -1452,7 +1476,6 @@ __device__ __noinline__ void factor_tiles(const SftDev& P, Ctl* ctl, double* ws)
 // (LDS flags written after the data, polled with s_sleep) and may lag behind by up to one step (Xp / LinvK / Abord
 // are double buffered by step parity; a wave re-enters a buffer only after every wave has finished with it).
 // ------------------------------------------------------------------------------------------
-using lds_int = __attribute__((address_space(3))) int;
 __device__ __forceinline__ void flag_set(lds_int* f, int v) {      // publish: data first, then the flag
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) *(volatile lds_int*)f = v;

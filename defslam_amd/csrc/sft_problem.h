@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #define SFT_NT 512             // threads of the band-mode workgroup / upper bound of the tile-mode one (8 wavefronts)
-#define SFT_CAM_STRIDE 14      // doubles per observation camera record: rho' w, e0, e1, five non-zero entries of each row of J_cam (+1 pad: 16-byte rows)
+#define SFT_CAM_STRIDE 16      // doubles per observation camera record: rho' w, e0, e1, five non-zero entries of each row of J_cam, chi2, 2 pad = ONE 128-byte line
 #define SFT_BORDER 7           // 6 camera rows + the right-hand side carried through the factorisation
 // tile mode keeps zero padding around H so that the sliding window loads every tile unconditionally:
 #define SFT_H_PAD_TILE_ROWS 9  // zero tile rows below the band matrix (window height BT + the look-ahead tile)
