@@ -23,7 +23,8 @@ extern "C" hipError_t nrsfm_swp_step(int, const double*, const double*, const do
 extern "C" size_t nrsfm_swp_fit_bytes();
 extern "C" void nrsfm_swp_fit_fill(void*, double, double, int, double, double, int, int, double, double, double, float, float, int, const float*, const float*, const float*,
                                    double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, double*, float*, uint8_t*, int32_t*, double*,
-                                   const double*);
+                                   const double*, void*);
+extern "C" size_t nrsfm_swp_compact_bytes(int, int, int);
 extern "C" hipError_t nrsfm_swp_fit_batch(void*, int, int, int, int, int, hipStream_t);
 namespace dsh { void bbs_bending_dense(const dsh_bbs* b, double lambda, double* Bm); }
 extern "C" hipError_t nrsfm_swp_diffprop(double, double, int, double, double, int, int, const float*, const float*, const double*, float, float, float*,
@@ -185,10 +186,12 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
     } else {
       std::memcpy(hx + o.xo, q.x, 8 * (size_t)n2);
     }
-    DevBuf xn, g, dx, r, J, A, M, W, scal;
+    DevBuf xn, g, dx, r, J, A, M, W, scal, compact;
     const size_t np = (size_t)nrsfm_swp_solve_np(n2);
     HIPCHK(c, xn.alloc(c, 8 * (size_t)n2)); HIPCHK(c, g.alloc(c, 8 * (size_t)n2)); HIPCHK(c, dx.alloc(c, 8 * (size_t)n2)); HIPCHK(c, r.alloc(c, 8 * (size_t)m));
-    HIPCHK(c, J.alloc(c, 8 * (size_t)m * n2)); HIPCHK(c, A.alloc(c, 8 * (size_t)n2 * n2)); HIPCHK(c, M.alloc(c, 8 * np * np)); HIPCHK(c, W.alloc(c, 8 * np * 16));
+    // the dense (2P+4N) x 2N buffer only serves the Warp::initialize stage (its colocation matrix); the fit keeps its Jacobian structured
+    HIPCHK(c, J.alloc(c, q.init_lambda > 0.0 ? 8 * (size_t)m * n2 : 256)); HIPCHK(c, compact.alloc(c, nrsfm_swp_compact_bytes(q.P, q.bbs.nptsu, q.bbs.nptsv)));
+    HIPCHK(c, A.alloc(c, 8 * (size_t)n2 * n2)); HIPCHK(c, M.alloc(c, 8 * np * np)); HIPCHK(c, W.alloc(c, 8 * np * 16));
     HIPCHK(c, scal.alloc(c, 128));
     HIPCHK(c, hipMemsetAsync(scal.p, 0, 128, st));
     HIPCHK(c, hipMemsetAsync(dx.p, 0, 8 * (size_t)n2, st));
@@ -197,7 +200,7 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
                        reinterpret_cast<double*>(dob + o.xo), xn.as<double>(), reinterpret_cast<double*>(dib + o.cs), g.as<double>(), dx.as<double>(), r.as<double>(),
                        J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal.as<double>(), q.diff ? reinterpret_cast<float*>(dob + o.diff) : nullptr,
                        q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr, reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs),
-                       q.init_lambda > 0.0 ? reinterpret_cast<const double*>(dib + o.bend) : nullptr);
+                       q.init_lambda > 0.0 ? reinterpret_cast<const double*>(dib + o.bend) : nullptr, compact.p);
   }
   HIPCHK(c, hipMemcpyAsync(dib, hin, in_bytes, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(dob, hx, out_bytes, hipMemcpyHostToDevice, st));

@@ -420,6 +420,175 @@ __device__ __forceinline__ void swp_eval_body(SwpPar p, const float* __restrict_
   }
 }
 
+// The same residuals with the Jacobian in its structured form (SwpFit::Jw, Js): no dense (2P+4N) x 2N matrix is ever written.
+__device__ __forceinline__ void swp_evalc_body(SwpPar p, const float* __restrict__ kp1, const float* __restrict__ kp2, const float* __restrict__ invsig,
+                                               const double* __restrict__ x, double* __restrict__ r, double* __restrict__ Jw, double* __restrict__ Js) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < p.P) {
+    const int i = t;
+    const double u = kp1[2 * i], v = kp1[2 * i + 1];
+    double ex, ey;
+    swp_eval16(p, x, u, v, 0, 0, ex, ey);
+    r[i] = invsig[i] * ((double)kp2[2 * i] - ex) * p.fxs;
+    r[i + p.P] = invsig[i] * ((double)kp2[2 * i + 1] - ey) * p.fys;
+    int cols[16]; double w[16];
+    const bool in = swp_taps(p, u, v, 0, 0, cols, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) Jw[(size_t)i * 16 + k] = in ? -w[k] * p.fxs : 0.0;   // x row = y row (Schwarp.cc:291-298)
+  } else if (t < p.P + p.N) {
+    const int k = t - p.P;
+    const int iu = k / p.nv, iv = k % p.nv;
+    const double X = (double)((p.umax - p.umin) * iu) / (p.nu - 1) + p.umin;
+    const double Y = (double)((p.vmax - p.vmin) * iv) / (p.nv - 1) + p.vmin;
+    double xu, yu, xv, yv, xuu, yuu, xvv, yvv, xuv, yuv;
+    swp_eval16(p, x, X, Y, 1, 0, xu, yu);
+    swp_eval16(p, x, X, Y, 0, 1, xv, yv);
+    swp_eval16(p, x, X, Y, 2, 0, xuu, yuu);
+    swp_eval16(p, x, X, Y, 0, 2, xvv, yvv);
+    swp_eval16(p, x, X, Y, 1, 1, xuv, yuv);
+    const double lam = p.lambda;
+    double* rs = r + 2 * p.P;
+    rs[k] = ((xuu * yu - yuu * xu)) * lam;
+    rs[p.N + k] = ((yvv * xv - xvv * yv)) * lam;
+    rs[2 * p.N + k] = ((xuu * yv - yuu * xv + 2 * (xuv * yu - yuv * xu))) * lam;
+    rs[3 * p.N + k] = ((yvv * xu - xvv * yu + 2 * (yuv * xv - xuv * yv))) * lam;
+    int c[16]; double wu[16], wv[16], wuu[16], wvv[16], wuv[16];
+    const bool in = swp_taps(p, X, Y, 1, 0, c, wu);
+    if (in) { swp_taps(p, X, Y, 0, 1, c, wv); swp_taps(p, X, Y, 2, 0, c, wuu); swp_taps(p, X, Y, 0, 2, c, wvv); swp_taps(p, X, Y, 1, 1, c, wuv); }
+    double* J0 = Js + (size_t)k * 128;
+    for (int q = 0; q < 16; q++) {
+      const double Cu = in ? wu[q] : 0.0, Cv = in ? wv[q] : 0.0, Cuu = in ? wuu[q] : 0.0, Cvv = in ? wvv[q] : 0.0, Cuv = in ? wuv[q] : 0.0;
+      J0[q] = lam * (yu * Cuu - yuu * Cu);
+      J0[16 + q] = lam * (xuu * Cu - xu * Cuu);
+      J0[32 + q] = lam * (yvv * Cv - yv * Cvv);
+      J0[48 + q] = lam * (xv * Cvv - xvv * Cv);
+      J0[64 + q] = lam * (yv * Cuu - yuu * Cv + 2 * yu * Cuv - 2 * yuv * Cu);
+      J0[80 + q] = lam * (xuu * Cv - xv * Cuu + 2 * xuv * Cu - 2 * xu * Cuv);
+      J0[96 + q] = lam * (yvv * Cu - yu * Cvv - 2 * yv * Cuv + 2 * yuv * Cv);
+      J0[112 + q] = lam * (xu * Cvv - xvv * Cu - 2 * xuv * Cv + 2 * xv * Cuv);
+    }
+  }
+}
+
+// Rows bucketed by knot cell, once per fit (the key points do not move).  First the cell of every match and grid site (one lane each;
+// -1 outside the spline domain: in no bucket), then one 256-thread workgroup per fit: thread c owns cell c and walks the cell ids in
+// index order (a fixed order of the sums below).
+__device__ __forceinline__ void swp_cellid_body(SwpPar p, const float* __restrict__ kp1, int32_t* __restrict__ cid) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.P + p.N) return;
+  const int ncv = p.nv - 3;
+  double u, v;
+  if (t < p.P) { u = kp1[2 * t]; v = kp1[2 * t + 1]; }
+  else {
+    const int k = t - p.P, iu = k / p.nv, iv = k % p.nv;
+    u = (double)((p.umax - p.umin) * iu) / (p.nu - 1) + p.umin;
+    v = (double)((p.vmax - p.vmin) * iv) / (p.nv - 1) + p.vmin;
+  }
+  double nx; int Iu, Iv;
+  norm_inter(p.umin, p.umax, p.nu, u, nx, Iu);
+  norm_inter(p.vmin, p.vmax, p.nv, v, nx, Iv);
+  cid[t] = (Iu < 0 || Iu > p.nu - 4 || Iv < 0 || Iv > p.nv - 4) ? -1 : Iu * ncv + Iv;
+}
+__device__ __forceinline__ void swp_buckets_body(SwpPar p, const int32_t* cid, int32_t* __restrict__ bw_ptr, int32_t* __restrict__ bw_idx,
+                                                 int32_t* __restrict__ bs_ptr, int32_t* __restrict__ bs_idx, bool use_lds) {
+  __shared__ int cnt[2][512];
+  extern __shared__ int cid_l[];                 // the cell ids, read ncell times: from LDS
+  const int ncell = (p.nu - 3) * (p.nv - 3);
+  const int t = threadIdx.x;
+  if (use_lds) {
+    for (int i = t; i < p.P + p.N; i += blockDim.x) cid_l[i] = cid[i];
+    __syncthreads();
+    cid = cid_l;
+  }
+  for (int c = t; c < ncell; c += blockDim.x) {
+    int nw = 0, ns = 0;
+    for (int i = 0; i < p.P; i++) nw += cid[i] == c;
+    for (int k = 0; k < p.N; k++) ns += cid[p.P + k] == c;
+    cnt[0][c] = nw; cnt[1][c] = ns;
+  }
+  __syncthreads();
+  if (t < 2) {
+    int32_t* ptr = t == 0 ? bw_ptr : bs_ptr;
+    int acc = 0;
+    for (int c = 0; c < ncell; c++) { ptr[c] = acc; acc += cnt[t][c]; }
+    ptr[ncell] = acc;
+  }
+  __syncthreads();
+  for (int c = t; c < ncell; c += blockDim.x) {
+    int qw = bw_ptr[c], qs = bs_ptr[c];
+    for (int i = 0; i < p.P; i++) if (cid[i] == c) bw_idx[qw++] = i;
+    for (int k = 0; k < p.N; k++) if (cid[p.P + k] == c) bs_idx[qs++] = k;
+  }
+}
+
+// A = (J S)^T (J S) and g = (J S)^T r from the structured Jacobian, as a GATHER: one wavefront per control point l1; lane nb < 49 owns the
+// pair (l1, l2) with l2 in the 7 x 7 neighbourhood of l1 (two control points share a row of J only if a knot cell's 4 x 4 patch holds
+// both) and sums, over the <= 16 cells that hold both and over the rows of each cell in bucket order, the four products
+// (x|y of l1) x (x|y of l2).  The Huber weight of the reprojection block (one scalar for all 2P rows) and the duplicated y row enter as
+// the factor 2 rho' on the warp rows' sum.  Rows l1 and N + l1 of A are written completely (zeros outside the neighbourhood): no
+// memset, no atomics, both triangles from the same commutative products (bit-symmetric).  ~2.6 MFLOP where the dense product spent 460.
+__device__ __forceinline__ void swp_normalc_body(SwpPar p, const double* __restrict__ Jw, const double* __restrict__ Js, const int32_t* __restrict__ bw_ptr,
+                                                 const int32_t* __restrict__ bw_idx, const int32_t* __restrict__ bs_ptr, const int32_t* __restrict__ bs_idx,
+                                                 const double* __restrict__ r, const double* __restrict__ cs, const double* __restrict__ scal,
+                                                 double* __restrict__ A, double* __restrict__ g) {
+  const int N = p.N, n2 = 2 * N, nv = p.nv, ncv = p.nv - 3, ncu = p.nu - 3;
+  const int l1 = blockIdx.x, lane = threadIdx.x;
+  const int iu1 = l1 / nv, iv1 = l1 % nv;
+  const double rho1 = scal[1] * scal[1];        // scal[1] = sqrt(rho')
+  for (int j = lane; j < n2; j += 64) { A[(size_t)l1 * n2 + j] = 0.0; A[(size_t)(N + l1) * n2 + j] = 0.0; }
+  __syncthreads();
+  if (lane < 49) {
+    const int iu2 = iu1 + lane / 7 - 3, iv2 = iv1 + lane % 7 - 3;
+    if (iu2 >= 0 && iu2 < p.nu && iv2 >= 0 && iv2 < nv) {
+      const int l2 = iu2 * nv + iv2;
+      double wxx = 0.0, sxx = 0.0, sxy = 0.0, syx = 0.0, syy = 0.0;
+      for (int Iu = max(max(iu1, iu2) - 3, 0); Iu <= min(min(iu1, iu2), ncu - 1); Iu++)
+        for (int Iv = max(max(iv1, iv2) - 3, 0); Iv <= min(min(iv1, iv2), ncv - 1); Iv++) {
+          const int cell = Iu * ncv + Iv;
+          const int a = 4 * (iu1 - Iu) + (iv1 - Iv), b = 4 * (iu2 - Iu) + (iv2 - Iv);
+          const int w0 = bw_ptr[cell], w1 = bw_ptr[cell + 1];
+#pragma unroll 4
+          for (int q = w0; q < w1; q++) { const size_t i = (size_t)bw_idx[q] * 16; wxx = fma(Jw[i + a], Jw[i + b], wxx); }
+          const int s0 = bs_ptr[cell], s1 = bs_ptr[cell + 1];
+          for (int q = s0; q < s1; q++) {
+            const double* Jk = Js + (size_t)bs_idx[q] * 128;
+#pragma unroll
+            for (int rw = 0; rw < 4; rw++) {
+              const double xa = Jk[32 * rw + a], ya = Jk[32 * rw + 16 + a], xb = Jk[32 * rw + b], yb = Jk[32 * rw + 16 + b];
+              sxx = fma(xa, xb, sxx); sxy = fma(xa, yb, sxy); syx = fma(ya, xb, syx); syy = fma(ya, yb, syy);
+            }
+          }
+        }
+      const double c1x = cs[l1], c1y = cs[N + l1], c2x = cs[l2], c2y = cs[N + l2];
+      A[(size_t)l1 * n2 + l2] = (2.0 * rho1 * wxx + sxx) * (c1x * c2x);
+      A[(size_t)l1 * n2 + N + l2] = sxy * (c1x * c2y);
+      A[(size_t)(N + l1) * n2 + l2] = syx * (c1y * c2x);
+      A[(size_t)(N + l1) * n2 + N + l2] = syy * (c1y * c2y);
+    }
+  }
+  // g: sixteen lanes, one per knot cell that holds l1; their partial sums are added in cell order
+  double gx = 0.0, gy = 0.0;
+  if (lane < 16) {
+    const int Iu = iu1 - 3 + lane / 4, Iv = iv1 - 3 + lane % 4;
+    if (Iu >= 0 && Iu < ncu && Iv >= 0 && Iv < ncv) {
+      const int cell = Iu * ncv + Iv, a = 4 * (iu1 - Iu) + (iv1 - Iv);
+      double gw = 0.0;
+      for (int q = bw_ptr[cell]; q < bw_ptr[cell + 1]; q++) { const int i = bw_idx[q]; gw = fma(Jw[(size_t)i * 16 + a], r[i] + r[i + p.P], gw); }
+      gx = rho1 * gw;      // (sqrt(rho') J)^T (sqrt(rho') r) for the x row and its copy, the y row
+      const double* rs = r + 2 * p.P;
+      for (int q = bs_ptr[cell]; q < bs_ptr[cell + 1]; q++) {
+        const int k = bs_idx[q];
+        const double* Jk = Js + (size_t)k * 128;
+#pragma unroll
+        for (int rw = 0; rw < 4; rw++) { gx = fma(Jk[32 * rw + a], rs[rw * N + k], gx); gy = fma(Jk[32 * rw + 16 + a], rs[rw * N + k], gy); }
+      }
+    }
+  }
+  double tx = 0.0, ty = 0.0;
+  for (int j = 0; j < 16; j++) { tx += __shfl(gx, j, 64); ty += __shfl(gy, j, 64); }
+  if (lane == 0) { g[l1] = tx * cs[l1]; g[N + l1] = ty * cs[N + l1]; }
+}
+
 // Fixed-tree block sum: lane t sums its contiguous chunk in ascending order, then a binary tree over the 256 partial
 // sums (bit-reproducible run to run; differs from a sequential sum only in the last bits).
 __device__ double swp_block_sum256(double v, double* red) {
@@ -1096,6 +1265,13 @@ struct SwpFit {
   // the fit: C in J, the two right-hand sides in r, C^T C + Bending in A, C^T kp2 in g, the factor in M / W.
   const double* bend;
   int npi, bwti;                 // padded size and band width (in tiles) of the N x N system
+  // Structured Jacobian of the fit (every row touches the 4 x 4 patch of control points of ONE knot cell -- SURVEY 7 K11): the warp rows
+  // as 16 values per match (the x row; the reference's y row is a copy of it, Schwarp.cc:291-298), the Schwarzian rows as 32 values per
+  // row (16 for each coordinate), and the rows bucketed by knot cell (matches in index order: a fixed summation order).
+  double *Jw, *Js;               // P x 16;  N x 4 x 32 (site, row, [x taps | y taps])
+  int32_t *bw_ptr, *bw_idx;      // ncell + 1, P: matches of cell (Iu, Iv) = Iu * (nv - 3) + Iv
+  int32_t *bs_ptr, *bs_idx;      // ncell + 1, N: grid sites of the cell
+  int32_t* cid;                  // P + N: knot cell of every match / grid site (-1: outside the domain)
 };
 #define SWP_STAGE_ALWAYS 0      // setup stages: run for every fit
 #define SWP_STAGE_ACTIVE 1      // stages of an iteration: skipped once the fit is done
@@ -1113,7 +1289,7 @@ __global__ void swpb_eval_kernel(const SwpFit* fits, int stage, int at_xn) {
 }
 __global__ void swpb_zero_j_kernel(const SwpFit* fits, int stage) {
   const SwpFit& f = fits[blockIdx.y];
-  if (!swp_on(f, stage)) return;
+  if (!swp_on(f, stage) || !f.bend) return;      // (only the Warp::initialize stage has a dense buffer)
   const size_t tot = (size_t)f.m * f.n2 / 2;
   v2d_t* J2 = reinterpret_cast<v2d_t*>(f.J);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) J2[i] = (v2d_t){0.0, 0.0};
@@ -1132,6 +1308,24 @@ __global__ __launch_bounds__(256) void swpb_normal_kernel(const SwpFit* fits, in
   const SwpFit& f = fits[blockIdx.y];
   if (!swp_on(f, stage)) return;
   swp_normal_body(f.m, f.n2, nt, f.J, f.r, f.cs, f.A, f.g);
+}
+__global__ void swpb_evalc_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage)) return;
+  swp_evalc_body(f.p, f.kp1, f.kp2, f.isg, f.x, f.r, f.Jw, f.Js);
+}
+__global__ void swpb_cellid_kernel(const SwpFit* fits) {
+  const SwpFit& f = fits[blockIdx.y];
+  swp_cellid_body(f.p, f.kp1, f.cid);
+}
+__global__ __launch_bounds__(256) void swpb_buckets_kernel(const SwpFit* fits, int use_lds) {
+  const SwpFit& f = fits[blockIdx.y];
+  swp_buckets_body(f.p, f.cid, f.bw_ptr, f.bw_idx, f.bs_ptr, f.bs_idx, use_lds != 0);
+}
+__global__ __launch_bounds__(64) void swpb_normalc_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.y];
+  if (!swp_on(f, stage) || (int)blockIdx.x >= f.p.N) return;
+  swp_normalc_body(f.p, f.Jw, f.Js, f.bw_ptr, f.bw_idx, f.bs_ptr, f.bs_idx, f.r, f.cs, f.scal, f.A, f.g);
 }
 __global__ void swpb_colscale_kernel(const SwpFit* fits, int stage) {
   const SwpFit& f = fits[blockIdx.y];
@@ -1367,7 +1561,7 @@ extern "C" size_t nrsfm_swp_fit_bytes() { return sizeof(SwpFit); }
 extern "C" void nrsfm_swp_fit_fill(void* host_slot, double umin, double umax, int nu, double vmin, double vmax, int nv, int P, double fxs, double fys, double lambda,
                                    float fx, float fy, int max_iters, const float* kp1, const float* kp2, const float* isg, double* x, double* xn, double* cs,
                                    double* g, double* dx, double* r, double* J, double* A, double* M, double* W, double* scal, float* diff, uint8_t* drop,
-                                   int32_t* info, double* costs, const double* bend) {
+                                   int32_t* info, double* costs, const double* bend, void* compact) {
   SwpFit f{};
   f.p = SwpPar{umin, umax, vmin, vmax, fxs, fys, lambda, nu, nv, nu * nv, P};
   f.fx = fx; f.fy = fy;
@@ -1379,7 +1573,22 @@ extern "C" void nrsfm_swp_fit_fill(void* host_slot, double umin, double umax, in
   f.bend = bend;
   f.npi = nrsfm_swp_solve_np(nu * nv);
   f.bwti = min(f.npi / 16 - 1, (3 * nv + 3 + 15) / 16);   // colocation and bending couple a 4 x 4 patch of control points
+  {   // structured Jacobian + row buckets (nrsfm_swp_compact_bytes)
+    const int N = nu * nv, ncell = (nu - 3) * (nv - 3);
+    char* cb = static_cast<char*>(compact);
+    f.Jw = reinterpret_cast<double*>(cb); cb += 8 * (size_t)P * 16;
+    f.Js = reinterpret_cast<double*>(cb); cb += 8 * (size_t)N * 128;
+    f.bw_ptr = reinterpret_cast<int32_t*>(cb); cb += 4 * (size_t)(ncell + 1);
+    f.bw_idx = reinterpret_cast<int32_t*>(cb); cb += 4 * (size_t)P;
+    f.bs_ptr = reinterpret_cast<int32_t*>(cb); cb += 4 * (size_t)(ncell + 1);
+    f.bs_idx = reinterpret_cast<int32_t*>(cb); cb += 4 * (size_t)N;
+    f.cid = reinterpret_cast<int32_t*>(cb);
+  }
   memcpy(host_slot, &f, sizeof f);
+}
+extern "C" size_t nrsfm_swp_compact_bytes(int P, int nu, int nv) {
+  const size_t N = (size_t)nu * nv, ncell = (size_t)(nu - 3) * (nv - 3);
+  return 8 * (size_t)P * 16 + 8 * N * 128 + 4 * (ncell + 1) * 2 + 4 * (size_t)P + 4 * N + 4 * ((size_t)P + N) + 64;
 }
 extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int maxN, int max_iters, int with_init, hipStream_t st) {
   SwpFit* fits = static_cast<SwpFit*>(d_fits_v);
@@ -1393,13 +1602,18 @@ extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int m
   }
   const int nt = (maxn2 + 15) / 16, tiles = nt * (nt + 1) / 2;
   const dim3 g_eval((maxP + maxN + 127) / 128, B), g_one(1, B);
-  auto linearise = [&](int stage) {   // residuals + Jacobian at x, loss, Huber row scaling, normal equations
-    hipLaunchKernelGGL(swpb_zero_j_kernel, dim3(64, B), dim3(256), 0, st, fits, stage);
-    hipLaunchKernelGGL(swpb_eval_kernel<true>, g_eval, dim3(128), 0, st, fits, stage, 0);
+  (void)tiles;
+  auto linearise = [&](int stage) {   // residuals + structured Jacobian at x, loss (the Huber weight of the warp block), normal equations by gather
+    hipLaunchKernelGGL(swpb_evalc_kernel, g_eval, dim3(128), 0, st, fits, stage);
     hipLaunchKernelGGL(swpb_loss_kernel, g_one, dim3(256), 0, st, fits, stage);
-    hipLaunchKernelGGL(swpb_scale_kernel, dim3(64, B), dim3(256), 0, st, fits, stage);
-    hipLaunchKernelGGL(swpb_normal_kernel, dim3(tiles, B), dim3(256), 0, st, fits, stage, nt);
+    hipLaunchKernelGGL(swpb_normalc_kernel, dim3(maxN, B), dim3(64), 0, st, fits, stage);
   };
+  hipLaunchKernelGGL(swpb_cellid_kernel, g_eval, dim3(128), 0, st, fits);
+  {
+    const size_t cid_bytes = sizeof(int) * (size_t)(maxP + maxN);
+    const int use_lds = cid_bytes <= 48 * 1024;      // (very many matches: the cell ids stay in memory)
+    hipLaunchKernelGGL(swpb_buckets_kernel, g_one, dim3(256), use_lds ? cid_bytes : 0, st, fits, use_lds);
+  }
   const dim3 g_ctl((B + 63) / 64);
   if (with_init) {   // Warp::initialize for the fits that ask for it: same launches for everybody, a fit without it leaves at once
     const int npi = nrsfm_swp_solve_np(maxN), nti = (maxN + 15) / 16, tiles_i = nti * (nti + 1) / 2;
