@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector == matrix peak
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def kernel_source_hash() -> str:
