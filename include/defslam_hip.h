@@ -233,7 +233,8 @@ int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, c
 
 /* The same fit for B keyframe pairs at once (SchwarpDatabase::add fits one warp per anchor keyframe of the new keyframe,
  * SchwarpDatabase.cc:50-128): one copy up, a fixed sequence of launches in which all fits advance together with the
- * trust-region control on the device (no host round trip), one copy back.  Same results as B calls of dsh_schwarp_fit. */
+ * trust-region control on the device (no host round trip), one copy back.  A fit's result does not depend on what else is in the batch
+ * (dsh_schwarp_fit is the batch of one). */
 typedef struct dsh_schwarp_problem {
   dsh_bbs bbs;
   int32_t P;

@@ -151,10 +151,13 @@ def test_schwarp_fit_batch_equals_single_fits_and_the_oracle(gpu_ctx, oracle_mod
     regularisation, iteration limits and outlier rates advance together with the trust-region control on the device; every
     result is bit-identical to the single call and follows the oracle's accept / reject sequence."""
     from defslam_amd import nrsfm, synth
-    cases = [(300, 3, 0.1, 0.0, 3), (150, 5, 1.0, 0.0, 12), (40, 9, 0.5, 0.1, 3), (500, 21, 1e-2, 0.05, 3), (80, 22, 1e-2, 0.0, 0), (300, 3, 1.0, 0.05, 3)]
+    cases = [(300, 3, 0.1, 0.0, 3), (150, 5, 1.0, 0.0, 12), (40, 9, 0.5, 0.1, 3), (500, 21, 1e-2, 0.05, 3), (80, 22, 1e-2, 0.0, 0), (300, 3, 1.0, 0.05, 3),
+             (200, 31, 5.0, 0.0, 8), (120, 32, 0.1, 0.3, 6), (60, 23, 10.0, 0.0, 60)]
     probs, prs = [], []
     for P, seed, lam, outl, iters in cases:
         pr = synth.make_warp_problem(P, seed, outliers=outl)
+        if seed >= 31:   # a poor start far from the fitted warp: the trust region has steps to reject while the other fits of the batch go on
+            pr["x0"] = pr["x0"] + np.random.default_rng(seed).normal(scale=0.05, size=pr["x0"].size)
         prs.append(pr)
         probs.append(dict(bbs=nrsfm.Bbs(*pr["bbs"]), kp1=pr["kp1"], kp2=pr["kp2"], invsig=pr["invsig"], fx_slot=pr["fy"], fy_slot=pr["fx"], lam=lam, fx=pr["fx"], fy=pr["fy"],
                           x0=pr["x0"], max_iters=iters))
@@ -171,6 +174,13 @@ def test_schwarp_fit_batch_equals_single_fits_and_the_oracle(gpu_ctx, oracle_mod
         np.testing.assert_allclose(cb, co, rtol=1e-10)
         np.testing.assert_allclose(xb, xo, rtol=0, atol=1e-9 * max(1.0, np.abs(xo).max()))
         np.testing.assert_array_equal(drb, dro)
+    # the batch is heterogeneous where the device-side trust-region control matters: fits that stop before their iteration limit next to
+    # fits that use all of it, fits whose every step is rejected next to fits that accept some (each already equal to the ORACLE above,
+    # which runs every fit on its own -- the independent reference of the control, not the single-fit call, which is a batch of one)
+    infos = np.array([r[3] for r in res])
+    limits = np.array([c[4] for c in cases])
+    assert (infos[:, 0] < limits).any() and (infos[:, 0] == limits)[limits > 0].any()
+    assert (infos[:, 1] < infos[:, 0]).any() and (infos[:, 1] > 0).any() and (infos[:, 1] == 0)[limits > 0].any()
 
 
 def test_schwarp_fit_batch_with_the_initialisation_inside(gpu_ctx):
