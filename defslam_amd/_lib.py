@@ -76,6 +76,12 @@ SchwarpProblemC._fields_ = [("bbs", BbsC), ("P", C.c_int32), ("kp1", c_float_p),
                             ("fy_slot", C.c_double), ("lam", C.c_double), ("fx", C.c_float), ("fy", C.c_float), ("max_iters", C.c_int32), ("x", c_double_p),
                             ("diff", c_float_p), ("drop", c_u8_p), ("info", C.c_int32 * 2), ("costs", C.c_double * 2), ("init_lambda", C.c_double), ("init_ok", C.c_int32)]
 
+
+
+class SchwarpStoreC(C.Structure):
+    _fields_ = [("point_id", c_i32_p), ("idx2", c_i32_p), ("tag", C.c_int32)]
+
+
 DIFFPROP_FIELDS = ["I1u", "I1v", "I2u", "I2v", "J12a", "J12b", "J12c", "J12d", "J21a", "J21b", "J21c", "J21d",
                    "H12uux", "H12uuy", "H12uvx", "H12uvy", "H12vvx", "H12vvy"]
 
@@ -90,6 +96,8 @@ EXPORTED_SYMBOLS = [
     "dsh_sfn_estimate", "dsh_bbs_bending", "dsh_warp_initialize", "dsh_search_by_schwarp",
     "dsh_template_embed_device", "dsh_scale_min_median", "dsh_optimize_horn", "dsh_surface_register",
     "dsh_comm_unique_id", "dsh_comm_create", "dsh_comm_destroy", "dsh_sft_shared_solve", "dsh_sft_shared_solve_group", "dsh_sft_connected_solve", "dsh_sft_connected_solve_group",
+    "dsh_diffdb_create", "dsh_diffdb_destroy", "dsh_diffdb_clear", "dsh_diffdb_count", "dsh_diffdb_append", "dsh_schwarp_fit_batch_store",
+    "dsh_normals_estimate_db", "dsh_sfn_estimate_db",
 ]
 DSH_COMM_ID_BYTES = 128
 
@@ -151,8 +159,19 @@ def _bind(path: str, lab: bool) -> C.CDLL:
     L.dsh_schwarp_fit.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_float_p, c_float_p, c_float_p, C.c_double, C.c_double, C.c_double, C.c_float,
                                   C.c_float, C.c_int, c_double_p, c_float_p, c_u8_p, c_i32_p, c_double_p]
     L.dsh_schwarp_fit_batch.argtypes = [vp, C.c_int, C.POINTER(SchwarpProblemC)]
+    L.dsh_diffdb_create.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+    L.dsh_diffdb_destroy.argtypes = [vp]
+    L.dsh_diffdb_clear.argtypes = [vp]
+    L.dsh_diffdb_count.argtypes = [vp]
+    L.dsh_diffdb_count.restype = C.c_int64
+    L.dsh_diffdb_append.argtypes = [vp, C.c_int, c_float_p, c_i32_p, c_i32_p, c_i32_p]
+    L.dsh_schwarp_fit_batch_store.argtypes = [vp, C.c_int, C.POINTER(SchwarpProblemC), C.POINTER(SchwarpStoreC), vp]
+    L.dsh_normals_estimate_db.argtypes = [vp, vp, C.c_int, c_i32_p, c_float_p, c_u8_p, c_float_p, c_double_p, c_double_p, c_i32_p, c_float_p, c_i32_p,
+                                          C.c_int32, c_i32_p, c_i32_p, c_i32_p, c_i32_p, c_float_p, c_u8_p]
     L.dsh_sfn_estimate.argtypes = [vp, C.POINTER(BbsC), C.c_int, c_double_p, c_double_p, c_float_p, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_float_p, c_i32_p]
+    L.dsh_sfn_estimate_db.argtypes = [vp, C.POINTER(BbsC), vp, C.c_int, c_i32_p, c_double_p, c_double_p, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_float_p, c_i32_p]
     L.dsh_bbs_bending.argtypes = [C.POINTER(BbsC), C.c_double, c_double_p]
     L.dsh_search_by_schwarp.argtypes = [vp, C.POINTER(BbsC), c_double_p, C.c_int, c_float_p, c_u8_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, c_float_p,
                                         c_u8_p, c_u8_p, C.c_float, C.c_int, c_i32_p, c_i32_p]

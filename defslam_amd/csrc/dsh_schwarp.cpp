@@ -11,6 +11,11 @@
 
 #include "../../include/defslam_hip.h"
 #include "dsh_ctx.h"
+#include "dsh_diffdb.h"
+
+extern "C" hipError_t ddb_append(int, const uint8_t*, const float*, const int32_t*, const int32_t*, const int32_t*, int32_t*, int32_t*, void*, size_t, long long, long long,
+                                 float*, int32_t*, int32_t*, int32_t*, hipStream_t);
+extern "C" size_t ddb_scan_tmp_bytes(int);
 
 extern "C" hipError_t nrsfm_swp_eval(double, double, int, double, double, int, int, double, double, double, const float*, const float*, const float*,
                                      const double*, double*, double*, int, hipStream_t);
@@ -118,20 +123,26 @@ int dsh_schwarp_eval(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, 
   return DSH_OK;
 }
 
+}  // extern "C"
+
 // The batched fit: every problem's inputs go up in ONE copy, the fits advance together through a fixed sequence of launches
 // with the trust-region control on the device (nrsfm_kernels.hip: nrsfm_swp_fit_batch), every result comes back in ONE copy.
-int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
+// stores / db (both or neither): the DiffProp records of the matches that are kept go into the device-resident database instead of
+// (or besides) the host -- dsh_schwarp_fit_batch_store.
+static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_schwarp_store* stores, dsh_diffdb* db) {
   dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
   if (!c) return DSH_ERR_ARG;
   if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_schwarp_fit_batch: host-only context, no GPU (there is no CPU fallback)");
   if (B <= 0 || !probs) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: bad argument");
+  if (db && (db->ctx != c || !stores)) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch_store: the database belongs to another context / no store descriptors");
   int maxP = 0, maxN = 0, max_it = 0;
   for (int b = 0; b < B; b++) {
     const dsh_schwarp_problem& q = probs[b];
     if (!args_ok(&q.bbs, q.P, q.kp1, q.kp2, q.invsig, q.x) || q.max_iters < 0 || q.max_iters > 1000) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: bad argument in problem " + std::to_string(b));
     if (q.bbs.nptsu * q.bbs.nptsv > 256)
       return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit: more than 256 control points (the one-workgroup solve handles 2N <= 512 unknowns; the reference uses 13 x 15 = 195)");
-    if ((q.diff == nullptr) != (q.drop == nullptr)) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: diff and drop go together");
+    if (!db && (q.diff == nullptr) != (q.drop == nullptr)) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: diff and drop go together");
+    if (db && !stores[b].point_id) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch_store: point_id missing in problem " + std::to_string(b));
     maxP = std::max(maxP, q.P); maxN = std::max(maxN, q.bbs.nptsu * q.bbs.nptsv); max_it = std::max(max_it, q.max_iters);
   }
   (void)hipSetDevice(c->device);
@@ -161,10 +172,21 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
       with_init = 1;
     }
     o.xo = out_bytes; out_bytes += al(8 * n2);                  // x lives in the output block (in/out): its start value is copied there
-    o.diff = out_bytes; out_bytes += al(q.diff ? 72 * (size_t)q.P : 0);
-    o.drop = out_bytes; out_bytes += al(q.drop ? (size_t)q.P : 0);
+    o.diff = out_bytes; out_bytes += al(!db && q.diff ? 72 * (size_t)q.P : 0);     // store mode: records and flags live in one strided block (below)
+    o.drop = out_bytes; out_bytes += al(!db && q.drop ? (size_t)q.P : 0);
     o.info = out_bytes; out_bytes += 256;
     o.costs = out_bytes; out_bytes += 256;
+  }
+  // store mode: DiffProp records / drop flags / point ids / tags / second-keyframe indices of all fits, problem b at stride maxP
+  DevBuf sdiff, sdrop, skeep, spos, stmp;
+  const size_t nall = (size_t)B * maxP;
+  size_t o_pid = 0, o_tag = 0, o_idx2 = 0;
+  if (db) {
+    o_pid = in_bytes; in_bytes += al(4 * nall);
+    o_tag = in_bytes; in_bytes += al(4 * nall);
+    o_idx2 = in_bytes; in_bytes += al(4 * nall);
+    HIPCHK(c, sdiff.alloc(c, 72 * nall)); HIPCHK(c, sdrop.alloc(c, nall)); HIPCHK(c, skeep.alloc(c, 4 * nall)); HIPCHK(c, spos.alloc(c, 4 * nall));
+    HIPCHK(c, stmp.alloc(c, ddb_scan_tmp_bytes((int)nall)));
   }
   DevBuf din, dout;
   HIPCHK(c, din.alloc(c, in_bytes)); HIPCHK(c, dout.alloc(c, out_bytes));
@@ -198,27 +220,79 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) {
     nrsfm_swp_fit_fill(hin + fit_bytes * (size_t)b, q.bbs.umin, q.bbs.umax, q.bbs.nptsu, q.bbs.vmin, q.bbs.vmax, q.bbs.nptsv, q.P, q.fx_slot, q.fy_slot, q.lambda, q.fx, q.fy,
                        q.max_iters, reinterpret_cast<const float*>(dib + o.kp1), reinterpret_cast<const float*>(dib + o.kp2), reinterpret_cast<const float*>(dib + o.isg),
                        reinterpret_cast<double*>(dob + o.xo), xn.as<double>(), reinterpret_cast<double*>(dib + o.cs), g.as<double>(), dx.as<double>(), r.as<double>(),
-                       J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal.as<double>(), q.diff ? reinterpret_cast<float*>(dob + o.diff) : nullptr,
-                       q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr, reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs),
+                       J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal.as<double>(),
+                       db ? sdiff.as<float>() + 18 * (size_t)b * maxP : (q.diff ? reinterpret_cast<float*>(dob + o.diff) : nullptr),
+                       db ? sdrop.as<uint8_t>() + (size_t)b * maxP : (q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr),
+                       reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs),
                        q.init_lambda > 0.0 ? reinterpret_cast<const double*>(dib + o.bend) : nullptr, compact.p);
+  }
+  int32_t max_pid = -1;
+  if (db) {
+    int32_t* hp = reinterpret_cast<int32_t*>(hin + o_pid);
+    int32_t* ht = reinterpret_cast<int32_t*>(hin + o_tag);
+    int32_t* hi = reinterpret_cast<int32_t*>(hin + o_idx2);
+    for (int b = 0; b < B; b++)
+      for (int i = 0; i < maxP; i++) {
+        const bool in = i < probs[b].P;
+        const int32_t id = in ? stores[b].point_id[i] : -1;
+        hp[(size_t)b * maxP + i] = id;
+        ht[(size_t)b * maxP + i] = stores[b].tag;
+        hi[(size_t)b * maxP + i] = (in && stores[b].idx2) ? stores[b].idx2[i] : (in ? i : -1);
+        max_pid = std::max(max_pid, id);
+      }
   }
   HIPCHK(c, hipMemcpyAsync(dib, hin, in_bytes, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(dob, hx, out_bytes, hipMemcpyHostToDevice, st));
   HIPCHK(c, nrsfm_swp_fit_batch(dib, B, maxP, maxN, max_it, with_init, st));
   HIPCHK(c, hipMemcpyAsync(c->pin_out.p, dob, out_bytes, hipMemcpyDeviceToHost, st));
+  std::vector<uint8_t> hdrop;
+  std::vector<float> hdiff;
+  int32_t added = 0;
+  if (db) {   // kept records -> the database, in (fit, match) order; only the drop flags (and, if asked for, the records) travel to the host
+    HIPCHK(c, ddb_append((int)nall, sdrop.as<uint8_t>(), sdiff.as<float>(), reinterpret_cast<const int32_t*>(dib + o_pid), reinterpret_cast<const int32_t*>(dib + o_tag),
+                         reinterpret_cast<const int32_t*>(dib + o_idx2), skeep.as<int32_t>(), spos.as<int32_t>(), stmp.p, ddb_scan_tmp_bytes((int)nall), db->count,
+                         db->cap, db->rec, db->pid, db->tag, db->idx2, st));
+    hdrop.resize(nall);
+    HIPCHK(c, hipMemcpyAsync(hdrop.data(), sdrop.p, nall, hipMemcpyDeviceToHost, st));
+    bool want_diff = false;
+    for (int b = 0; b < B; b++) want_diff = want_diff || probs[b].diff != nullptr;
+    if (want_diff) { hdiff.resize(18 * nall); HIPCHK(c, hipMemcpyAsync(hdiff.data(), sdiff.p, 72 * nall, hipMemcpyDeviceToHost, st)); }
+    int32_t last[2] = {0, 0};   // records added = exclusive scan position + keep flag of the last entry
+    HIPCHK(c, hipMemcpyAsync(&last[0], spos.as<int32_t>() + nall - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&last[1], skeep.as<int32_t>() + nall - 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    added = last[0] + last[1];
+  }
   HIPCHK(c, hipStreamSynchronize(st));
+  if (db) {
+    if (db->count + added > db->cap) { db->count = db->cap; return dsh_fail(c, DSH_ERR_STATE, "dsh_schwarp_fit_batch_store: the database is full (records beyond its capacity were not stored)"); }
+    db->count += added;
+    db->max_pid = std::max(db->max_pid, max_pid);
+  }
   const char* ho = c->pin_out.p;
   for (int b = 0; b < B; b++) {
     dsh_schwarp_problem& q = probs[b];
     const Off& o = off[b];
     const size_t n2 = 2 * (size_t)q.bbs.nptsu * q.bbs.nptsv;
     std::memcpy(q.x, ho + o.xo, 8 * n2);
-    if (q.diff) { std::memcpy(q.diff, ho + o.diff, 72 * (size_t)q.P); std::memcpy(q.drop, ho + o.drop, (size_t)q.P); }
+    if (db) {
+      if (q.drop) std::memcpy(q.drop, hdrop.data() + (size_t)b * maxP, (size_t)q.P);
+      if (q.diff) std::memcpy(q.diff, hdiff.data() + 18 * (size_t)b * maxP, 72 * (size_t)q.P);
+    } else if (q.diff) { std::memcpy(q.diff, ho + o.diff, 72 * (size_t)q.P); std::memcpy(q.drop, ho + o.drop, (size_t)q.P); }
     std::memcpy(q.info, ho + o.info, sizeof q.info);
     std::memcpy(&q.init_ok, ho + o.info + sizeof q.info, sizeof q.init_ok);
     std::memcpy(q.costs, ho + o.costs, sizeof q.costs);
   }
   return DSH_OK;
+}
+
+extern "C" {
+
+int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs) { return fit_batch(ctx, B, probs, nullptr, nullptr); }
+
+int dsh_schwarp_fit_batch_store(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_schwarp_store* stores, dsh_diffdb* db) {
+  if (!db || !stores) return dsh_fail(reinterpret_cast<dsh_ctx_base*>(ctx), DSH_ERR_ARG, "dsh_schwarp_fit_batch_store: bad argument");
+  return fit_batch(ctx, B, probs, stores, db);
 }
 
 int dsh_schwarp_fit(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, const float* invsig, double fx_slot, double fy_slot,

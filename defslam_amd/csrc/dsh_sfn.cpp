@@ -12,6 +12,7 @@
 
 #include "../../include/defslam_hip.h"
 #include "dsh_ctx.h"
+#include "dsh_diffdb.h"
 
 extern "C" hipError_t nrsfm_swp_normal(int, int, int, double*, double*, const double*, const double*, double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_swp_solve(int, const double*, const double*, double, double*, double*, double*, double*, int, int, hipStream_t);
@@ -24,6 +25,7 @@ extern "C" hipError_t nrsfm_warp_coloc(double, double, int, double, double, int,
 extern "C" hipError_t nrsfm_mat_add(size_t, const double*, double*, hipStream_t);
 extern "C" hipError_t nrsfm_match_search(double, double, int, double, double, int, const double*, int, const float*, const uint32_t*, const float*, const float*, int, int,
                                          int, const float*, const uint32_t*, const uint8_t*, float, int, int32_t*, int32_t*, hipStream_t);
+extern "C" hipError_t ddb_pick_normals(int, const int32_t*, const float*, const float*, float*, hipStream_t);
 extern "C" hipError_t nrsfm_sfn_points(double, double, int, double, double, int, const double*, int, const double*, const double*, float*, hipStream_t);
 
 namespace {
@@ -102,13 +104,24 @@ int dsh_bbs_bending(const dsh_bbs* bbs, double lambda, double* bending) {
   return DSH_OK;
 }
 
-int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, double bending_weight,
-                     double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok) {
+}  // extern "C"
+
+// The body of dsh_sfn_estimate / dsh_sfn_estimate_db: the normals come from the host (normals) or are picked on the device out of the
+// last normal solve of a database (db, sel).
+static int sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, const dsh_diffdb* ndb, const int32_t* sel,
+                        double bending_weight, double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts,
+                        int32_t* ok) {
   dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
   if (!c) return DSH_ERR_ARG;
   if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_sfn_estimate: host-only context, no GPU (there is no CPU fallback)");
-  if (!bbs_ok(bbs) || n < 0 || n_all < 0 || (n > 0 && (!u || !v || !normals)) || (n_all > 0 && (!u_all || !v_all || !pts)) || !ctrl || !ok)
+  if (!bbs_ok(bbs) || n < 0 || n_all < 0 || (n > 0 && (!u || !v || (!normals && !(ndb && sel)))) || (n_all > 0 && (!u_all || !v_all || !pts)) || !ctrl || !ok)
     return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate: bad argument");
+  if (ndb) {
+    if (ndb->ctx != c) return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate_db: the database belongs to another context");
+    for (int i = 0; i < n; i++)
+      if (sel[i] >= ndb->last_P || -1 - (long long)sel[i] >= ndb->last_R)
+        return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate_db: sel[" + std::to_string(i) + "] is outside the last normal solve of the database");
+  }
   const int N = bbs->nptsu * bbs->nptsv;
   if (N > 512) return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate: more than 512 control points (one-workgroup solve)");
   *ok = 0;
@@ -136,7 +149,14 @@ int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, c
   if (n > 0) {
     HIPCHK(c, hipMemcpyAsync(du.p, u, 8 * (size_t)n, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(dv.p, v, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dn.p, normals, 12 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (ndb) {
+      DevBuf dsel;
+      HIPCHK(c, dsel.alloc(c, 4 * (size_t)n));
+      HIPCHK(c, hipMemcpyAsync(dsel.p, sel, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+      HIPCHK(c, ddb_pick_normals(n, dsel.as<int32_t>(), ndb->last_normals, ndb->last_normals + 3 * (size_t)ndb->last_P, dn.as<float>(), st));
+    } else {
+      HIPCHK(c, hipMemcpyAsync(dn.p, normals, 12 * (size_t)n, hipMemcpyHostToDevice, st));
+    }
   }
   HIPCHK(c, nrsfm_sfn_rows(bbs->umin, bbs->umax, bbs->nptsu, bbs->vmin, bbs->vmax, bbs->nptsv, n, du.as<double>(), dv.as<double>(), dn.as<float>(), dA.as<double>(), st));
   // x0: G x = A^T b  (the solve kernel returns M dx = -g, so it is fed g = A^T (-(b - A x)))
@@ -173,6 +193,21 @@ int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, c
   HIPCHK(c, hipStreamSynchronize(st));
   *ok = 1;
   return DSH_OK;
+}
+
+extern "C" {
+
+int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, double bending_weight,
+                     double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok) {
+  return sfn_estimate(ctx, bbs, n, u, v, normals, nullptr, nullptr, bending_weight, mean_depth, n_all, u_all, v_all, ctrl_raw, ctrl, pts, ok);
+}
+
+int dsh_sfn_estimate_db(dsh_ctx* ctx, const dsh_bbs* bbs, const dsh_diffdb* db, int n, const int32_t* sel, const double* u, const double* v, double bending_weight,
+                        double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok) {
+  dsh_ctx_base* c = reinterpret_cast<dsh_ctx_base*>(ctx);
+  if (!c) return DSH_ERR_ARG;
+  if (!db || (n > 0 && !sel)) return dsh_fail(c, DSH_ERR_ARG, "dsh_sfn_estimate_db: bad argument");
+  return sfn_estimate(ctx, bbs, n, u, v, nullptr, db, sel, bending_weight, mean_depth, n_all, u_all, v_all, ctrl_raw, ctrl, pts, ok);
 }
 
 int dsh_warp_initialize(dsh_ctx* ctx, const dsh_bbs* bbs, int P, const float* kp1, const float* kp2, double lambda, double* x, int32_t* ok) {

@@ -93,6 +93,74 @@ def ObtainK1K2(ctx: Context, rec_ptr, recs, rec_is_ref, rec_first_normal, rec_ha
     return out
 
 
+class DiffDatabase:
+    """defSLAM::WarpDatabase's mapPointsDB_ (WarpDatabase.h:61) held in HBM: dsh_diffdb."""
+
+    def __init__(self, ctx: Context, capacity: int):
+        self._ctx, self._h = ctx, None
+        h = C.c_void_p()
+        ctx._check(ctx._L.dsh_diffdb_create(ctx._h, int(capacity), C.byref(h)), "dsh_diffdb_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._ctx._L.dsh_diffdb_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def clear(self):
+        self._ctx._check(self._ctx._L.dsh_diffdb_clear(self._h), "dsh_diffdb_clear")
+
+    def __len__(self):
+        return int(self._ctx._L.dsh_diffdb_count(self._h))
+
+    def append(self, recs, point_id, tag=None, idx2=None):
+        recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 18)
+        pid = np.ascontiguousarray(point_id, np.int32)
+        tag = np.ascontiguousarray(tag, np.int32) if tag is not None else None
+        idx2 = np.ascontiguousarray(idx2, np.int32) if idx2 is not None else None
+        assert pid.shape[0] == recs.shape[0]
+        self._ctx._check(self._ctx._L.dsh_diffdb_append(self._h, recs.shape[0], _ptr(recs, C.c_float), _ptr(pid, C.c_int32), _ptr(tag, C.c_int32),
+                                                        _ptr(idx2, C.c_int32)), "dsh_diffdb_append")
+
+
+@dataclass
+class NormalsDbResult:
+    k1k2: np.ndarray
+    cov: np.ndarray
+    status: np.ndarray
+    normal_ref: np.ndarray
+    iters: np.ndarray
+    rec_point: np.ndarray
+    rec_tag: np.ndarray
+    rec_idx2: np.ndarray
+    normal_rec: np.ndarray
+    rec_written: np.ndarray
+
+
+def ObtainK1K2Database(ctx: Context, db: DiffDatabase, point_ids, x0, has_x0, ref_uv, per_record=True) -> NormalsDbResult:
+    """NormalEstimator::ObtainK1K2 over the device-resident database (dsh_normals_estimate_db): the records never visit the host."""
+    ids = np.ascontiguousarray(point_ids, np.int32)
+    P = ids.shape[0]
+    x0 = np.ascontiguousarray(x0, np.float32).reshape(-1, 2)
+    hx0 = np.ascontiguousarray(has_x0, np.uint8)
+    uv = np.ascontiguousarray(ref_uv, np.float32).reshape(-1, 2)
+    cap = len(db) if per_record else 0
+    k, cov, st, nref, it = np.zeros((P, 2)), np.zeros((P, 2, 2)), np.zeros(P, np.int32), np.zeros((P, 3), np.float32), np.zeros(P, np.int32)
+    rp, rt, ri = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    nrec, wr = np.zeros((cap, 3), np.float32), np.zeros(cap, np.uint8)
+    n = C.c_int32(0)
+    pr = per_record and cap > 0
+    ctx._check(ctx._L.dsh_normals_estimate_db(ctx._h, db._h, P, _ptr(ids, C.c_int32), _ptr(x0, C.c_float), _ptr(hx0, C.c_uint8), _ptr(uv, C.c_float),
+                                              _ptr(k, C.c_double), _ptr(cov, C.c_double), _ptr(st, C.c_int32), _ptr(nref, C.c_float), _ptr(it, C.c_int32),
+                                              cap, C.byref(n), _ptr(rp, C.c_int32) if pr else None, _ptr(rt, C.c_int32) if pr else None,
+                                              _ptr(ri, C.c_int32) if pr else None, _ptr(nrec, C.c_float) if pr else None, _ptr(wr, C.c_uint8) if pr else None),
+               "dsh_normals_estimate_db")
+    R = n.value if pr else 0
+    return NormalsDbResult(k, cov, st, nref, it, rp[:R], rt[:R], ri[:R], nrec[:R], wr[:R])
+
+
 def schwarp_eval(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot, lam, x, want_jacobian=True):
     """Warps::Warp::Evaluate + Warps::Schwarzian::Evaluate once: (residuals[2P+4N], J[(2P+4N), 2N] or None)."""
     kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
@@ -126,8 +194,10 @@ def calculateSchwarps(ctx: Context, bbs: Bbs, kp1, kp2, invsig, fx_slot, fy_slot
     return x, diff, drop.astype(bool), info, costs
 
 
-def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3):
-    """B fits in one call (dsh_schwarp_fit_batch).  problems: dicts with bbs (Bbs), kp1, kp2, invsig, fx_slot, fy_slot, lam, fx, fy and
+def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3, db=None, want_records=True):
+    """B fits in one call (dsh_schwarp_fit_batch).  With db (a DiffDatabase) the kept records also go into the device-resident database
+    (dsh_schwarp_fit_batch_store): every problem then carries point_id[P] (map point of each match, < 0 = not stored), optionally idx2[P]
+    and tag; want_records=False leaves the records on the device (the diffprops of the result stay zero).  problems: dicts with bbs (Bbs), kp1, kp2, invsig, fx_slot, fy_slot, lam, fx, fy and
     either x0 (start value) or init_lam (the fit starts from Warp::initialize with that bending weight, computed inside the call).
     Returns a list of (x, diffprops, drop, info, costs) like calculateSchwarps; with init_lam the tuple ends with init_ok."""
     B = len(problems)
@@ -151,7 +221,19 @@ def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3):
         a.max_iters = int(q.get("max_iters", max_iters))
         a.x, a.diff, a.drop = _ptr(x, C.c_double), _ptr(diff, C.c_float), _ptr(drop, C.c_uint8)
         a.init_lambda = init_lam
-    ctx._check(ctx._L.dsh_schwarp_fit_batch(ctx._h, B, arr), "dsh_schwarp_fit_batch")
+    if db is not None:
+        st = (_lib.SchwarpStoreC * B)()
+        for b, q in enumerate(problems):
+            pid = np.ascontiguousarray(q["point_id"], np.int32)
+            idx2 = np.ascontiguousarray(q["idx2"], np.int32) if q.get("idx2") is not None else None
+            assert pid.shape[0] == arr[b].P and (idx2 is None or idx2.shape[0] == arr[b].P)
+            keep.append((pid, idx2))
+            st[b].point_id, st[b].idx2, st[b].tag = _ptr(pid, C.c_int32), _ptr(idx2, C.c_int32), int(q.get("tag", b))
+            if not want_records:
+                arr[b].diff = None
+        ctx._check(ctx._L.dsh_schwarp_fit_batch_store(ctx._h, B, arr, st, db._h), "dsh_schwarp_fit_batch_store")
+    else:
+        ctx._check(ctx._L.dsh_schwarp_fit_batch(ctx._h, B, arr), "dsh_schwarp_fit_batch")
     out = []
     for b in range(B):
         t = (keep[b][3], keep[b][4], keep[b][5].astype(bool), np.array(arr[b].info[:], np.int32), np.array(arr[b].costs[:]))
@@ -187,6 +269,24 @@ def ShapeFromNormals(ctx: Context, bbs: Bbs, u, v, normals, bending_weight: floa
     ctx._check(ctx._L.dsh_sfn_estimate(ctx._h, C.byref(b), u.shape[0], _ptr(u, C.c_double), _ptr(v, C.c_double), _ptr(nrm, C.c_float), float(bending_weight),
                                        float(mean_depth), ua.shape[0], _ptr(ua, C.c_double), _ptr(va, C.c_double), _ptr(raw, C.c_double), _ptr(ctrl, C.c_double),
                                        _ptr(pts, C.c_float), C.byref(ok)), "dsh_sfn_estimate")
+    return bool(ok.value), raw, ctrl, pts
+
+
+def ShapeFromNormalsDatabase(ctx: Context, bbs: Bbs, db: DiffDatabase, sel, u, v, bending_weight: float, mean_depth: float, u_all, v_all):
+    """ShapeFromNormals with the normals picked on the device from the last ObtainK1K2Database of db (dsh_sfn_estimate_db): sel >= 0 = index of
+    a requested point (normal in its reference keyframe), sel < 0 = record -1 - sel (normal propagated to the record's second keyframe)."""
+    sel = np.ascontiguousarray(sel, np.int32)
+    u = np.ascontiguousarray(u, np.float64)
+    v = np.ascontiguousarray(v, np.float64)
+    assert sel.shape[0] == u.shape[0] == v.shape[0]
+    ua = np.ascontiguousarray(u_all, np.float64)
+    va = np.ascontiguousarray(v_all, np.float64)
+    N = bbs.nptsu * bbs.nptsv
+    raw, ctrl, pts, ok = np.zeros(N), np.zeros(N), np.zeros((ua.shape[0], 3), np.float32), C.c_int32(0)
+    b = bbs.c()
+    ctx._check(ctx._L.dsh_sfn_estimate_db(ctx._h, C.byref(b), db._h, u.shape[0], _ptr(sel, C.c_int32), _ptr(u, C.c_double), _ptr(v, C.c_double), float(bending_weight),
+                                          float(mean_depth), ua.shape[0], _ptr(ua, C.c_double), _ptr(va, C.c_double), _ptr(raw, C.c_double), _ptr(ctrl, C.c_double),
+                                          _ptr(pts, C.c_float), C.byref(ok)), "dsh_sfn_estimate_db")
     return bool(ok.value), raw, ctrl, pts
 
 

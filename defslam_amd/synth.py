@@ -264,11 +264,18 @@ def _coloc_dense(umin, umax, nu, vmin, vmax, nv, u, v):
     return A
 
 
-def make_warp_problem(n_matches: int = 400, seed: int = 3, nu: int = 13, nv: int = 15, noise: float = 5e-4, outliers: float = 0.0):
+def make_warp_problem(n_matches: int = 400, seed: int = 3, nu: int = 13, nv: int = 15, noise: float = 5e-4, outliers: float = 0.0, kp1=None, motion=None):
+    """One keyframe pair: matches kp1 -> kp2 under a plane-induced homography plus a ripple.  kp1 (given key points of the first keyframe,
+    e.g. a subset of one pool shared by several pairs) and motion (rotation vector, translation of the second camera) are optional."""
     rng = np.random.default_rng(seed)
-    kp1 = np.stack([rng.uniform(-0.55, 0.55, n_matches), rng.uniform(-0.42, 0.42, n_matches)], 1)
+    if kp1 is None:
+        kp1 = np.stack([rng.uniform(-0.55, 0.55, n_matches), rng.uniform(-0.42, 0.42, n_matches)], 1)
+    else:
+        kp1 = np.asarray(kp1, np.float64).reshape(-1, 2)
+        n_matches = kp1.shape[0]
     N = np.array([0.15, -0.1, 1.0]) / 1.1
-    Hm = _rodrigues(np.array([0.02, -0.05, 0.03])) + np.outer(np.array([0.06, -0.04, 0.02]), N)
+    rv, tv = motion if motion is not None else (np.array([0.02, -0.05, 0.03]), np.array([0.06, -0.04, 0.02]))
+    Hm = _rodrigues(np.asarray(rv, np.float64)) + np.outer(np.asarray(tv, np.float64), N)
     p = np.c_[kp1, np.ones(n_matches)] @ Hm.T
     kp2 = p[:, :2] / p[:, 2:3]
     kp2[:, 0] += 0.01 * np.sin(3.0 * kp1[:, 1])

@@ -256,6 +256,41 @@ typedef struct dsh_schwarp_problem {
 } dsh_schwarp_problem;
 int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* problems);
 
+/* ---- device-resident mapping chain --------------------------------------------------------------------------------------
+ * defSLAM::WarpDatabase keeps the DiffProp records of every map point in a host map (WarpDatabase.h:61 mapPointsDB_): the fits write
+ * them (SchwarpDatabase.cc:299-345), NormalEstimator::ObtainK1K2 reads them back (NormalEstimator.cc:50-110).  dsh_diffdb is that
+ * database in HBM: dsh_schwarp_fit_batch_store appends the records of its fits on the device (in fit, match order; only the drop flags
+ * travel to the host), dsh_normals_estimate_db groups the records of the requested points on the device (a point's records in their
+ * insertion order, like the host vector) and solves -- key points in, normals out, no record crosses PCIe. */
+typedef struct dsh_diffdb dsh_diffdb;
+int dsh_diffdb_create(dsh_ctx* ctx, int64_t capacity_records, dsh_diffdb** out);
+int dsh_diffdb_destroy(dsh_diffdb* db);
+int dsh_diffdb_clear(dsh_diffdb* db);                 /* forget every record (WarpDatabase::clear) */
+int64_t dsh_diffdb_count(const dsh_diffdb* db);       /* records stored */
+/* Records a host already holds (a map loaded from elsewhere, tests): point_id[n] >= 0, tag[n] / idx2[n] may be NULL (0 / the index). */
+int dsh_diffdb_append(dsh_diffdb* db, int n, const dsh_diffprop* recs, const int32_t* point_id, const int32_t* tag, const int32_t* idx2);
+/* What dsh_schwarp_fit_batch_store needs per problem besides the fit itself: the map point of every match (point_id[P]; < 0: the record
+ * is not stored -- the reference stores only points whose reference keyframe is the pair's first keyframe, SchwarpDatabase.cc:297), the
+ * key point index of the match in the second keyframe (idx2[P], NULL = the match index) and a tag the caller chooses for the keyframe
+ * pair; both come back with the propagated normals. */
+typedef struct dsh_schwarp_store {
+  const int32_t* point_id;
+  const int32_t* idx2;
+  int32_t tag;
+} dsh_schwarp_store;
+/* dsh_schwarp_fit_batch + storing: problems[b].diff may be NULL (no record is copied to the host), problems[b].drop receives the drop
+ * flags (the host bookkeeping of SchwarpDatabase.cc:283-293 needs them).  Records of matches that are dropped or have point_id < 0 are
+ * not stored.  DSH_ERR_STATE when the database is full. */
+int dsh_schwarp_fit_batch_store(dsh_ctx* ctx, int B, dsh_schwarp_problem* problems, const dsh_schwarp_store* stores, dsh_diffdb* db);
+/* NormalEstimator::ObtainK1K2 over the database for the P map points point_ids[P] (x0 / has_x0 / ref_uv and the per-point outputs as in
+ * dsh_normals_estimate; every stored record is a residual block of its point; the ids are distinct, ids without records are
+ * skipped like a point without observations).  Per-record outputs (all may be NULL), n_rec entries in
+ * point order then insertion order, the buffers holding max_rec entries: rec_point (index into point_ids), rec_tag, rec_idx2, the
+ * normal propagated to the second keyframe (normal_rec[3 n]) and whether the reference writes it (rec_written). */
+int dsh_normals_estimate_db(dsh_ctx* ctx, dsh_diffdb* db, int P, const int32_t* point_ids, const float* x0, const uint8_t* has_x0, const float* ref_uv,
+                            double* k1k2, double* cov, int32_t* status, float* normal_ref, int32_t* iters, int32_t max_rec, int32_t* n_rec,
+                            int32_t* rec_point, int32_t* rec_tag, int32_t* rec_idx2, float* normal_rec, uint8_t* rec_written);
+
 /* ---- Shape from Normals -------------------------------------------------------------------------
  * ShapeFromNormals::ShapeFromNormals + ::estimate (Modules/Mapping/ShapeFromNormals.cc:38-171, obtainM :178-260): the
  * depth B-spline (valdim 1, bbs->valdim is ignored) of a keyframe from the normals of its map points.
@@ -268,6 +303,12 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* problems);
  * *ok = 0 (and DSH_OK) when the reference's estimate() would return false: no key points, rank-deficient system, NaN/Inf. */
 int dsh_sfn_estimate(dsh_ctx* ctx, const dsh_bbs* bbs, int n, const double* u, const double* v, const float* normals, double bending_weight,
                      double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok);
+/* The same with the normals taken on the device from the last dsh_normals_estimate_db of db (they never visit the host): sel[n] >= 0 is
+ * the index of a point in that call's point_ids (its normal in the reference keyframe, normal_ref), sel[n] < 0 is record -1 - sel[n] of
+ * that call's per-record order (the normal propagated to the record's second keyframe, normal_rec).  The caller picks solved points /
+ * written records from the status and rec_written arrays that call returned, like obtainM filters missing normals. */
+int dsh_sfn_estimate_db(dsh_ctx* ctx, const dsh_bbs* bbs, const dsh_diffdb* db, int n, const int32_t* sel, const double* u, const double* v, double bending_weight,
+                        double mean_depth, int n_all, const double* u_all, const double* v_all, double* ctrl_raw, double* ctrl, float* pts, int32_t* ok);
 /* Warps::Warp::initialize (Modules/Mapping/Schwarp.cc:99-160): the control points of the warp kp1 -> kp2 that start the
  * Schwarzian fit, (C^T C + Bending(lambda)) X = C^T kp2 with C the colocation matrix of the P key points kp1 (float32 x,y
  * pairs, normalised coordinates).  x[2N]: first coordinate of the N control points, then the second (the layout

@@ -4,6 +4,10 @@ SchwarpDatabase::add, SchwarpDatabase.cc:50-128; the template it hands to tracki
     dsh_warp_initialize -> dsh_search_by_schwarp -> dsh_schwarp_fit (per keyframe pair)
       -> dsh_normals_estimate -> dsh_sfn_estimate -> dsh_surface_register -> dsh_template_build + embedding -> dsh_sft_solve
 
+and, beside it, the device-resident route through the handles (dsh_schwarp_fit_batch_store -> dsh_normals_estimate_db ->
+dsh_sfn_estimate_db: key points in, normals / control points out, no DiffProp record or normal crosses PCIe), which has to give the
+same bits.
+
 Every stage consumes what the previous GPU stage produced; the oracle of the stage is run on the same inputs and compared (index
 work bit-exact, floating point to the stage's tolerance), so a disagreement is pinned to the stage that caused it, and the chain
 as a whole has to recover the scene (scale, surface, tracking pose)."""
@@ -22,7 +26,8 @@ def test_mapping_loop_chain_matches_the_oracles_stage_by_stage(gpu_ctx, oracle_m
     fx, fy = float(sc["cam"][0]), float(sc["cam"][1])
     lam_init, lam_fit = 1e-2, 0.1
     recs_per_point = [[] for _ in range(P)]
-    for kf in sc["kfs"]:
+    db = nrsfm.DiffDatabase(gpu_ctx, 4 * P)
+    for ikf, kf in enumerate(sc["kfs"]):
         # ---- Warp::initialize on the tracked matches
         kp1, kp2 = sc["kp0"][:nt], kf["kp_norm"][:nt]
         okg, x0 = nrsfm.WarpInitialize(gpu_ctx, b2, kp1, kp2, lam_init)
@@ -50,6 +55,14 @@ def test_mapping_loop_chain_matches_the_oracles_stage_by_stage(gpu_ctx, oracle_m
         np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-9 * max(1.0, np.abs(xo).max()))
         np.testing.assert_allclose(dg, do, rtol=2e-6, atol=1e-6)
         assert cg[1] <= cg[0]
+        # the same fit through the handle: the records stay in HBM, only the drop flags come back
+        idx2 = np.r_[kf["index_of_point"][:nt], mg[found]].astype(np.int32)
+        (xs, ds, drs, is_, cs), = nrsfm.calculateSchwarpsBatch(gpu_ctx, [dict(bbs=b2, kp1=args[0], kp2=kp2n, invsig=args[2], fx_slot=fy, fy_slot=fx, lam=lam_fit, fx=fx, fy=fy,
+                                                                               x0=x0, max_iters=3, point_id=sel.astype(np.int32), idx2=idx2, tag=ikf)],
+                                                               db=db, want_records=False)
+        np.testing.assert_array_equal(xs, xg)
+        np.testing.assert_array_equal(drs, drg)
+        assert not ds.any()
         for k, p in enumerate(sel):
             if not drg[k]:
                 recs_per_point[p].append(dg[k])
@@ -63,6 +76,11 @@ def test_mapping_loop_chain_matches_the_oracles_stage_by_stage(gpu_ctx, oracle_m
     ng = nrsfm.ObtainK1K2(gpu_ctx, *nargs)
     no = oracle_mod.normals(*nargs)
     np.testing.assert_array_equal(ng.status, no["status"])
+    assert len(db) == R
+    nd = nrsfm.ObtainK1K2Database(gpu_ctx, db, np.array(pts, np.int32), nargs[5], nargs[6], nargs[7])
+    for k in ["k1k2", "cov", "status", "normal_ref", "iters", "normal_rec", "rec_written"]:
+        np.testing.assert_array_equal(getattr(nd, k), getattr(ng, k), err_msg=k)
+    assert set(nd.rec_tag.tolist()) == set(range(len(sc["kfs"]))) and (nd.rec_point == np.repeat(np.arange(len(pts)), np.diff(rec_ptr))).all()
     okn = ng.status == 0
     assert okn.mean() > 0.9
     np.testing.assert_allclose(ng.k1k2[okn], no["k1k2"][okn], rtol=0, atol=1e-7)
@@ -83,6 +101,11 @@ def test_mapping_loop_chain_matches_the_oracles_stage_by_stage(gpu_ctx, oracle_m
     okg, rawg, ctrlg, surf = nrsfm.ShapeFromNormals(gpu_ctx, b1, *sargs)
     oko, rawo, ctrlo, surfo = oracle_mod.sfn_estimate(sc["bbs1"], *sargs)
     assert okg and oko
+    okd, rawd, ctrld, surfd = nrsfm.ShapeFromNormalsDatabase(gpu_ctx, b1, db, np.flatnonzero(okn), *sargs[:2], *sargs[3:])   # normals picked on the device
+    assert okd
+    np.testing.assert_array_equal(rawd, rawg)
+    np.testing.assert_array_equal(ctrld, ctrlg)
+    np.testing.assert_array_equal(surfd.view(np.uint32), surf.view(np.uint32))
     np.testing.assert_allclose(rawg, rawo, rtol=0, atol=1e-7 * np.abs(rawo).max())
     np.testing.assert_allclose(surf, surfo, rtol=5e-6, atol=2e-6)
     shape_err = np.abs(surf[:, 2] / np.median(surf[:, 2]) - sc["depth"] / np.median(sc["depth"]))

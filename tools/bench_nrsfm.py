@@ -66,6 +66,17 @@ def main():
             rec["cpu_baseline"] = {"value": m / dtc, "unit": "points/s", "cores": 1, "kind": "port", "sample": f"{m} points, oracle/nrsfm_oracle.c (Ceres-style LM restated; parity unpinned)"}
         out.append(rec)
 
+        # the same records held in HBM (dsh_diffdb): the call ships key points in, normals out
+        owner = np.repeat(np.arange(P, dtype=np.int32), np.diff(sc["rec_ptr"]))
+        db = nrsfm.DiffDatabase(ctx, R)
+        db.append(sc["recs"], owner)
+        ids = np.arange(P, dtype=np.int32)
+        for per_record in (False, True):
+            dtd = timeit(lambda: nrsfm.ObtainK1K2Database(ctx, db, ids, sc["x0"], sc["has_x0"], sc["ref_uv"], per_record=per_record), args.reps)
+            out.append({"metric": "NRSfM normal solve map points/s (records resident in HBM: dsh_normals_estimate_db" + (", per-record normals returned)" if per_record else ")"),
+                        "value": P / dtd, "unit": "points/s", "points": P, "records": int(R), "ms_per_call": 1e3 * dtd})
+        db.close()
+
     # ---- SchwarpDatabase::calculateSchwarps (Modules/Mapping/SchwarpDatabase.cc:246-340): one keyframe pair ----
     wp = synth.make_warp_problem(n_matches=args.matches, seed=3)
     wb = nrsfm.Bbs(*wp["bbs"])
