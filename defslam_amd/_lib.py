@@ -72,14 +72,16 @@ class BbsC(C.Structure):
                 ("nptsv", C.c_int32), ("valdim", C.c_int32)]
 
 
-SchwarpProblemC._fields_ = [("bbs", BbsC), ("P", C.c_int32), ("kp1", c_float_p), ("kp2", c_float_p), ("invsig", c_float_p), ("fx_slot", C.c_double),
-                            ("fy_slot", C.c_double), ("lam", C.c_double), ("fx", C.c_float), ("fy", C.c_float), ("max_iters", C.c_int32), ("x", c_double_p),
-                            ("diff", c_float_p), ("drop", c_u8_p), ("info", C.c_int32 * 2), ("costs", C.c_double * 2), ("init_lambda", C.c_double), ("init_ok", C.c_int32)]
+# the pointer members are declared void*: the mirror fills them with plain addresses (base of a pooled array + offset), which costs a
+# fraction of a typed ctypes pointer per field
+SchwarpProblemC._fields_ = [("bbs", BbsC), ("P", C.c_int32), ("kp1", C.c_void_p), ("kp2", C.c_void_p), ("invsig", C.c_void_p), ("fx_slot", C.c_double),
+                            ("fy_slot", C.c_double), ("lam", C.c_double), ("fx", C.c_float), ("fy", C.c_float), ("max_iters", C.c_int32), ("x", C.c_void_p),
+                            ("diff", C.c_void_p), ("drop", C.c_void_p), ("info", C.c_int32 * 2), ("costs", C.c_double * 2), ("init_lambda", C.c_double), ("init_ok", C.c_int32)]
 
 
 
 class SchwarpStoreC(C.Structure):
-    _fields_ = [("point_id", c_i32_p), ("idx2", c_i32_p), ("tag", C.c_int32)]
+    _fields_ = [("point_id", C.c_void_p), ("idx2", C.c_void_p), ("tag", C.c_int32)]
 
 
 DIFFPROP_FIELDS = ["I1u", "I1v", "I2u", "I2v", "J12a", "J12b", "J12c", "J12d", "J21a", "J21b", "J21c", "J21d",

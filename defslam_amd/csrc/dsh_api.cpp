@@ -506,7 +506,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   // (4 wavefronts: two problems share a CU's 160 KB)
   size_t jl_doubles = 0;
   int max_kd = 0;
-  const size_t lds_budget = ((nw == 4 ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
+  const size_t lds_budget = (((nw == 4 || SFT_WAVES_PER_EU >= 4) ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
   for (int b = 0; b < B; b++) {
     SftDev& hh = c->packed[b].h;
     // A narrow band (kd <= 128) that is long enough for two parts also takes the two-sided factorisation in latency mode: it runs on the

@@ -155,6 +155,9 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
   int with_init = 0;
   struct Off { size_t kp1, kp2, isg, x0, cs, xo, diff, drop, info, costs, bend; };
   std::vector<Off> off(B);
+  // x lives at the head of the output block (in/out): only that part is uploaded with the start values
+  for (int b = 0; b < B; b++) { off[b].xo = out_bytes; out_bytes += al(8 * 2 * (size_t)probs[b].bbs.nptsu * probs[b].bbs.nptsv); }
+  const size_t x_bytes = out_bytes;
   for (int b = 0; b < B; b++) {
     const dsh_schwarp_problem& q = probs[b];
     const size_t n2 = 2 * (size_t)q.bbs.nptsu * q.bbs.nptsv;
@@ -171,7 +174,6 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
       else { o.bend = in_bytes; in_bytes += al(8 * (n2 / 2) * (n2 / 2)); }
       with_init = 1;
     }
-    o.xo = out_bytes; out_bytes += al(8 * n2);                  // x lives in the output block (in/out): its start value is copied there
     o.diff = out_bytes; out_bytes += al(!db && q.diff ? 72 * (size_t)q.P : 0);     // store mode: records and flags live in one strided block (below)
     o.drop = out_bytes; out_bytes += al(!db && q.drop ? (size_t)q.P : 0);
     o.info = out_bytes; out_bytes += 256;
@@ -190,12 +192,19 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
   }
   DevBuf din, dout;
   HIPCHK(c, din.alloc(c, in_bytes)); HIPCHK(c, dout.alloc(c, out_bytes));
-  HIPCHK(c, c->pin_in.ensure(in_bytes + out_bytes)); HIPCHK(c, c->pin_out.ensure(out_bytes));
+  HIPCHK(c, c->pin_in.ensure(in_bytes + x_bytes)); HIPCHK(c, c->pin_out.ensure(out_bytes));
   char* hin = c->pin_in.p;
-  char* hx = c->pin_in.p + in_bytes;   // start values of x, laid out like the output block
-  std::memset(hx, 0, out_bytes);
+  char* hx = c->pin_in.p + in_bytes;   // start values of x, laid out like the head of the output block
+  std::memset(hx, 0, x_bytes);
   char* dib = din.as<char>();
   char* dob = dout.as<char>();
+  // what has to start at zero (scalars of the controller, the step vector) lies in one block: one memset for the whole batch
+  DevBuf dzero;
+  size_t zero_bytes = 0;
+  for (int b = 0; b < B; b++) zero_bytes += 128 + al(8 * 2 * (size_t)probs[b].bbs.nptsu * probs[b].bbs.nptsv);
+  HIPCHK(c, dzero.alloc(c, zero_bytes));
+  HIPCHK(c, hipMemsetAsync(dzero.p, 0, zero_bytes, st));
+  size_t zoff = 0;
   for (int b = 0; b < B; b++) {
     const dsh_schwarp_problem& q = probs[b];
     const Off& o = off[b];
@@ -208,19 +217,19 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
     } else {
       std::memcpy(hx + o.xo, q.x, 8 * (size_t)n2);
     }
-    DevBuf xn, g, dx, r, J, A, M, W, scal, compact;
+    DevBuf xn, g, r, J, A, M, W, compact;
+    double* scal = reinterpret_cast<double*>(dzero.as<char>() + zoff);
+    double* dx = reinterpret_cast<double*>(dzero.as<char>() + zoff + 128);
+    zoff += 128 + al(8 * (size_t)n2);
     const size_t np = (size_t)nrsfm_swp_solve_np(n2);
-    HIPCHK(c, xn.alloc(c, 8 * (size_t)n2)); HIPCHK(c, g.alloc(c, 8 * (size_t)n2)); HIPCHK(c, dx.alloc(c, 8 * (size_t)n2)); HIPCHK(c, r.alloc(c, 8 * (size_t)m));
+    HIPCHK(c, xn.alloc(c, 8 * (size_t)n2)); HIPCHK(c, g.alloc(c, 8 * (size_t)n2)); HIPCHK(c, r.alloc(c, 8 * (size_t)m));
     // the dense (2P+4N) x 2N buffer only serves the Warp::initialize stage (its colocation matrix); the fit keeps its Jacobian structured
     HIPCHK(c, J.alloc(c, q.init_lambda > 0.0 ? 8 * (size_t)m * n2 : 256)); HIPCHK(c, compact.alloc(c, nrsfm_swp_compact_bytes(q.P, q.bbs.nptsu, q.bbs.nptsv)));
     HIPCHK(c, A.alloc(c, 8 * (size_t)n2 * n2)); HIPCHK(c, M.alloc(c, 8 * np * np)); HIPCHK(c, W.alloc(c, 8 * np * 16));
-    HIPCHK(c, scal.alloc(c, 128));
-    HIPCHK(c, hipMemsetAsync(scal.p, 0, 128, st));
-    HIPCHK(c, hipMemsetAsync(dx.p, 0, 8 * (size_t)n2, st));
     nrsfm_swp_fit_fill(hin + fit_bytes * (size_t)b, q.bbs.umin, q.bbs.umax, q.bbs.nptsu, q.bbs.vmin, q.bbs.vmax, q.bbs.nptsv, q.P, q.fx_slot, q.fy_slot, q.lambda, q.fx, q.fy,
                        q.max_iters, reinterpret_cast<const float*>(dib + o.kp1), reinterpret_cast<const float*>(dib + o.kp2), reinterpret_cast<const float*>(dib + o.isg),
-                       reinterpret_cast<double*>(dob + o.xo), xn.as<double>(), reinterpret_cast<double*>(dib + o.cs), g.as<double>(), dx.as<double>(), r.as<double>(),
-                       J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal.as<double>(),
+                       reinterpret_cast<double*>(dob + o.xo), xn.as<double>(), reinterpret_cast<double*>(dib + o.cs), g.as<double>(), dx, r.as<double>(),
+                       J.as<double>(), A.as<double>(), M.as<double>(), W.as<double>(), scal,
                        db ? sdiff.as<float>() + 18 * (size_t)b * maxP : (q.diff ? reinterpret_cast<float*>(dob + o.diff) : nullptr),
                        db ? sdrop.as<uint8_t>() + (size_t)b * maxP : (q.drop ? reinterpret_cast<uint8_t*>(dob + o.drop) : nullptr),
                        reinterpret_cast<int32_t*>(dob + o.info), reinterpret_cast<double*>(dob + o.costs),
@@ -242,7 +251,8 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
       }
   }
   HIPCHK(c, hipMemcpyAsync(dib, hin, in_bytes, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(dob, hx, out_bytes, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(dob, hx, x_bytes, hipMemcpyHostToDevice, st));
+  if (out_bytes > x_bytes) HIPCHK(c, hipMemsetAsync(dob + x_bytes, 0, out_bytes - x_bytes, st));
   HIPCHK(c, nrsfm_swp_fit_batch(dib, B, maxP, maxN, max_it, with_init, st));
   HIPCHK(c, hipMemcpyAsync(c->pin_out.p, dob, out_bytes, hipMemcpyDeviceToHost, st));
   std::vector<uint8_t> hdrop;

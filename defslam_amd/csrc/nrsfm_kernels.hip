@@ -1332,6 +1332,16 @@ __global__ void swpb_colscale_kernel(const SwpFit* fits, int stage) {
   if (!swp_on(f, stage)) return;
   swp_colscale_body(f.n2, f.A, f.cs);
 }
+// The Jacobi scaling enters the normal equations as a factor on sums that do not depend on it (swp_normalc_body: sum * (c1 * c2), g: sum * c):
+// the equations linearised with cs = 1 become the scaled ones by those factors -- the same bits as a second linearisation at the same x.
+__global__ __launch_bounds__(256) void swpb_rescale_kernel(const SwpFit* fits, int stage) {
+  const SwpFit& f = fits[blockIdx.z];
+  const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (!swp_on(f, stage) || i >= f.n2 || j >= f.n2) return;
+  const double ci = f.cs[i];
+  f.A[(size_t)i * f.n2 + j] *= ci * f.cs[j];
+  if (j == 0) f.g[i] *= ci;
+}
 __global__ __launch_bounds__(256) void swpb_damp_kernel(const SwpFit* fits, int stage) {
   const SwpFit& f = fits[blockIdx.z];
   if (!swp_on(f, stage) || (int)blockIdx.y >= f.np) return;
@@ -1627,10 +1637,10 @@ extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int m
     hipLaunchKernelGGL(wib_resolve_kernel, g_one, dim3(512), 0, st, fits);
   }
   hipLaunchKernelGGL(wib_finish_kernel, g_ctl, dim3(64), 0, st, fits, B);
-  // Jacobi scaling from the initial Jacobian (cs = 1 first), then the scaled linearisation of the start; a zero step measures |x|, max |g|
+  // Jacobi scaling from the initial Jacobian (cs = 1 first), then the start's normal equations rescaled; a zero step measures |x|, max |g|
   linearise(SWP_STAGE_ALWAYS);
   hipLaunchKernelGGL(swpb_colscale_kernel, dim3((maxn2 + 127) / 128, B), dim3(128), 0, st, fits, SWP_STAGE_ALWAYS);
-  linearise(SWP_STAGE_ALWAYS);
+  hipLaunchKernelGGL(swpb_rescale_kernel, dim3((maxn2 + 255) / 256, maxn2, B), dim3(256), 0, st, fits, SWP_STAGE_ALWAYS);
   hipLaunchKernelGGL(swpb_step_kernel, g_one, dim3(256), 0, st, fits, SWP_STAGE_ALWAYS);
   hipLaunchKernelGGL(swpb_ctl_kernel, g_ctl, dim3(64), 0, st, fits, B, 0);
   for (int it = 0; it <= max_iters; it++) {   // the last round only lets phase 1 retire the fits that used every iteration

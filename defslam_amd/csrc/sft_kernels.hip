@@ -25,7 +25,6 @@
 #include <float.h>
 #define SFT_KERNEL_SOURCE
 #include "sft_problem.h"
-#define SFT_WAVES_PER_EU 2      // 256 VGPRs per wave: the trailing window of the factorisation lives in accumulator registers
 #include "tile_chol.h"
 
 #define NB 32  // panel width of the blocked band Cholesky

@@ -71,6 +71,10 @@ struct SftSc {
 #define SFT_SPEC_INIT 0
 #define SFT_SPEC_LIN 1
 #define SFT_SPEC_TRIAL 2
+// waves per SIMD the persistent kernels are compiled for (A/B builds override it: tools/ab_build.sh)
+#ifndef SFT_WAVES_PER_EU
+#define SFT_WAVES_PER_EU 2      // 256 VGPRs per wave: the trailing window of the factorisation lives in accumulator registers
+#endif
 #define SFT_SPEC_FACTOR 3       // split problems: the two parts of the factorisation, one workgroup each, in front of SFT_SPEC_TRIAL
 struct SftSpecRes { double chi_new, scale, lambda, ni, pose[8]; int32_t ok, valid; };
 struct SftSpec {

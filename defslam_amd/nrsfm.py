@@ -202,42 +202,55 @@ def calculateSchwarpsBatch(ctx: Context, problems, max_iters=3, db=None, want_re
     Returns a list of (x, diffprops, drop, info, costs) like calculateSchwarps; with init_lam the tuple ends with init_ok."""
     B = len(problems)
     arr = (_lib.SchwarpProblemC * B)()
-    keep = []
+    # inputs and outputs of all fits live in pooled arrays (one address computation per pool, views per fit)
+    Ps = np.array([np.shape(q["kp1"])[0] for q in problems], np.int64)
+    off = np.concatenate([[0], np.cumsum(Ps)])
+    n2s = np.array([2 * q["bbs"].nptsu * q["bbs"].nptsv for q in problems], np.int64)
+    xoff = np.concatenate([[0], np.cumsum(n2s)])
+    kp1 = np.ascontiguousarray(np.concatenate([np.asarray(q["kp1"], np.float32).reshape(-1, 2) for q in problems]))
+    kp2 = np.ascontiguousarray(np.concatenate([np.asarray(q["kp2"], np.float32).reshape(-1, 2) for q in problems]))
+    isg = np.ascontiguousarray(np.concatenate([np.asarray(q["invsig"], np.float32).reshape(-1) for q in problems]))
+    assert kp1.shape[0] == kp2.shape[0] == isg.shape[0] == off[-1]
+    x = np.zeros(int(xoff[-1]))
+    store = db is not None
+    diff = (np.empty if (want_records or not store) else np.zeros)((int(off[-1]), 18), np.float32)     # the call writes every record it is handed a buffer for
+    drop = np.empty(int(off[-1]), np.uint8)
+    a_kp1, a_kp2, a_isg, a_x, a_diff, a_drop = (v.ctypes.data for v in (kp1, kp2, isg, x, diff, drop))
+    if store:
+        pid = np.ascontiguousarray(np.concatenate([np.asarray(q["point_id"], np.int32).reshape(-1) for q in problems]))
+        has_idx2 = [q.get("idx2") is not None for q in problems]
+        idx2 = np.ascontiguousarray(np.concatenate([np.asarray(q["idx2"], np.int32).reshape(-1) if h else np.arange(P, dtype=np.int32)
+                                                    for q, h, P in zip(problems, has_idx2, Ps)]))
+        assert pid.shape[0] == idx2.shape[0] == off[-1]
+        a_pid, a_idx2 = pid.ctypes.data, idx2.ctypes.data
+        st = (_lib.SchwarpStoreC * B)()
     for b, q in enumerate(problems):
-        kp1 = np.ascontiguousarray(q["kp1"], np.float32).reshape(-1, 2)
-        kp2 = np.ascontiguousarray(q["kp2"], np.float32).reshape(-1, 2)
-        isg = np.ascontiguousarray(q["invsig"], np.float32)
+        o, P, xo = int(off[b]), int(Ps[b]), int(xoff[b])
         init_lam = float(q.get("init_lam", 0.0))
-        x = np.array(q["x0"], np.float64, copy=True) if init_lam <= 0.0 else np.zeros(2 * q["bbs"].nptsu * q["bbs"].nptsv)
-        P = kp1.shape[0]
-        diff = np.zeros((P, 18), np.float32)
-        drop = np.zeros(P, np.uint8)
-        keep.append((kp1, kp2, isg, x, diff, drop))
+        if init_lam <= 0.0:
+            x[xo:xo + int(n2s[b])] = q["x0"]
         a = arr[b]
         a.bbs = q["bbs"].c()
         a.P = P
-        a.kp1, a.kp2, a.invsig = _ptr(kp1, C.c_float), _ptr(kp2, C.c_float), _ptr(isg, C.c_float)
+        a.kp1, a.kp2, a.invsig = a_kp1 + 8 * o, a_kp2 + 8 * o, a_isg + 4 * o
         a.fx_slot, a.fy_slot, a.lam, a.fx, a.fy = float(q["fx_slot"]), float(q["fy_slot"]), float(q["lam"]), float(q["fx"]), float(q["fy"])
         a.max_iters = int(q.get("max_iters", max_iters))
-        a.x, a.diff, a.drop = _ptr(x, C.c_double), _ptr(diff, C.c_float), _ptr(drop, C.c_uint8)
+        a.x, a.drop = a_x + 8 * xo, a_drop + o
+        a.diff = a_diff + 72 * o if (want_records or not store) else None
         a.init_lambda = init_lam
-    if db is not None:
-        st = (_lib.SchwarpStoreC * B)()
-        for b, q in enumerate(problems):
-            pid = np.ascontiguousarray(q["point_id"], np.int32)
-            idx2 = np.ascontiguousarray(q["idx2"], np.int32) if q.get("idx2") is not None else None
-            assert pid.shape[0] == arr[b].P and (idx2 is None or idx2.shape[0] == arr[b].P)
-            keep.append((pid, idx2))
-            st[b].point_id, st[b].idx2, st[b].tag = _ptr(pid, C.c_int32), _ptr(idx2, C.c_int32), int(q.get("tag", b))
-            if not want_records:
-                arr[b].diff = None
+        if store:
+            st[b].point_id, st[b].idx2, st[b].tag = a_pid + 4 * o, a_idx2 + 4 * o, int(q.get("tag", b))
+    if store:
         ctx._check(ctx._L.dsh_schwarp_fit_batch_store(ctx._h, B, arr, st, db._h), "dsh_schwarp_fit_batch_store")
     else:
         ctx._check(ctx._L.dsh_schwarp_fit_batch(ctx._h, B, arr), "dsh_schwarp_fit_batch")
+    dropb = drop.view(np.bool_)
     out = []
     for b in range(B):
-        t = (keep[b][3], keep[b][4], keep[b][5].astype(bool), np.array(arr[b].info[:], np.int32), np.array(arr[b].costs[:]))
-        out.append(t + (bool(arr[b].init_ok),) if arr[b].init_lambda > 0.0 else t)
+        o, e, xo = int(off[b]), int(off[b + 1]), int(xoff[b])
+        a = arr[b]
+        t = (x[xo:xo + int(n2s[b])], diff[o:e], dropb[o:e], np.array(a.info[:], np.int32), np.array(a.costs[:]))
+        out.append(t + (bool(a.init_ok),) if a.init_lambda > 0.0 else t)
     return out
 
 

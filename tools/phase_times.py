@@ -2,8 +2,10 @@ import sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from defslam_amd import synth, sft, _lib
 import os
-if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ab', 'lab_timers.so')):
-    _lib.LAB_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ab', 'lab_timers.so')   # a lab build with -DSFT_PHASE_TIMERS
+_ab = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ab', os.environ.get('AB_LIB', 'lab_timers') + '.so')
+if os.path.exists(_ab):
+    _lib.LAB_LIB_PATH = _ab   # an A/B lab build (tools/ab_build.sh NAME "-DSFT_PHASE_TIMERS ..."), chosen with AB_LIB=NAME
+    print("lab library:", _ab)
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 WAVES = int(sys.argv[3]) if len(sys.argv) > 3 else 0
