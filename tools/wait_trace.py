@@ -3,7 +3,11 @@ factorisation of problem 0, columns: buffers free, W, X1, X2..i, border, store f
 usage: tools/wait_trace.py [B] [waves]"""
 import sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from defslam_amd import synth, sft
+from defslam_amd import synth, sft, _lib
+import os
+_ab = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ab", os.environ.get("AB_LIB", "lab_trace") + ".so")
+if os.path.exists(_ab):
+    _lib.LAB_LIB_PATH = _ab
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = sft.Context(0, lab=True)
