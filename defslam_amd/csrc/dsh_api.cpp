@@ -301,7 +301,10 @@ int run_once(dsh_ctx* c) {
   while (true) {
     for (int i = 0; i < group && rounds < worst; i++, rounds++) {
       HIPCHK(c, launch(SFT_SPEC_LIN));
-      if (c->any_split) HIPCHK(c, launch(SFT_SPEC_FACTOR));   // two workgroups per lane: the two parts of the two-sided factorisation
+      if (c->any_split) {   // two workgroups per lane: the two parts of the two-sided factorisation, then the solve (reduced problem + own part)
+        HIPCHK(c, launch(SFT_SPEC_FACTOR));
+        HIPCHK(c, launch(SFT_SPEC_SOLVE));
+      }
       HIPCHK(c, launch(SFT_SPEC_TRIAL));
     }
     HIPCHK(c, launch(SFT_SPEC_LIN));   // the verdict on the last round (and, unless the problem is finished, the next linearisation)
@@ -532,6 +535,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
         p1.nS = n1p / kTS; p1.nT = p1.nS + sT; p1.tpr = hh.tpr; p1.wbt = hh.wbt; p1.b_base = hh.Dn - 1 + hh.sp_pad; p1.b_sign = -1; p1.b_lo = hh.sp_pad; p1.b_hi = n1p;
         p2.nS = sT; p2.nT = sT; p2.wbt = sT - 1; p2.tpr = sT;
         hh.sp_xl = sT * p2.tpr * kTS * kTS + 8 * kTS * sT + 64;
+        hh.part[3] = p2;   // second workspace of the reduced problem (SFT_SPEC_SOLVE: one per workgroup)
       }
     }
     size_t used = 0;
@@ -576,7 +580,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   }
   c->res_bytes = a.size - c->res_off;
   struct POffs { size_t Hb, Lb, Lt, LbT, Lbord, Linv, x, xchg; };
-  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hc, Hb, Hbord, Hcn, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; POffs part[3]; };
+  struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hc, Hb, Hbord, Hcn, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; POffs part[4]; };
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
@@ -603,7 +607,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     w.Lt = a.take(h.tile_mode == 2 ? 8 * band_elems : 0); w.LbT = a.take(h.tile_mode == 2 ? 8 * (Dnp / kTS) * (size_t)kTS * kTS : 0);
     w.x = a.take(8 * (Dnp + 8)); w.dbg = a.take(1024);
     if (h.split)
-      for (int g = 0; g < 3; g++) {   // the band matrices of the two parts and of the reduced problem (H of a part: one copy, lane 0's, shared by the lanes)
+      for (int g = 0; g < 4; g++) {   // the band matrices of the two parts and of the reduced problem, twice (H of a part: one copy, lane 0's, shared by the lanes)
         const SftPart& q = h.part[g];
         const size_t tiles = 8 * (size_t)q.nT * q.tpr * kTS * kTS, col = 8 * (size_t)q.nT * kTS * kTS;
         POffs& po = w.part[g];
@@ -670,7 +674,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.x = (double*)(base + w.x); h.dbg = (double*)(base + w.dbg);
     h.spec_xyz[0] = (double*)(base + w.sx0); h.spec_xyz[1] = (double*)(base + w.sx1);
     if (h.split)
-      for (int g = 0; g < 3; g++) {
+      for (int g = 0; g < 4; g++) {
         const POffs& po = w.part[g];
         SftPart& q = h.part[g];
         q.Hb = g < 2 ? (double*)(base + (lane ? wo[b].part[g].Hb : po.Hb)) : (double*)(base + po.xchg);   // reduced problem: H = the summed exchange buffer

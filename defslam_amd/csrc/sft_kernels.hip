@@ -2283,30 +2283,9 @@ __device__ __forceinline__ double damping_trial(const SftDev& P, Ctl* ctl, doubl
   if (P.tile_mode == 2) {
     if constexpr (NW == 8) {   // wide band: always the 512-thread kernel
       if (P.split && prefactored) {
-        // two-sided factorisation: both parts were factored by their own workgroups (sft_spec_kernel, SFT_SPEC_FACTOR).  Their Schur
-        // contributions are summed into the reduced (separator + camera) problem, which is solved here; then the parts back-substitute.
-        const int xl = P.sp_xl;
-        const auto x0 = P.part[0].xchg, x1 = P.part[1].xchg, xs = P.part[2].xchg;
-        for (int i = tid; i < xl; i += NT) xs[i] = x0[i] + x1[i];
-        __syncthreads();
-        const int nTr = P.part[2].nT;
-        const bool parts_ok = xs[(size_t)nTr * P.part[2].tpr * (TS * TS) + (size_t)8 * TS * nTr + 56] == 0.0;
-        __syncthreads();
-        if (parts_ok) factor_wide(P, 2, ctl, panel);
-        else if (tid == 0) ctl->fact_ok = 0;
-        __syncthreads();
-        PH_ADD(5);
-        backsub_wide(P, 2, ctl, panel);
-        backsub_wide(P, 0, ctl, panel);
-        backsub_wide(P, 1, ctl, panel);
-        if (ctl->fact_ok) {   // the solution in the natural ordering
-          const int c0 = P.sp_c0, sp = P.sp_s, pad = P.sp_pad, n1p = P.sp_n1p;
-          const auto xa = P.part[0].x, xb = P.part[1].x, xr = P.part[2].x;
-          for (int j = tid; j < c0; j += NT) P.x[j] = xa[j];
-          for (int k = tid; k < sp; k += NT) P.x[c0 + k] = xr[k];
-          for (int j = pad + tid; j < n1p; j += NT) P.x[Dn - 1 - (j - pad)] = xb[j];
-          if (tid < 6) P.x[Dnp + tid] = xr[TS * nTr + tid];
-        }
+        // two-sided factorisation: the parts were factored (SFT_SPEC_FACTOR) and the system solved (SFT_SPEC_SOLVE: P.x holds the update
+        // in the natural ordering) by the two workgroups of the lane; what they report is all this launch needs
+        if (tid == 0) ctl->fact_ok = (P.part[0].x[TS * P.part[0].nT + 7] == 1.0 && P.part[1].x[TS * P.part[1].nT + 7] == 1.0) ? 1 : 0;
         __syncthreads();
         PH_ADD(6);
       } else {
@@ -2585,8 +2564,8 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K, int phase) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // SFT_SPEC_FACTOR runs two workgroups per (problem, lane): one per part of the two-sided factorisation
-  const int wgs = phase == SFT_SPEC_FACTOR ? 2 : 1, fpart = blockIdx.x % wgs;
+  // SFT_SPEC_FACTOR / SFT_SPEC_SOLVE run two workgroups per (problem, lane): one per part of the two-sided factorisation
+  const int wgs = (phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) ? 2 : 1, fpart = blockIdx.x % wgs;
   const int bx = blockIdx.x / wgs;
   const int B = gridDim.x / (K * wgs), b = bx / K, j = bx % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
   const SftDev& P = probs[(size_t)j * B + b];
@@ -2698,7 +2677,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     }
     return;
   }
-  if (phase == SFT_SPEC_FACTOR) {
+  if (phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) {
     // ---- two-sided factorisation of the lane's trial: this workgroup factors part `fpart` at the lane's damping.  The controller state is
     // only READ here (the trial launch behind this one updates it): on a fresh linearisation of the first iteration the initial damping is
     // recomputed from H -- the same number the trial launch stores.
@@ -2715,7 +2694,40 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     if (S.qbase + j >= 10) return;
     if (tid == 0) ctl->lambda = lam;
     __syncthreads();
-    factor_wide(P, fpart, ctl, panel);
+    if (phase == SFT_SPEC_FACTOR) {
+      factor_wide(P, fpart, ctl, panel);
+      return;
+    }
+    // ---- SFT_SPEC_SOLVE: the Schur contributions of the two parts are summed into the reduced (separator + camera) problem (which adds the
+    // damping of the separator's diagonal); BOTH workgroups of the lane solve it, each in its own workspace (part[2 + fpart]), and then
+    // back-substitute their own part and scatter it into the natural ordering
+    const int red = 2 + fpart;
+    const int xl = P.sp_xl;
+    const auto x0 = P.part[0].xchg, x1 = P.part[1].xchg, xs = P.part[red].xchg;
+    for (int i = tid; i < xl; i += NT) xs[i] = x0[i] + x1[i];
+    __syncthreads();
+    const int nTr = P.part[2].nT;
+    const bool parts_ok = xs[(size_t)nTr * P.part[2].tpr * (TS * TS) + (size_t)8 * TS * nTr + 56] == 0.0;
+    __syncthreads();
+    if (parts_ok) factor_wide(P, red, ctl, panel);
+    else if (tid == 0) ctl->fact_ok = 0;
+    __syncthreads();
+    backsub_wide(P, red, ctl, panel);
+    backsub_wide(P, fpart, ctl, panel, red);
+    const int okf = ctl->fact_ok;
+    if (okf) {   // this workgroup's share of the solution in the natural ordering
+      const int c0 = P.sp_c0, sp = P.sp_s, pad = P.sp_pad, n1p = P.sp_n1p;
+      const int Dnp = ((Dn + NB - 1) / NB) * NB;
+      const auto xp = P.part[fpart].x, xr = P.part[red].x;
+      if (fpart == 0) {
+        for (int q = tid; q < c0; q += NT) P.x[q] = xp[q];
+        for (int k = tid; k < sp; k += NT) P.x[c0 + k] = xr[k];
+        if (tid < 6) P.x[Dnp + tid] = xr[TS * nTr + tid];
+      } else {
+        for (int q = pad + tid; q < n1p; q += NT) P.x[Dn - 1 - (q - pad)] = xp[q];
+      }
+    }
+    if (tid == 0) P.part[fpart].x[TS * P.part[fpart].nT + 7] = okf ? 1.0 : 0.0;
     return;
   }
   // ---- SFT_SPEC_TRIAL
@@ -3160,7 +3172,7 @@ extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, in
     if (e != hipSuccess) return e;
     *configured = lds;
   }
-  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K * (phase == SFT_SPEC_FACTOR ? 2 : 1)), dim3(512), lds, stream, d_probs, d_spec, K, phase);
+  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K * ((phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) ? 2 : 1)), dim3(512), lds, stream, d_probs, d_spec, K, phase);
   return hipGetLastError();
 }
 

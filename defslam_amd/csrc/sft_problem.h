@@ -76,6 +76,7 @@ struct SftSc {
 #define SFT_WAVES_PER_EU 2      // 256 VGPRs per wave: the trailing window of the factorisation lives in accumulator registers
 #endif
 #define SFT_SPEC_FACTOR 3       // split problems: the two parts of the factorisation, one workgroup each, in front of SFT_SPEC_TRIAL
+#define SFT_SPEC_SOLVE 4        // split problems: reduced solve (by both workgroups, each in its own copy) + the workgroup's part back-substituted
 struct SftSpecRes { double chi_new, scale, lambda, ni, pose[8]; int32_t ok, valid; };
 struct SftSpec {
   double lambda, ni, chi_cur, chi_ini, lambda_start, rho;
@@ -93,7 +94,9 @@ struct SftSpec {
 // contributions, is solved once, and the parts back-substitute independently.
 //   part g as a band matrix: nS eliminated tile columns (part 1: pad identity scalars first, so that the separator starts on a tile
 //   boundary), then the sT separator tile rows; its border columns are read from the natural border rows through (base, sign).
-//   part[2] = the reduced (separator) problem: dense band of sT tile columns, border = camera + right-hand side.
+//   part[2] = the reduced (separator) problem: dense band of sT tile columns, border = camera + right-hand side; part[3] = a second
+//   workspace of the same shape: in SFT_SPEC_SOLVE both workgroups of a lane solve the reduced problem (cheaper than handing its
+//   solution from one to the other through another launch), workgroup g in part[2 + g].
 struct SftPart {
   int32_t nT, nS, tpr, wbt;            // tile rows (eliminated + separator), eliminated tile columns, tile pitch of a row, most sub-diagonal tiles
   int32_t b_base, b_sign, b_lo, b_hi;  // column j of the part (b_lo <= j < b_hi) is natural border column b_base + b_sign * j; others are zero
@@ -187,5 +190,5 @@ struct SftDev {
   int32_t sp_c0, sp_s, sp_n1p, sp_pad;   // cut: part 0 = scalars [0, c0), separator [c0, c0+s), part 1 = the rest, reversed behind sp_pad identity scalars (n1p = pad + count)
   int32_t sp_xl;                  // doubles of one exchange buffer
   int32_t pad2[2];
-  SftPart part[3];
+  SftPart part[4];
 };

@@ -50,7 +50,7 @@ __device__ __forceinline__ WideView wide_view(const SftDev& P, int which) {
   v.nT = uni(q.nT); v.nS = uni(q.nS); v.tpr = uni(q.tpr); v.wb = uni(q.wbt);
   v.Hb = uni(q.Hb); v.Lb = uni(q.Lb); v.Lt = uni(q.Lt); v.LbT = uni(q.LbT); v.Lbord = uni(q.Lbord); v.Linv = uni(q.Linv); v.x = uni(q.x); v.xchg = uni(q.xchg);
   v.xr_tpr = uni(P.part[2].tpr); v.xr_nT = uni(P.part[2].nT);
-  if (which == 2) {   // the reduced problem: its input is the summed exchange buffer
+  if (which >= 2) {   // the reduced problem (2, or its second copy 3): its input is the summed exchange buffer
     v.lam_lo = 0; v.lam_hi = uni(P.sp_s);
     v.bstride = TS * v.nT; v.b_base = 0; v.b_sign = 1; v.b_lo = 0; v.b_hi = TS * v.nT;
     v.reversed = false; v.corner_from_H = true; v.finish = true;
@@ -93,7 +93,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
   };
   v4d cacc = {0.0, 0.0, 0.0, 0.0};     // this wave's share of the corner updates; wave 0 starts from H_cc + lambda I
   if (wave == 0 && V.corner_from_H) {
-    const double lam_c = which == 2 ? 0.0 : lambda;   // the reduced corner already carries the damping (part 0 added it)
+    const double lam_c = which >= 2 ? 0.0 : lambda;   // the reduced corner already carries the damping (part 0 added it)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int r = crow + 4 * q;
@@ -385,7 +385,8 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
 // last to the first; wave w forms the partial products of tiles (J + d, J), d = w + 1 and w + 9; wave 0 finishes the block.
 // which: see WideView.  A part (0 / 1) starts behind its eliminated columns: the separator rows of its band matrix take the solution of
 // the reduced problem (part 1 in reversed order), the camera update comes from there as well.
-__device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, double* ws) {
+// red: which copy of the reduced problem holds the separator / camera solution a part starts from (2 or 3)
+__device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, double* ws, int red = 2) {
   constexpr int NW = 8, RPW = WB / NW, RING = 32;
   if (!ctl->fact_ok) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -398,7 +399,7 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, 
   lds_double* part = xw + TS * RING;           // slot 0: camera rows, slots 1..WB: sub-diagonal tiles
   const int crow = lane >> 4, ccol = lane & 15;
   const bool is_part = which == 0 || which == 1;
-  const auto xred = is_part ? uni(P.part[2].x) : V.x;        // where the camera update (and, for a part, the separator solution) is
+  const auto xred = is_part ? uni(P.part[red].x) : V.x;        // where the camera update (and, for a part, the separator solution) is
   const int sred = is_part ? TS * V.xr_nT : Dnp;
   const double xc = (lane < 6) ? xred[sred + lane] : 0.0;
   double xcr[6];
