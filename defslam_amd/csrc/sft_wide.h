@@ -20,6 +20,18 @@
 
 __device__ __forceinline__ size_t wtile_off(int tpr, int I, int d) { return ((size_t)I * tpr + d) * (TS * TS); }
 
+#ifdef SFT_WIDE_SC1_PROBE
+// A/B probe: L tiles loaded at agent scope (what a tile written by ANOTHER workgroup, possibly on another XCD, would need)
+__device__ __forceinline__ v4d wide_ltile_load(const SFT_G double* p) {
+  v4d r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+#else
+__device__ __forceinline__ v4d wide_ltile_load(const SFT_G double* p) { return *reinterpret_cast<const SFT_G v4d*>(p); }
+#endif
+
 // What one call factors / back-substitutes: the whole node block of a problem (which = -1), or -- two-sided factorisation, SftPart in
 // sft_problem.h -- part 0 or 1 (a band matrix whose LAST rows are the separator: the elimination stops after the part's own nS tile
 // columns and the rest of the loop only forms the part's Schur contribution to the separator block, the separator x camera border and
@@ -136,13 +148,13 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
     v4d buf[2][U];
     const int last = max(Kend - 1 - K0, 0);
 #pragma unroll
-    for (int u = 0; u < U; u++) buf[0][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(u, last) * bstride + 4 * lane);
+    for (int u = 0; u < U; u++) buf[0][u] = wide_ltile_load(brow + (long)min(u, last) * bstride + 4 * lane);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       if (c + 1 < NCH) {
 #pragma unroll
         for (int u = 0; u < U; u++)
-          buf[(c + 1) & 1][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
+          buf[(c + 1) & 1][u] = wide_ltile_load(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -159,13 +171,13 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
     v4d buf[2][U];
     const int last = max(n - 1, 0);
 #pragma unroll
-    for (int u = 0; u < U; u++) buf[0][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(u, last) * bstride + 4 * lane);
+    for (int u = 0; u < U; u++) buf[0][u] = wide_ltile_load(brow + (long)min(u, last) * bstride + 4 * lane);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       if (c + 1 < 4) {
 #pragma unroll
         for (int u = 0; u < U; u++)
-          buf[(c + 1) & 1][u] = *reinterpret_cast<const SFT_G v4d*>(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
+          buf[(c + 1) & 1][u] = wide_ltile_load(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
       }
 #pragma unroll
       for (int u = 0; u < U; u++)
@@ -224,7 +236,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
     for (int h = 0; h < 2; h++) {
       const int dist = 2 + wave + 8 * h, K = J + 1 - dist;
       staged[h] = dist <= wb && K >= 0 && J + 1 < nT;
-      if (staged[h]) stage[h] = *reinterpret_cast<const SFT_G v4d*>(Ltg + wtile_off(tpr, K, dist) + 4 * lane);
+      if (staged[h]) stage[h] = wide_ltile_load(Ltg + wtile_off(tpr, K, dist) + 4 * lane);
     }
     const bool elim = J < nS;          // a separator column of a part is not eliminated: its tiles are the Schur contribution
     if (d == 0) {
