@@ -491,33 +491,50 @@ __device__ __forceinline__ void swp_cellid_body(SwpPar p, const float* __restric
 }
 __device__ __forceinline__ void swp_buckets_body(SwpPar p, const int32_t* cid, int32_t* __restrict__ bw_ptr, int32_t* __restrict__ bw_idx,
                                                  int32_t* __restrict__ bs_ptr, int32_t* __restrict__ bs_idx, bool use_lds) {
+  // A stable counting sort of the rows by knot cell (rows of a cell in index order: the order the gather adds them in).  Histogram by LDS
+  // atomics, the row pointers by one lane per set, placement by one thread per cell.
   __shared__ int cnt[2][512];
-  extern __shared__ int cid_l[];                 // the cell ids, read ncell times: from LDS
+  extern __shared__ __attribute__((aligned(16))) int cid_l[];
   const int ncell = (p.nu - 3) * (p.nv - 3);
   const int t = threadIdx.x;
   if (use_lds) {
     for (int i = t; i < p.P + p.N; i += blockDim.x) cid_l[i] = cid[i];
-    __syncthreads();
     cid = cid_l;
   }
-  for (int c = t; c < ncell; c += blockDim.x) {
-    int nw = 0, ns = 0;
-    for (int i = 0; i < p.P; i++) nw += cid[i] == c;
-    for (int k = 0; k < p.N; k++) ns += cid[p.P + k] == c;
-    cnt[0][c] = nw; cnt[1][c] = ns;
+  for (int c = t; c < 2 * 512; c += blockDim.x) (&cnt[0][0])[c] = 0;
+  __syncthreads();
+  for (int i = t; i < p.P + p.N; i += blockDim.x) {
+    const int c = cid[i];
+    if (c >= 0) atomicAdd(&cnt[i < p.P ? 0 : 1][c], 1);
   }
   __syncthreads();
   if (t < 2) {
     int32_t* ptr = t == 0 ? bw_ptr : bs_ptr;
     int acc = 0;
-    for (int c = 0; c < ncell; c++) { ptr[c] = acc; acc += cnt[t][c]; }
+    for (int c = 0; c < ncell; c++) { const int k = cnt[t][c]; ptr[c] = acc; cnt[t][c] = acc; acc += k; }   // cnt becomes the cursor of the cell
     ptr[ncell] = acc;
   }
   __syncthreads();
-  for (int c = t; c < ncell; c += blockDim.x) {
-    int qw = bw_ptr[c], qs = bs_ptr[c];
-    for (int i = 0; i < p.P; i++) if (cid[i] == c) bw_idx[qw++] = i;
-    for (int k = 0; k < p.N; k++) if (cid[p.P + k] == c) bs_idx[qs++] = k;
+  // placement: one thread per (set, cell) walks the ids in index order, four per LDS read (the ids are the same address for every lane: a
+  // broadcast), and appends the rows of its cell -- stable by construction
+  for (int w = t; w < 2 * ncell; w += blockDim.x) {
+    const int set = w >= ncell, c = set ? w - ncell : w;
+    const int off = set ? p.P : 0, count = set ? p.N : p.P;
+    int32_t* idx = set ? bs_idx : bw_idx;
+    int q = cnt[set][c];
+    int i = 0;
+    if (use_lds) {
+      // (4-aligned stretch of the LDS copy; the warp rows start at 0, the Schwarzian rows at P)
+      for (; i < count && ((off + i) & 3); i++) if (cid[off + i] == c) idx[q++] = i;
+      for (; i + 4 <= count; i += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(cid + off + i);
+        if (v.x == c) idx[q++] = i;
+        if (v.y == c) idx[q++] = i + 1;
+        if (v.z == c) idx[q++] = i + 2;
+        if (v.w == c) idx[q++] = i + 3;
+      }
+    }
+    for (; i < count; i++) if (cid[off + i] == c) idx[q++] = i;
   }
 }
 
@@ -740,13 +757,172 @@ __device__ __forceinline__ double swp_row16_sum(double v) {
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
 }
-__device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, const double* __restrict__ A, const double* __restrict__ g, double radius,
-                                                        double* __restrict__ M, double* __restrict__ Winv, double* __restrict__ dx, double* __restrict__ out) {
+// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global stores (the L tiles that nobody reads
+// before the end of the factorisation), a round trip to L2 in every step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Factor loop of the solve for a band of at most 7 sub-diagonal tiles (the Schwarp fit: exactly 7; Warp::initialize: 3): the trailing
+// window lives in REGISTERS -- wavefront w owns the tile rows I = w (mod 8), tile (I, J) transposed in acc[J & 7], loaded once from the
+// natural-order matrix A by the wave that owns the row (eight steps before it is needed: a second register set keeps the row after next in
+// flight, a row fetched one step ahead made every step wait for its gather).  With T^T in accumulator layout every product takes registers as they are:
+//   TRSM    X_I^T = W_K T(I,K)^T        A = W_K (LDS), B = acc[K & 7]
+//   update  T(I,J)^T -= X_J X_I^T       A = X_J (LDS, written by the owner of row J in lane order: the reader lane reads what the same lane
+//                                        wrote), B = X_I^T (the TRSM result, still in registers); J = I: A = the same registers
+// so a step is two barriers and no global round trip (the version below that keeps M in memory: four dependent ones, 7 us per step
+// against 1.8).  L tiles are stored (fire and forget) in the layout the back substitution reads.  Same products in the same order as the
+// memory version: the factor is bit-identical, the forward substitution sums in another order.
+// The rows come straight from A (natural ordering, row-major n x n): element (r, c) of the interleaved, damped, identity-padded matrix
+// is A[unperm(r)][unperm(c)] (+ clamp(diag) / radius on the diagonal) -- the damp kernel and its 1.3 MB copy per solve are not needed.
+__device__ __forceinline__ void swp_factor_band8(int n, int np, int il, const double* __restrict__ A_, double radius, double* __restrict__ M_,
+                                                 double* __restrict__ Winv_, double* Xl, double* Wk, double* yv, int* bad) {
+  // The pointers come out of a descriptor in memory: generic address space, i.e. FLAT loads and stores, which count on the LDS counter as
+  // well -- every LDS wait (the barriers of the loop) would then wait for the rows in flight.  Global-address-space views:
+  typedef __attribute__((address_space(1))) double gdbl;
+  const gdbl* A = (const gdbl*)A_;
+  gdbl* M = (gdbl*)M_;
+  gdbl* Winv = (gdbl*)Winv_;
+  const int NT = np / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int crow = lane >> 4, ccol = lane & 15;
+  v4d acc[8];
+  const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto unperm = [&](int i) { return il ? ((i & 1) ? n / 2 + (i >> 1) : (i >> 1)) : i; };
+  v4d nxt[8];                                        // the row after next of this wave, in flight for eight steps
+  auto load_row = [&](v4d (&acc)[8], int I) {
+    const int c = 16 * I + ccol, pc = unperm(c);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++) {
+      // slot s8 holds column J = the one of I-7 .. I with J & 7 == s8; acc[s8][q] = element (16 J + crow + 4 q, 16 I + ccol)
+      const int J = I - ((I - s8) & 7);
+      v4d t = zero4;
+      if (J >= 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int r = 16 * J + crow + 4 * q;
+          t[q] = (r < n && c < n) ? A[(size_t)unperm(r) * n + pc] : ((r == c) ? 1.0 : 0.0);
+        }
+      }
+      acc[s8] = t;
+    }
+    // the damping of the diagonal tile (slot I & 7 == wave), behind ALL the loads: written into the load loop it made the compiler wait for
+    // every element before the next one was requested -- 32 round trips in a row per tile row
+#pragma unroll
+    for (int s8 = 0; s8 < 8; s8++)
+      if (s8 == wave && crow == (ccol & 3) && c < n) {
+        const int qd = ccol >> 2;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q == qd) acc[s8][q] += fmin(fmax(acc[s8][q], 1e-6), 1e32) / radius;
+      }
+  };
+  auto factor_diag = [&](int K, v4d a) {
+    v4d w;
+    if (!chol_inv_blocked(a, w) && lane == 0) *bad = 1;
+    const double yk = yv[16 * K + ccol];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      Wk[(crow + 4 * q) * SWS_TP + ccol] = w[q];                        // W row-major: the TRSM reads it as the A operand
+      Winv[(size_t)(16 * K + crow + 4 * q) * 16 + ccol] = w[q];
+    }
+    double z[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) z[q] = swp_row16_sum(w[q] * yk);      // z_K = W y_K, row crow + 4q
+    if (ccol == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) yv[16 * K + crow + 4 * q] = z[q];
+    }
+  };
+  int myrow = wave;                                  // the row whose tiles acc holds
+  if (myrow < NT) load_row(acc, myrow);
+  if (myrow + 8 < NT) load_row(nxt, myrow + 8);
+  if (wave == 0) factor_diag(0, acc[0]);
+  __syncthreads();
+  for (int K = 0; K < NT; K++) {
+    v4d xt = zero4;
+    const bool pivot_row = myrow == K;
+    const bool active = myrow > K && myrow < NT;     // K < myrow <= K + 7
+    if (pivot_row) {
+      myrow = K + 8;                                  // this wave's next row has been on its way since step K - 8; the one after it starts now
+#pragma unroll
+      for (int s8 = 0; s8 < 8; s8++) acc[s8] = nxt[s8];
+      if (myrow + 8 < NT) load_row(nxt, myrow + 8);
+    } else if (active) {
+      const int I = myrow;
+      double a[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) a[kk] = Wk[ccol * SWS_TP + crow + 4 * kk];
+      v4d b = zero4;                                  // tile (I, K): slot K & 7 (wave-uniform branches, no run-time register index)
+#pragma unroll
+      for (int s8 = 0; s8 < 8; s8++)
+        if (s8 == (K & 7)) b = acc[s8];
+      v4d x = zero4, x2 = zero4;
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], x, 0, 0, 0);
+      x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], x2, 0, 0, 0);
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], x, 0, 0, 0);
+      x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], x2, 0, 0, 0);
+      xt = x + x2;                                    // xt[q] = X_I[ccol][crow + 4q]
+      gdbl* Lt = M + ((size_t)I * NT + K) * 256 + (size_t)((ccol & 3) * 16 + crow) * 4 + (ccol >> 2);
+      double p = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        Lt[16 * q] = xt[q];                           // element (ccol, crow + 4q) of tile (I, K), accumulator-order storage
+        Xl[(size_t)(I & 7) * 256 + q * 64 + lane] = xt[q];
+        p = fma(xt[q], yv[16 * K + crow + 4 * q], p);
+      }
+      p += __shfl_xor(p, 16, 64);
+      p += __shfl_xor(p, 32, 64);
+      if (crow == 0) yv[16 * I + ccol] -= p;          // forward substitution of block row I: only this wave touches it in this step
+    }
+    lds_barrier();
+    if (active) {
+      const int I = myrow;
+      // the diagonal tile first: the owner of row K+1 factors it while the longer rows are still being updated
+      v4d d = zero4;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; s8++)
+        if (s8 == wave) d = acc[s8];                  // I & 7 == wave
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[kk], xt[kk], d, 0, 0, 0);
+      if (I == K + 1) {
+        __builtin_amdgcn_s_setprio(3);                // the chain of the factorisation runs through this tile: ahead of the wave it shares the SIMD with
+        factor_diag(I, d);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+          if (s8 == wave) acc[s8] = d;
+          const int J = I - ((I - s8) & 7);           // the column slot s8 holds for row I; X_J sits in slot J & 7 == s8 of Xl as well
+          if (J > K && J < I) {
+            v4d t = acc[s8];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xl[(size_t)s8 * 256 + kk * 64 + lane], xt[kk], t, 0, 0, 0);
+            acc[s8] = t;
+          }
+        }
+      }
+    }
+    lds_barrier();
+  }
+}
+
+// gnv > 0: A is the normal matrix of a two-coordinate problem on a control grid with gnv points along v (rows of A outside the 7 x 7
+// neighbourhood of their control point are zero: the model decrease only reads that neighbourhood); 0: dense rows
+__device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, const double* __restrict__ A_, const double* __restrict__ g_, double radius,
+                                                        double* __restrict__ M_, double* __restrict__ Winv_, double* __restrict__ dx_, double* __restrict__ out_, int gnv = 0) {
+  // (global-address-space views: pointers read from a descriptor are generic, and flat accesses also count on the LDS counter)
+  typedef __attribute__((address_space(1))) double gdbl;
+  typedef __attribute__((address_space(1))) v4d gv4d;
+  const gdbl* A = (const gdbl*)A_;
+  const gdbl* g = (const gdbl*)g_;
+  gdbl* M = (gdbl*)M_;
+  gdbl* Winv = (gdbl*)Winv_;
+  gdbl* dx = (gdbl*)dx_;
+  gdbl* out = (gdbl*)out_;
   // il: interleaved unknown ordering (swp_perm); bwt: sub-diagonal tiles of the band (NT - 1: dense)
   extern __shared__ double sws[];
   const int NT = np / 16;
   double* Xp = sws;                       // NT panel tiles, k-major padded: Xp[T*SWS_TILE + k*SWS_TP + i] = X_T[i][k]
-  double* Wk = Xp + (size_t)NT * SWS_TILE;  // W^T of the current block, k-major: Wk[k*SWS_TP + j] = W[j][k]
+  double* Wk = Xp + (size_t)max(NT * SWS_TILE, 8 * 256);  // W^T of the current block, k-major: Wk[k*SWS_TP + j] = W[j][k] (band version: W row-major; its X ring takes 8 x 256 doubles of Xp)
   double* yv = Wk + SWS_TILE;             // np: right-hand side -> forward-substituted -> solution
   double* red = yv + np;                  // 16 partial sums
   __shared__ int bad;
@@ -754,7 +930,7 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
   const int crow = lane >> 4, ccol = lane & 15;
   for (int i = tid; i < np; i += 512) yv[i] = 0.0;
   __syncthreads();
-  for (int i = tid; i < n; i += 512) yv[swp_perm(n, il, i)] = -g[i];     // M was prepared by swp_damp_kernel
+  for (int i = tid; i < n; i += 512) yv[swp_perm(n, il, i)] = -g[i];     // (wide bands: M was prepared by swp_damp_kernel)
   if (tid == 0) bad = 0;
   __syncthreads();
   // Diagonal tile K: Cholesky + inverse (wave 0), W^T into LDS for the TRSM, z_K = W y_K.  `a` = the updated tile.
@@ -775,9 +951,10 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
       for (int q = 0; q < 4; q++) yv[16 * K + crow + 4 * q] = z[q];
     }
   };
-  if (wave == 0) factor_diag(0, *reinterpret_cast<const v4d*>(M + 4 * lane));
+  if (bwt <= 7) swp_factor_band8(n, np, il, A_, radius, M_, Winv_, Xp, Wk, yv, &bad);   // (wave-uniform: the whole workgroup takes one path)
+  if (bwt > 7 && wave == 0) factor_diag(0, *reinterpret_cast<const gv4d*>(M + 4 * lane));
   __syncthreads();
-  for (int K = 0; K < NT; K++) {
+  for (int K = 0; K < (bwt > 7 ? NT : 0); K++) {
     // TRSM: X_I = A_IK W^T, and the forward substitution of block row I: y_I -= X_I z_K
     const double zk = yv[16 * K + ccol];
     constexpr int TU = 4;   // tiles of this wave in flight (NT <= 32)
@@ -802,7 +979,7 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
         x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][2], bv[2], x, 0, 0, 0);
         x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][3], bv[3], x2, 0, 0, 0);
         x += x2;
-        *reinterpret_cast<v4d*>(M + ((size_t)I * NT + K) * 256 + 4 * lane) = x;
+        *reinterpret_cast<gv4d*>(M + ((size_t)I * NT + K) * 256 + 4 * lane) = x;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           Xp[(size_t)I * SWS_TILE + ccol * SWS_TP + crow + 4 * q] = x[q];
@@ -820,7 +997,7 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
     if (wave == 0) {
       if (ntr > 0) {
         const int I = K + 1;
-        v4d acc = *reinterpret_cast<const v4d*>(M + ((size_t)I * NT + I) * 256 + 4 * lane);
+        v4d acc = *reinterpret_cast<const gv4d*>(M + ((size_t)I * NT + I) * 256 + 4 * lane);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
           const double xv = Xp[(size_t)I * SWS_TILE + (4 * kk + crow) * SWS_TP + ccol];
@@ -845,7 +1022,7 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
               const int J = min(J0 + u, I);
-              acc[u] = *reinterpret_cast<const v4d*>(M + ((size_t)I * NT + J) * 256 + 4 * lane);
+              acc[u] = *reinterpret_cast<const gv4d*>(M + ((size_t)I * NT + J) * 256 + 4 * lane);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
@@ -858,7 +1035,7 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
             }
 #pragma unroll
             for (int u = 0; u < UNR; u++)
-              if (J0 + u <= I) *reinterpret_cast<v4d*>(M + ((size_t)I * NT + J0 + u) * 256 + 4 * lane) = acc[u];
+              if (J0 + u <= I) *reinterpret_cast<gv4d*>(M + ((size_t)I * NT + J0 + u) * 256 + 4 * lane) = acc[u];
           }
         }
       }
@@ -905,6 +1082,37 @@ __device__ __forceinline__ void swp_solve_body(int n, int np, int il, int bwt, c
   for (int i = tid; i < n; i += 512) dx[i] = yv[swp_perm(n, il, i)];
   // ---- model decrease -(dx.g + 1/2 dx^T A dx): a wave per row, lanes across the columns --------------------------
   double part = 0.0;
+  if (gnv > 0) {
+    // two-coordinate grid problem (Schwarp): row a only holds the 7 x 7 neighbourhood of its control point in both coordinate blocks.  One
+    // THREAD per row (n <= 512): its 2 x 49 loads are independent and go out together (a wave per row and four rows in flight spent 46 us on
+    // thirteen dependent round trips); products added in neighbourhood order, x block then y block.
+    const int N = n / 2, gnu = N / gnv;
+    const int a = tid;
+    if (a < n) {
+      const int l1 = a < N ? a : a - N;
+      const int iu1 = l1 / gnv, iv1 = l1 % gnv;
+      const gdbl* row = A + (size_t)a * n;
+      double t = 0.0;
+#pragma unroll 1
+      for (int blk = 0; blk < 2; blk++) {
+        double av[49];
+#pragma unroll
+        for (int e = 0; e < 49; e++) {
+          const int iu2 = iu1 + e / 7 - 3, iv2 = iv1 + e % 7 - 3;
+          const bool in = iu2 >= 0 && iu2 < gnu && iv2 >= 0 && iv2 < gnv;
+          av[e] = in ? row[blk * N + iu2 * gnv + iv2] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 49; e++) {
+          const int iu2 = iu1 + e / 7 - 3, iv2 = iv1 + e % 7 - 3;
+          const bool in = iu2 >= 0 && iu2 < gnu && iv2 >= 0 && iv2 < gnv;
+          if (in) t = fma(av[e], yv[swp_perm(n, il, blk * N + iu2 * gnv + iv2)], t);
+        }
+      }
+      part = yv[swp_perm(n, il, a)] * (g[a] + 0.5 * t);
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+  } else
   for (int a0 = 4 * wave; a0 < n; a0 += 32) {   // four rows per wave in flight
     double t[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b2 = lane; b2 < n; b2 += 64) {
@@ -1344,13 +1552,13 @@ __global__ __launch_bounds__(256) void swpb_rescale_kernel(const SwpFit* fits, i
 }
 __global__ __launch_bounds__(256) void swpb_damp_kernel(const SwpFit* fits, int stage) {
   const SwpFit& f = fits[blockIdx.z];
-  if (!swp_on(f, stage) || (int)blockIdx.y >= f.np) return;
+  if (!swp_on(f, stage) || (int)blockIdx.y >= f.np || f.bwt <= 7) return;   // (the band solver reads A itself)
   swp_damp_body(f.n2, f.np, f.il, f.A, f.radius, f.M);
 }
 __global__ __launch_bounds__(512) void swpb_solve_kernel(const SwpFit* fits, int stage) {
   const SwpFit& f = fits[blockIdx.y];
   if (!swp_on(f, stage)) return;
-  swp_solve_body(f.n2, f.np, f.il, f.bwt, f.A, f.g, f.radius, f.M, f.W, f.dx, f.scal + 2);
+  swp_solve_body(f.n2, f.np, f.il, f.bwt, f.A, f.g, f.radius, f.M, f.W, f.dx, f.scal + 2, f.il ? f.p.nv : 0);
 }
 __global__ __launch_bounds__(256) void swpb_step_kernel(const SwpFit* fits, int stage) {
   const SwpFit& f = fits[blockIdx.y];
@@ -1381,7 +1589,7 @@ __global__ void wib_bend_kernel(const SwpFit* fits) {
 }
 __global__ __launch_bounds__(256) void wib_damp_kernel(const SwpFit* fits) {
   const SwpFit& f = fits[blockIdx.z];
-  if (!f.bend || (int)blockIdx.y >= f.npi) return;
+  if (!f.bend || (int)blockIdx.y >= f.npi || f.bwti <= 7) return;
   swp_damp_body(f.p.N, f.npi, 0, f.A, 1e300, f.M);
 }
 __global__ __launch_bounds__(512) void wib_solve_kernel(const SwpFit* fits) {
@@ -1544,13 +1752,13 @@ extern "C" hipError_t nrsfm_swp_solve(int n2, const double* A, const double* g, 
                                       int kd, hipStream_t st) {
   const int np = nrsfm_swp_solve_np(n2), NT = np / 16;
   const int bwt = min(NT - 1, (max(kd, 0) + 15) / 16);
-  const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + np + 16);
+  const size_t lds = sizeof(double) * ((size_t)max(NT * SWS_TILE, 8 * 256) + SWS_TILE + np + 16);
   if (lds > 150 * 1024 || np > 512) return hipErrorInvalidValue;   // one thread per unknown in the backward substitution
   {   // the attribute is per device: set every time (microseconds) rather than cached per process
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swp_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(swp_damp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, n2, np, interleave, A, radius, M);
+  if (bwt > 7) hipLaunchKernelGGL(swp_damp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, st, n2, np, interleave, A, radius, M);   // (the band solver reads A itself)
   hipLaunchKernelGGL(swp_solve_kernel, dim3(1), dim3(512), lds, st, n2, np, interleave, bwt, A, g, radius, M, Winv, dx, out);
   return hipGetLastError();
 }
@@ -1603,7 +1811,7 @@ extern "C" size_t nrsfm_swp_compact_bytes(int P, int nu, int nv) {
 extern "C" hipError_t nrsfm_swp_fit_batch(void* d_fits_v, int B, int maxP, int maxN, int max_iters, int with_init, hipStream_t st) {
   SwpFit* fits = static_cast<SwpFit*>(d_fits_v);
   const int maxn2 = 2 * maxN, maxnp = nrsfm_swp_solve_np(maxn2), NT = maxnp / 16;
-  const size_t lds = sizeof(double) * ((size_t)(NT + 1) * SWS_TILE + maxnp + 16);
+  const size_t lds = sizeof(double) * ((size_t)max(NT * SWS_TILE, 8 * 256) + SWS_TILE + maxnp + 16);
   if (lds > 150 * 1024 || maxnp > 512) return hipErrorInvalidValue;
   {   // the attribute is per device: set every time (microseconds) rather than cached per process
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(swpb_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

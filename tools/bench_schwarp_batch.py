@@ -7,7 +7,11 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from defslam_amd import nrsfm, sft, synth
+from defslam_amd import _lib, nrsfm, sft, synth
+
+_ab = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ab", os.environ.get("AB_LIB", "") + ".so")
+if os.environ.get("AB_LIB") and os.path.exists(_ab):
+    _lib.LIB_PATH = _ab   # an A/B build (tools/ab_build.sh)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
