@@ -137,7 +137,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 1; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -513,7 +513,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   for (int b = 0; b < B; b++) {
     SftDev& hh = c->packed[b].h;
     // A narrow band (kd <= 128) that is long enough for two parts also takes the two-sided factorisation in latency mode: it runs on the
-    // left-looking wide-tile code (tile mode 2 works for any half-bandwidth up to 256), two workgroups per damping trial instead of one.
+    // left-looking wide-tile code (tile mode 2 works for any half-bandwidth up to 256), two workgroups per damping trial instead of one
+    // (C2: 4.1 ms per frame against 4.5 on the register-window solver -- the default since the SOLVE launch split the back substitutions).
     if ((c->force_split && hh.tile_mode == 1) || (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS))) {
       hh.tile_mode = 2;
       hh.wbt = (hh.kd + kTS - 1) / kTS;

@@ -25,10 +25,11 @@ extern "C" {
  *   "wide_off" 1 = half-bandwidths 128 < kd <= 256 use the row-major band solver instead of the wide tile solver
  *   "speculate"  0 = automatic, 1 = off (the one-workgroup persistent kernel), 2..4 = that many workgroups per problem try
  *                consecutive dampings of an iteration side by side (latency mode; results are bit-identical either way)
- *   "split"    1 = in latency mode a wide-band problem (128 < kd <= 256) is factored from both ends by two workgroups with a
- *              separator of one bandwidth in between (default), 0 = one factorisation of the whole band (same Cholesky in another
- *              elimination order: trajectories agree, numbers to rounding), 2 = narrower bands take the two-sided wide-tile path as
- *              well (measured slower than their register-window solver: C2 4.67 vs 4.49 ms per frame) */
+ *   "split"    2 (default) = in latency mode every band that is long enough (at least eight times its bandwidth) is factored from both
+ *              ends by two workgroups with a separator of one bandwidth in between; a narrow band (kd <= 128) then runs on the
+ *              left-looking wide-tile code as well (C2: 4.1 ms per frame against 4.5 on the register-window solver of one workgroup),
+ *              1 = wide bands (128 < kd <= 256) only, 0 = one factorisation of the whole band (the same Cholesky in another
+ *              elimination order: trajectories agree, numbers to rounding) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
 /* How problem b of the uploaded batch is solved: out[8] = {two-sided factorisation on?, first separator scalar c0, separator
  * scalars s, scalars of part 1 incl. padding, its padding, workgroups (lanes) per problem, tile mode, wavefronts per workgroup}. */

@@ -22,5 +22,5 @@ for cfg in cfgs:
         it, tr = ctx.batch_counts()
         info = ctx.solver_info(0)
         print(f"{cfg} split={split}: {ms:.3f} ms per frame, {it} iterations, {tr} trials, {it / ms * 1e3:.0f} it/s, tile_mode {info['tile_mode']}, two-sided {info['split']}, lanes {info['lanes']}")
-ctx.set_option("split", 1)
+ctx.set_option("split", 2)
 ctx.close()
