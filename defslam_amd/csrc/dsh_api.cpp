@@ -515,7 +515,11 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     // A narrow band (kd <= 128) that is long enough for two parts also takes the two-sided factorisation in latency mode: it runs on the
     // left-looking wide-tile code (tile mode 2 works for any half-bandwidth up to 256), two workgroups per damping trial instead of one
     // (C2: 4.1 ms per frame against 4.5 on the register-window solver -- the default since the SOLVE launch split the back substitutions).
-    if ((c->force_split && hh.tile_mode == 1) || (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS))) {
+    // Only while the launch is small: measured on C2, 4 lanes (tools/latency_batch_ab.py), the two-sided path wins up to 12 problems per launch
+    // (4.09 against 4.49 ms for one, 5.97 against 6.15 for twelve) and loses from 16 on (6.31 against 6.18; 48 problems: 11.0 against 7.4) --
+    // a wide band gains at every size (C5: 33 against 62 ms for one problem, 89 against 116 for 64).
+    if ((c->force_split && hh.tile_mode == 1) ||
+        (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && 20 * B <= c->num_cus && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS))) {
       hh.tile_mode = 2;
       hh.wbt = (hh.kd + kTS - 1) / kTS;
       hh.tpr = hh.wbt + 1;

@@ -27,7 +27,8 @@ extern "C" {
  *                consecutive dampings of an iteration side by side (latency mode; results are bit-identical either way)
  *   "split"    2 (default) = in latency mode every band that is long enough (at least eight times its bandwidth) is factored from both
  *              ends by two workgroups with a separator of one bandwidth in between; a narrow band (kd <= 128) then runs on the
- *              left-looking wide-tile code as well (C2: 4.1 ms per frame against 4.5 on the register-window solver of one workgroup),
+ *              left-looking wide-tile code as well (C2: 4.1 ms per frame against 4.5 on the register-window solver of one workgroup)
+ *              while the launch holds at most num_cus / 20 problems (beyond that the register-window solver wins),
  *              1 = wide bands (128 < kd <= 256) only, 0 = one factorisation of the whole band (the same Cholesky in another
  *              elimination order: trajectories agree, numbers to rounding) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
