@@ -1,10 +1,11 @@
 // CI driver of integration/schwarp_database_hip.h: keyframes and map points from a text file, SchwarpDatabaseHIP::add for every
 // keyframe in turn, ObtainK1K2HIP, and a dump of everything the reference's calls would have changed.
-//   usage: mapping_shim_test <input.txt> <output.txt> [device]
+//   usage: mapping_shim_test <input.txt> <output.txt> [device] [devrec]     (devrec: the DiffProp records stay in HBM, dsh_diffdb)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
+#include <string>
 
 #include "schwarp_database_hip.h"
 #include "standin_mapping_types.h"
@@ -45,6 +46,8 @@ int main(int argc, char** argv) {
   dsh_ctx* ctx = nullptr;
   if (dsh_create(&ctx, argc > 3 ? std::atoi(argv[3]) : 0) != DSH_OK) return 3;
   DB db(ctx, lambda);
+  const bool devrec = argc > 4 && std::string(argv[4]) == "devrec";
+  if (devrec && !db.enable_device_records(1 << 16)) { std::fprintf(stderr, "dsh_diffdb_create failed: %s\n", dsh_last_error(ctx)); return 5; }
   for (auto& kf : kfs) {
     db.add(kf.get());
     if (db.last_status() != DSH_OK) { std::fprintf(stderr, "add failed: %s\n", dsh_last_error(ctx)); return 4; }
@@ -54,7 +57,8 @@ int main(int argc, char** argv) {
   // the DiffProp database, per map point id
   size_t nrec = 0;
   for (auto& pr : db.getDiffDatabase()) nrec += pr.second.size();
-  out << nrec << "\n";
+  if (devrec) { out << dsh_diffdb_count(db.device_records()) << " " << nrec << "\n"; }   // (records on the device, records on the host: 0)
+  else out << nrec << "\n";
   for (int p = 0; p < P; p++) {
     auto it = db.getDiffDatabase().find(mps[p].get());
     if (it == db.getDiffDatabase().end()) continue;
@@ -72,7 +76,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < kfs[k]->N; i++) out << " " << (kfs[k]->mvpMapPoints[i] ? kfs[k]->mvpMapPoints[i]->id : -1);
     out << "\n";
   }
-  const int solved = defslam_hip::ObtainK1K2HIP<DB, KeyFrame, KeyFrame, MapPointM>(ctx, &db);
+  const int solved = devrec ? defslam_hip::ObtainK1K2DeviceHIP<DB, KeyFrame, KeyFrame, MapPointM>(ctx, &db)
+                            : defslam_hip::ObtainK1K2HIP<DB, KeyFrame, KeyFrame, MapPointM>(ctx, &db);
   out << solved << "\n";
   for (int k = 0; k < nKF; k++) {
     out << kfs[k]->surface->writes << "\n";

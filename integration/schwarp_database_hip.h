@@ -7,6 +7,9 @@
 //        numeric step on the GPU (dsh_warp_initialize, dsh_schwarp_eval, dsh_search_by_schwarp, dsh_schwarp_fit), the object
 //        bookkeeping (map point observations, the DiffProp database) exactly where the reference does it.
 //   ObtainK1K2HIP(ctx, warpDB)                 drop-in for NormalEstimator(warpDB).ObtainK1K2() (NormalEstimator.cc:38-229).
+//   enable_device_records(capacity) + ObtainK1K2DeviceHIP(ctx, warpDB): the same two steps with the DiffProp records resident in HBM
+//        (dsh_diffdb): the fit appends them on the device, the normal solve groups them there -- mapPointsDB_ stays empty, only key
+//        points go up and normals come down.
 //
 // Templates over the reference's own classes (members cited at each use); the repository's CI instantiates them with the stand-ins
 // of integration/standin_mapping_types.h.
@@ -61,8 +64,19 @@ class SchwarpDatabaseHIP : public Base {
     mpkeyframes.insert(mpCurrentKeyFrame);
   }
   void erase(KeyFrameT* kf) override { mpkeyframes.erase(kf); }
-  void clear() override { mpkeyframes.clear(); }
+  void clear() override {
+    mpkeyframes.clear();
+    if (devdb_) { dsh_diffdb_clear(devdb_); point_id_.clear(); points_.clear(); tag_kf_.clear(); }
+  }
   int last_status() const { return status_; }
+  ~SchwarpDatabaseHIP() { if (devdb_) dsh_diffdb_destroy(devdb_); }
+
+  // Device-resident records (include/defslam_hip.h: dsh_diffdb): from now on calculateSchwarps leaves the DiffProp records in HBM.
+  bool enable_device_records(int64_t capacity_records) { return devdb_ || dsh_diffdb_create(ctx_, capacity_records, &devdb_) == DSH_OK; }
+  dsh_diffdb* device_records() const { return devdb_; }
+  const std::vector<MapPointT*>& device_points() const { return points_; }       // map point of a point id
+  const std::vector<KeyFrameT*>& device_tags() const { return tag_kf_; }         // second keyframe of a record tag
+  int32_t device_point_id(MapPointT* mp) const { auto it = point_id_.find(mp); return it == point_id_.end() ? -1 : it->second; }
 
  protected:
   static dsh_bbs bbs_of(DefKeyFrameT* KF, int valdim) { return dsh_bbs{KF->umin, KF->umax, KF->NCu, KF->vmin, KF->vmax, KF->NCv, valdim}; }
@@ -171,6 +185,35 @@ class SchwarpDatabaseHIP : public Base {
     int32_t info[2];
     double costs[2];
     // the reference hands (fy, fx) to Warp's (fx, fy) slots (:199-201); 3 LM iterations (:213)
+    if (devdb_) {
+      // which matches the reference would store (:268-297, the drop test aside -- the library applies it): both map points alive and the
+      // point anchored in the estimated keyframe; their records go into the device database under the point's id
+      std::vector<int32_t> pid(P, -1), i2(P);
+      for (int ikp = 0; ikp < P; ikp++) {
+        i2[ikp] = (int32_t)vMatchedIndices[ikp].second;
+        MapPointT* mapPoint = KF->GetMapPoint(vMatchedIndices[ikp].first);
+        MapPointT* mapPoint2 = KF2->GetMapPoint(vMatchedIndices[ikp].second);
+        if (!mapPoint || !mapPoint2 || mapPoint->isBad() || mapPoint2->isBad() || mapPoint->GetReferenceKeyFrame() != KFi) continue;
+        auto it = point_id_.find(mapPoint);
+        if (it == point_id_.end()) { it = point_id_.emplace(mapPoint, (int32_t)points_.size()).first; points_.push_back(mapPoint); }
+        pid[ikp] = it->second;
+      }
+      dsh_schwarp_problem q{};
+      q.bbs = bbs; q.P = P; q.kp1 = k1.data(); q.kp2 = k2.data(); q.invsig = isg.data(); q.fx_slot = (double)KF->fy; q.fy_slot = (double)KF->fx;
+      q.lambda = lambda; q.fx = KF->fx; q.fy = KF->fy; q.max_iters = 3; q.x = x.data(); q.diff = nullptr; q.drop = drop.data();
+      const dsh_schwarp_store st{pid.data(), i2.data(), (int32_t)tag_kf_.size()};
+      tag_kf_.push_back(KF2i);
+      status_ = dsh_schwarp_fit_batch_store(ctx_, 1, &q, &st, devdb_);
+      if (status_ != DSH_OK) return;
+      for (int ikp = 0; ikp < P; ikp++) {
+        MapPointT* mapPoint = KF->GetMapPoint(vMatchedIndices[ikp].first);
+        MapPointT* mapPoint2 = KF2->GetMapPoint(vMatchedIndices[ikp].second);
+        if (!mapPoint || !mapPoint2 || mapPoint->isBad() || mapPoint2->isBad()) continue;
+        if (drop[ikp]) { mapPoint2->EraseObservation(KF2); KF2->EraseMapPointMatch(vMatchedIndices[ikp].second); continue; }
+        if (pid[ikp] >= 0) this->newInformation_[mapPoint] = true;
+      }
+      return;
+    }
     status_ = dsh_schwarp_fit(ctx_, &bbs, P, k1.data(), k2.data(), isg.data(), (double)KF->fy, (double)KF->fx, lambda, KF->fx, KF->fy, 3, x.data(), dp.data(),
                               drop.data(), info, costs);
     if (status_ != DSH_OK) return;
@@ -203,6 +246,10 @@ class SchwarpDatabaseHIP : public Base {
   double lambda_;
   std::set<KeyFrameT*> mpkeyframes;
   int status_ = DSH_OK;
+  dsh_diffdb* devdb_ = nullptr;
+  std::unordered_map<MapPointT*, int32_t> point_id_;
+  std::vector<MapPointT*> points_;
+  std::vector<KeyFrameT*> tag_kf_;
 };
 
 // NormalEstimator::ObtainK1K2 (NormalEstimator.cc:38-229) over the warp database: the points with new information, their DiffProp
@@ -269,6 +316,58 @@ int ObtainK1K2HIP(dsh_ctx* ctx, WarpDBT* warpDB) {
     for (int r = rec_ptr[p]; r < rec_ptr[p + 1]; r++)
       if (wr[r]) static_cast<DefKeyFrameT*>(flat[r]->KFToKF.second)->surface->setNormalSurfacePoint(flat[r]->idx2, &nrec[3 * (size_t)r]);
   }
+  return solved;
+}
+
+// The same over the device-resident records (SchwarpDatabaseHIP::enable_device_records): key points in, normals out.  Every stored record
+// is anchored in its point's reference keyframe (the fit stores no other), so there are no first-keyframe normals to look up; a point whose
+// reference keyframe changed after its records were stored is outside this mode.
+template <class WarpDBT, class KeyFrameT, class DefKeyFrameT, class MapPointT>
+int ObtainK1K2DeviceHIP(dsh_ctx* ctx, WarpDBT* warpDB) {
+  auto& toProcess = warpDB->getToProccess();
+  std::vector<int32_t> ids;
+  std::vector<uint8_t> has_x0;
+  std::vector<float> x0, ref_uv;
+  std::vector<MapPointT*> pts;
+  for (auto& pr : toProcess) {
+    if (!pr.second) continue;
+    pr.second = false;
+    MapPointT* mp = pr.first;
+    if (!mp || mp->isBad()) continue;
+    const int32_t id = warpDB->device_point_id(mp);
+    if (id < 0) continue;
+    KeyFrameT* refKF = mp->GetReferenceKeyFrame();
+    const size_t idx = mp->GetIndexInKeyFrame(refKF);
+    float Ni[3] = {0, 0, 0};
+    const bool h = static_cast<DefKeyFrameT*>(refKF)->surface->getNormalSurfacePoint(idx, Ni);
+    ids.push_back(id); pts.push_back(mp);
+    has_x0.push_back(h);
+    x0.push_back(h ? Ni[0] : 0.f); x0.push_back(h ? Ni[1] : 0.f);
+    const auto& kpn = static_cast<DefKeyFrameT*>(refKF)->mpKeypointNorm[idx].pt;
+    ref_uv.push_back(kpn.x); ref_uv.push_back(kpn.y);
+  }
+  const int P = (int)pts.size();
+  if (P == 0) return 0;
+  const int32_t max_rec = (int32_t)dsh_diffdb_count(warpDB->device_records());
+  std::vector<double> k(2 * (size_t)P), cov(4 * (size_t)P);
+  std::vector<int32_t> st(P), rp(max_rec), rt(max_rec), ri(max_rec);
+  std::vector<float> nref(3 * (size_t)P), nrec(3 * (size_t)max_rec);
+  std::vector<uint8_t> wr(max_rec);
+  int32_t n_rec = 0;
+  if (dsh_normals_estimate_db(ctx, warpDB->device_records(), P, ids.data(), x0.data(), has_x0.data(), ref_uv.data(), k.data(), cov.data(), st.data(), nref.data(),
+                              nullptr, max_rec, &n_rec, rp.data(), rt.data(), ri.data(), nrec.data(), wr.data()) != DSH_OK)
+    return -1;
+  int solved = 0;
+  for (int p = 0; p < P; p++) {
+    if (st[p] != 0) continue;
+    solved++;
+    MapPointT* mp = pts[p];
+    KeyFrameT* refKF = mp->GetReferenceKeyFrame();
+    for (int c4 = 0; c4 < 4; c4++) mp->covNorm[c4] = cov[4 * (size_t)p + c4];
+    static_cast<DefKeyFrameT*>(refKF)->surface->setNormalSurfacePoint(mp->GetIndexInKeyFrame(refKF), &nref[3 * (size_t)p]);
+  }
+  for (int r = 0; r < n_rec; r++)
+    if (wr[r]) static_cast<DefKeyFrameT*>(warpDB->device_tags()[rt[r]])->surface->setNormalSurfacePoint(ri[r], &nrec[3 * (size_t)r]);
   return solved;
 }
 

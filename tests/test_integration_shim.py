@@ -300,3 +300,11 @@ def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow
         sel = (allrec[:, 1] == k) & (ng.rec_written == 1)
         assert wk == int(sel.sum())
         np.testing.assert_allclose(sk[allrec[sel, 3].astype(int), 1:], ng.normal_rec[sel], rtol=2e-7)
+    # ---- the same run with the DiffProp records resident in HBM (SchwarpDatabaseHIP::enable_device_records + ObtainK1K2DeviceHIP: dsh_diffdb,
+    # dsh_schwarp_fit_batch_store, dsh_normals_estimate_db): no record on the host, and everything the calls change comes out the same
+    r2 = subprocess.run([exe, str(tmp_path / "in.txt"), str(tmp_path / "out_dev.txt"), "0", "devrec"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    host_lines = open(tmp_path / "out.txt").read().split("\n")
+    dev_lines = open(tmp_path / "out_dev.txt").read().split("\n")
+    assert dev_lines[0].split() == [str(nrec), "0"]                # as many records on the device as the host map held; none on the host
+    assert dev_lines[1:] == host_lines[1 + nrec:]                  # bookkeeping, normals written into the surfaces, covariances, pending flags
