@@ -167,4 +167,16 @@ def test_database_capacity_and_argument_errors(gpu_ctx):
     assert r.k1k2.shape == (0, 2)
     with pytest.raises(DshError):
         nrsfm.DiffDatabase(gpu_ctx, 0)
+    # a database belongs to the context that created it
+    from defslam_amd import sft
+    other = sft.Context(0)
+    try:
+        with pytest.raises(DshError, match="bad argument"):
+            nrsfm.ObtainK1K2Database(other, small, np.arange(3, dtype=np.int32), np.zeros((3, 2)), np.zeros(3), np.zeros((3, 2)))
+        with pytest.raises(DshError, match="another context"):
+            nrsfm.calculateSchwarpsBatch(other, probs, db=small)
+    finally:
+        other.close()
+    small.append(np.zeros((0, 18), np.float32), np.zeros(0, np.int32))      # nothing to append is fine
+    assert len(small) == 5
     small.close()
