@@ -578,16 +578,43 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
     }
     return h;
   };
+  // First chunk of the two lists of the lane's diagonal block (8 lanes per node: 2 observations and 3 curvature / stretch contributions per
+  // lane).  Fetched ONE ROUND AHEAD as well, from the header that came a round ahead of that: a round then starts with the loads of its
+  // records instead of with the loads of the list entries that say which records -- one dependent round trip per round instead of two.
+  constexpr int DCH = 2, HCH = 3;   // per lane and round trip: 8 lanes x 2 = 16 observations, 8 x 3 = 24 curvature / stretch contributions
+  struct DL { int mm[DCH]; double bb[DCH]; uint32_t rc[HCH]; double c0[HCH], c1[HCH]; };
+  auto load_dlists = [&](const Hdr& h) -> DL {
+    DL l;
+    const int sub = lane & 7;
+#pragma unroll
+    for (int i = 0; i < DCH; i++) {
+      const int p = h.dob0 + sub + 8 * i;
+      const bool in = p < h.dob1;
+      l.mm[i] = in ? P.ob_m[p] : 0;
+      l.bb[i] = in ? P.ob_c[p] : 0.0;      // a zero coefficient switches a padding entry off
+    }
+#pragma unroll
+    for (int i = 0; i < HCH; i++) {
+      const int p = h.dsh0 + sub + 8 * i;
+      const bool in = p < h.dsh1;
+      l.rc[i] = in ? P.sh_rec[p] : 0xFFFFFFFFu;
+      l.c0[i] = in ? P.sh_cf[2 * p] : 0.0;
+      l.c1[i] = in ? P.sh_cf[2 * p + 1] : 0.0;
+    }
+    return l;
+  };
   // (part, nparts): this workgroup takes every nparts-th round of its wavefronts -- the latency mode splits one assembly over the
   // workgroups of a problem, which all write into the same H (sft_spec_kernel); 0, 1 = everything
   const int I0 = wave + NW * part, dI = NW * nparts;
   Hdr nxt = load_hdr(I0);
+  DL nl = load_dlists(nxt);
 
 #pragma unroll 1
   for (int I = I0; I < ngroups; I += dI) {
     int a_lo, a_hi;
     group_nodes(I, a_lo, a_hi);
     Hdr cur = nxt;
+    const DL cl = nl;
     nxt = load_hdr(I + dI);
     // element (r, c), c <= r, of H in the band / wide-tile layouts (and its mirror inside a diagonal tile, which is stored symmetric)
     auto put = [&](int r, int c, double v) {
@@ -649,7 +676,6 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       }
       if (on) {
         const int ob0 = cur.dob0, ob1 = cur.dob1, sh0 = cur.dsh0, sh1 = cur.dsh1;
-        constexpr int DCH = 2, HCH = 3;   // per lane and round trip: 8 lanes x 2 = 16 observations, 8 x 3 = 24 curvature / stretch contributions
         auto add_obs = [&](const double (&rr)[14], double b) {
           const double om = rr[0] * b;
           sii += om * b;
@@ -666,26 +692,8 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
           Hs[3] += f * (u2 * u0); Hs[4] += f * (u2 * u1); Hs[5] += f * (u2 * u2);
           bn[0] -= g * u0; bn[1] -= g * u1; bn[2] -= g * u2;
         };
-        // first chunk of BOTH lists in one round trip, their records in the next; the sums stay in list order per lane
-        int mm[DCH];
-        double bb[DCH];
-        uint32_t rc[HCH];
-        double c0[HCH], c1[HCH];
-#pragma unroll
-        for (int i = 0; i < DCH; i++) {
-          const int p = ob0 + sub + 8 * i;
-          const bool in = p < ob1;
-          mm[i] = in ? P.ob_m[p] : 0;
-          bb[i] = in ? P.ob_c[p] : 0.0;      // a zero coefficient switches a padding entry off
-        }
-#pragma unroll
-        for (int i = 0; i < HCH; i++) {
-          const int p = sh0 + sub + 8 * i;
-          const bool in = p < sh1;
-          rc[i] = in ? P.sh_rec[p] : 0xFFFFFFFFu;
-          c0[i] = in ? P.sh_cf[2 * p] : 0.0;
-          c1[i] = in ? P.sh_cf[2 * p + 1] : 0.0;
-        }
+        // the first chunk of both lists came a round ahead (cl); their records now; the sums stay in list order per lane
+        const auto& mm = cl.mm; const auto& bb = cl.bb; const auto& rc = cl.rc; const auto& c0 = cl.c0; const auto& c1 = cl.c1;
         {
           double rr[DCH][14], r[HCH][4];
 #pragma unroll
@@ -751,6 +759,7 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       }
     }
     AS_ADD(34);
+    nl = load_dlists(nxt);   // the next round's list entries travel while this round's off-diagonal blocks are summed
     // ---- off-diagonal blocks of the block rows a_lo .. a_hi: one lane per block; the headers of the first 64 came a group ahead
     for (int q = cur.q; q < cur.qe; q += 64) {
       Hdr h = cur;
