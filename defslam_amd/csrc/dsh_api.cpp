@@ -357,6 +357,7 @@ int dsh_create(dsh_ctx** out, int device) {
 
 int dsh_destroy(dsh_ctx* c) {
   if (!c) return DSH_ERR_ARG;
+  ddb_detach_all(c);   // databases of this context stay valid objects (dsh_diffdb_destroy still frees them) but no longer name it
   if (c->host_only) { c->stage.release(); c->results.release(); delete c; return DSH_OK; }
   (void)hipSetDevice(c->device);
   drop_graphs(c);

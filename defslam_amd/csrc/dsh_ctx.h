@@ -69,7 +69,9 @@ struct dsh_ctx_base {
   bool host_only = false;   // device == -1: template + packer only (CPU tests of the host logic)
   hipStream_t stream = nullptr;
   std::string err;
+  std::vector<struct dsh_diffdb*> diffdbs;   // databases created on this context: dsh_destroy detaches them (dsh_diffdb.cpp: ddb_detach_all)
 };
+void ddb_detach_all(dsh_ctx_base* c);
 
 // error helper usable from every translation unit
 inline int dsh_fail(dsh_ctx_base* c, int code, const std::string& m) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ int dsh_diffdb_create(dsh_ctx* ctx, int64_t capacity, dsh_diffdb** out) {
   (void)hipSetDevice(c->device);
   dsh_diffdb* db = new dsh_diffdb();
   db->ctx = c;
+  db->device = c->device;
   db->cap = capacity;
   char* base = nullptr;
   const size_t bytes = (size_t)capacity * (72 + 12);
@@ -51,18 +53,60 @@ int dsh_diffdb_create(dsh_ctx* ctx, int64_t capacity, dsh_diffdb** out) {
   db->pid = reinterpret_cast<int32_t*>(base + (size_t)capacity * 72);
   db->tag = db->pid + capacity;
   db->idx2 = db->tag + capacity;
+  c->diffdbs.push_back(db);
   *out = db;
   return DSH_OK;
 }
 
+// Works in either order with dsh_destroy of the context: the database remembers its device, waits for the whole device (the context's
+// stream may be gone) and never dereferences a context that has been destroyed (dsh_destroy detaches its databases).
 int dsh_diffdb_destroy(dsh_diffdb* db) {
   if (!db) return DSH_ERR_ARG;
-  if (db->ctx) { (void)hipSetDevice(db->ctx->device); if (db->ctx->stream) (void)hipStreamSynchronize(db->ctx->stream); }
+  (void)hipSetDevice(db->device);
+  (void)hipDeviceSynchronize();
+  if (db->ctx) {
+    auto& v = db->ctx->diffdbs;
+    v.erase(std::remove(v.begin(), v.end(), db), v.end());
+  }
   if (db->rec) (void)hipFree(db->rec);
   if (db->last_normals) (void)hipFree(db->last_normals);
   delete db;
   return DSH_OK;
 }
+
+}  // extern "C"
+
+void ddb_detach_all(dsh_ctx_base* c) {
+  for (dsh_diffdb* db : c->diffdbs) db->ctx = nullptr;
+  c->diffdbs.clear();
+}
+
+int ddb_reserve(dsh_diffdb* db, long long need) {
+  if (need <= db->cap) return 0;
+  if (need > (1ll << 30)) return (int)hipErrorOutOfMemory;
+  const long long ncap = std::min<long long>(std::max(need, 2 * db->cap), 1ll << 30);
+  (void)hipSetDevice(db->device);
+  char* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, (size_t)ncap * (72 + 12));
+  if (e != hipSuccess) return (int)e;
+  float* rec = reinterpret_cast<float*>(base);
+  int32_t* pid = reinterpret_cast<int32_t*>(base + (size_t)ncap * 72);
+  int32_t *tag = pid + ncap, *idx2 = tag + ncap;
+  (void)hipDeviceSynchronize();   // nothing of this device may still read or write the old arrays
+  const size_t n = (size_t)db->count;
+  if (n) {
+    e = hipMemcpy(rec, db->rec, 72 * n, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pid, db->pid, 4 * n, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tag, db->tag, 4 * n, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(idx2, db->idx2, 4 * n, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(base); return (int)e; }
+  }
+  (void)hipFree(db->rec);
+  db->rec = rec; db->pid = pid; db->tag = tag; db->idx2 = idx2; db->cap = ncap;
+  return 0;
+}
+
+extern "C" {
 
 int dsh_diffdb_clear(dsh_diffdb* db) {
   if (!db) return DSH_ERR_ARG;
@@ -78,15 +122,16 @@ int dsh_diffdb_append(dsh_diffdb* db, int n, const dsh_diffprop* recs, const int
   if (!db || !db->ctx) return DSH_ERR_ARG;
   dsh_ctx_base* c = db->ctx;
   if (n < 0 || (n > 0 && (!recs || !point_id))) return dsh_fail(c, DSH_ERR_ARG, "dsh_diffdb_append: bad argument");
-  if (db->count + n > db->cap) return dsh_fail(c, DSH_ERR_STATE, "dsh_diffdb_append: the database is full");
   if (n == 0) return DSH_OK;
   (void)hipSetDevice(c->device);
+  if (ddb_reserve(db, db->count + n) != 0) return dsh_fail(c, DSH_ERR_HIP, "dsh_diffdb_append: out of device memory while growing the database");
   hipStream_t st = c->stream;
   std::vector<int32_t> fill;
+  const std::vector<int32_t> zeros(tag ? 0 : (size_t)n, 0);   // lives until the stream synchronisation below
   HIPCHK(c, hipMemcpyAsync(db->rec + 18 * (size_t)db->count, recs, 72 * (size_t)n, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(db->pid + db->count, point_id, 4 * (size_t)n, hipMemcpyHostToDevice, st));
   if (!tag || !idx2) { fill.assign(n, 0); if (!idx2) for (int i = 0; i < n; i++) fill[i] = i; }
-  HIPCHK(c, hipMemcpyAsync(db->tag + db->count, tag ? tag : std::vector<int32_t>(n, 0).data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(db->tag + db->count, tag ? tag : zeros.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(db->idx2 + db->count, idx2 ? idx2 : fill.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));
   for (int i = 0; i < n; i++) db->max_pid = std::max(db->max_pid, point_id[i]);
@@ -110,6 +155,7 @@ int dsh_normals_estimate_db(dsh_ctx* ctx, dsh_diffdb* db, int P, const int32_t* 
   hipStream_t st = c->stream;
   const long long n = db->count;
   const size_t nn = n > 0 ? (size_t)n : 1;
+  if (db->max_pid == INT32_MAX) return dsh_fail(c, DSH_ERR_ARG, "dsh_normals_estimate_db: point id 2^31 - 1 is not supported");
   const int nlook = std::max(db->max_pid + 1, 1);
   DevBuf d_ids, d_look, d_key, d_count, d_cursor, d_perm, d_owner, d_tmp, d_ptr, d_x0, d_hx0, d_uv;
   HIPCHK(c, d_ids.alloc(c, 4 * (size_t)P)); HIPCHK(c, d_look.alloc(c, 4 * (size_t)nlook)); HIPCHK(c, d_key.alloc(c, 4 * nn)); HIPCHK(c, d_count.alloc(c, 4 * (size_t)(P + 1)));

@@ -4,7 +4,8 @@
 
 struct dsh_ctx_base;
 struct dsh_diffdb {
-  dsh_ctx_base* ctx = nullptr;
+  dsh_ctx_base* ctx = nullptr;   // the owning context; set to null by dsh_destroy of that context (the database can then only be destroyed)
+  int device = 0;                // HIP device of the allocation: dsh_diffdb_destroy needs nothing else
   long long cap = 0, count = 0;
   int32_t max_pid = -1;          // largest point id stored so far (size of the lookup table of a grouping)
   float* rec = nullptr;          // cap x 18 float32: the DiffProp fields in the order of dsh_diffprop
@@ -14,3 +15,7 @@ struct dsh_diffdb {
   long long last_cap = 0;          // floats allocated
   int last_P = 0, last_R = 0;
 };
+
+// Room for `need` records in total: the database grows on demand (the reference's mapPointsDB_ is unbounded) -- a new allocation of at
+// least twice the capacity, the stored records copied device to device.  Returns a HIP error code (0 = ok).
+int ddb_reserve(dsh_diffdb* db, long long need);

@@ -135,6 +135,11 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
   if (c->host_only) return dsh_fail(c, DSH_ERR_NO_DEVICE, "dsh_schwarp_fit_batch: host-only context, no GPU (there is no CPU fallback)");
   if (B <= 0 || !probs) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch: bad argument");
   if (db && (db->ctx != c || !stores)) return dsh_fail(c, DSH_ERR_ARG, "dsh_schwarp_fit_batch_store: the database belongs to another context / no store descriptors");
+  if (db) {   // room for every record this call can add, BEFORE anything is launched: a call stores all of its records or fails untouched
+    long long worst = 0;
+    for (int b = 0; b < B; b++) worst += std::max(probs[b].P, 0);
+    if (ddb_reserve(db, db->count + worst) != 0) return dsh_fail(c, DSH_ERR_HIP, "dsh_schwarp_fit_batch_store: out of device memory while growing the database");
+  }
   int maxP = 0, maxN = 0, max_it = 0;
   for (int b = 0; b < B; b++) {
     const dsh_schwarp_problem& q = probs[b];
@@ -275,7 +280,7 @@ static int fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* probs, const dsh_
   }
   HIPCHK(c, hipStreamSynchronize(st));
   if (db) {
-    if (db->count + added > db->cap) { db->count = db->cap; return dsh_fail(c, DSH_ERR_STATE, "dsh_schwarp_fit_batch_store: the database is full (records beyond its capacity were not stored)"); }
+    if (db->count + added > db->cap) return dsh_fail(c, DSH_ERR_STATE, "dsh_schwarp_fit_batch_store: internal error, the reserved capacity was exceeded");
     db->count += added;
     db->max_pid = std::max(db->max_pid, max_pid);
   }

@@ -252,13 +252,18 @@ class Context:
         self._check(self._L.dsh_sft_batch_problem_info(self._h, b, C.byref(nbytes), _ptr(counts, C.c_int32)), "dsh_sft_batch_problem_info")
         return nbytes.value, counts
 
-    def batch_download(self) -> List[int]:
+    def batch_download(self, only=None) -> List[int]:
         """Write results back into the uploaded Frame objects (the reference's in-place mutations,
-        DefOptimizer.cc:515-576) and return the per-frame inlier counts."""
+        DefOptimizer.cc:515-576) and return the per-frame inlier counts.  `only`: ids whose arrays are wanted (the C call skips
+        output pointers that are null; counters and statistics come back for every problem)."""
         frames = self._frames
         res = (_lib.SftResultC * len(frames))()
         keep = []
+        want = None if only is None else set(int(i) for i in only)
         for i, f in enumerate(frames):
+            if want is not None and i not in want:
+                keep.append(None)
+                continue
             M, n = f.obs_nodes.shape[0], f.nodes_xyz.shape[0]
             bufs = dict(Tcw=np.zeros((4, 4), np.float32), pose7=np.zeros(7), xyz=np.zeros((n, 3)), chi2=np.zeros(M), outl=np.zeros(M, np.uint8),
                         mp=np.zeros((M, 3), np.float32), trace=np.zeros((max(self._max_iters, 1), _lib.DSH_TRACE_STRIDE)))
@@ -275,6 +280,10 @@ class Context:
         out = []
         for i, f in enumerate(frames):
             b, r = keep[i], res[i]
+            if b is None:
+                f.iters, f.trials, f.dim, f.half_bandwidth, f.status = r.iters, r.trials, r.dim, r.half_bandwidth, r.status
+                out.append(int(r.inliers))
+                continue
             f.Tcw = b["Tcw"]
             f.pose7 = b["pose7"]
             f.nodes_xyz = b["xyz"]

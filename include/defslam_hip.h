@@ -263,6 +263,10 @@ int dsh_schwarp_fit_batch(dsh_ctx* ctx, int B, dsh_schwarp_problem* problems);
  * travel to the host), dsh_normals_estimate_db groups the records of the requested points on the device (a point's records in their
  * insertion order, like the host vector) and solves -- key points in, normals out, no record crosses PCIe. */
 typedef struct dsh_diffdb dsh_diffdb;
+/* capacity_records is the initial capacity: like the reference's map the database grows on demand (appends and stores reserve their
+ * worst case first, so a call stores all of its records or fails without storing any).  Lifetime: a database belongs to the context it
+ * was created on; dsh_destroy of that context detaches it -- every call on it then returns DSH_ERR_ARG -- and dsh_diffdb_destroy works
+ * before or after dsh_destroy. */
 int dsh_diffdb_create(dsh_ctx* ctx, int64_t capacity_records, dsh_diffdb** out);
 int dsh_diffdb_destroy(dsh_diffdb* db);
 int dsh_diffdb_clear(dsh_diffdb* db);                 /* forget every record (WarpDatabase::clear) */

@@ -38,6 +38,22 @@ def lib() -> C.CDLL:
     return _LIB
 
 
+_LIB_FAST = None
+FAST_FLAGS = "-O3 -march=native (FMA contraction allowed)"
+
+
+def lib_fast() -> C.CDLL:
+    """The timing-only build of sft_oracle.c (oracle/Makefile: libdefslam_oracle_fast.so).  bench.py's cpu_baseline is its only user."""
+    global _LIB_FAST
+    if _LIB_FAST is None:
+        so = os.path.join(_HERE, "_build", "libdefslam_oracle_fast.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "_build/libdefslam_oracle_fast.so"], stdout=subprocess.DEVNULL)
+        _LIB_FAST = C.CDLL(so)
+        _LIB_FAST.sft_oracle_solve.restype = C.c_int
+    return _LIB_FAST
+
+
 def _p(a, t):
     if a is None:
         return None
@@ -120,8 +136,8 @@ class SftResult:
 
 
 def sft_solve(tc: TemplateConsts, Tcw, K, n_frame, obs_nodes, obs_bary, obs_uv, obs_invsig2, xyz,
-              reg_lap, reg_inex, reg_temp, layers=1, max_iters=50, ldlt_mode=0) -> SftResult:
-    L = lib()
+              reg_lap, reg_inex, reg_temp, layers=1, max_iters=50, ldlt_mode=0, fast=False) -> SftResult:
+    L = lib_fast() if fast else lib()   # fast: the timing build (never a parity reference)
     M = int(obs_nodes.shape[0])
     Tcw = np.ascontiguousarray(Tcw, dtype=np.float32)
     K = np.ascontiguousarray(K, dtype=np.float64)

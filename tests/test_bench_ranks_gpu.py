@@ -59,3 +59,54 @@ def test_dry_ranks_rehearses_the_n_rank_launch_on_the_devices_that_exist():
     assert d["config"]["dist_backend"] == ("nccl" if ndev >= 2 else "gloo")
     assert len(d["rank_ms_per_step"]) == 2 and all(v > 0 for v in d["rank_ms_per_step"])
     assert abs(max(d["rank_ms_per_step"]) - d["ms_per_step"]) < 0.25 * d["ms_per_step"]
+
+
+@pytest.mark.gpu
+def test_dry_ranks_8_is_the_eight_rank_launch_on_the_devices_that_exist():
+    """The launch the driver makes on an 8-GPU node, rehearsed: eight ranks, 64 problems each, one step.  One JSON line with eight per-rank
+    step times; on a one-GPU box all ranks share device 0 (gloo carries the barrier), n_gpus stays the number of distinct devices."""
+    import torch
+    ndev = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-ranks", "8", "--steps", "1", "--warmup", "1", "--batch", "64",
+                        "--no-cpu-baseline", "--no-extra-legs"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["ranks"] == 8 and d["config"]["dry_ranks"] is True and d["config"]["problems_per_gpu"] == 64
+    assert d["config"]["parallelism"] == "8 x independent problems (no collective)"
+    assert d["n_gpus"] == min(8, ndev)
+    assert len(d["rank_ms_per_step"]) == 8 and all(v > 0 for v in d["rank_ms_per_step"])
+    frames = d["frames_per_s"] * d["ms_per_step"] * 1e-3
+    assert abs(frames - 8 * 64) < 1e-6 * 512
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rank_plan_under_the_drivers_launcher_one_gpu_per_rank():
+    """`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`: rank r computes on device LOCAL_RANK, RCCL carries the barrier, the
+    line says "8 x independent problems"; a WORLD_SIZE that contradicts --gpus or a device that does not exist is refused."""
+    b = _bench_module()
+    for lr in range(8):
+        env = {"RANK": str(lr), "LOCAL_RANK": str(lr), "WORLD_SIZE": "8"}
+        p = b.rank_plan(8, 0, -1, "nccl", env, 8)
+        assert p["device"] == lr and p["rank"] == lr and p["world"] == 8
+        assert p["backend"] == "nccl" and p["ranks_per_device"] == 1
+        assert p["parallelism"] == "8 x independent problems (no collective)"
+    assert "error" in b.rank_plan(8, 0, -1, "nccl", {"RANK": "5", "LOCAL_RANK": "5", "WORLD_SIZE": "8"}, 4)      # device 5 of 4
+    assert "error" in b.rank_plan(4, 0, -1, "nccl", {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "8"}, 8)      # --gpus 4, eight ranks
+    # rehearsal on one device: every rank on device 0, gloo instead of RCCL (duplicate GPU in one communicator)
+    p = b.rank_plan(8, 8, -1, "nccl", {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8"}, 1)
+    assert p["device"] == 0 and p["ranks_per_device"] == 8 and p["backend"] == "gloo"
+    # rehearsal on a full node: the real backend
+    p = b.rank_plan(8, 8, -1, "nccl", {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8"}, 8)
+    assert p["device"] == 3 and p["ranks_per_device"] == 1 and p["backend"] == "nccl"
+    # single process
+    p = b.rank_plan(1, 0, -1, "nccl", {}, 1)
+    assert p["device"] == 0 and p["world"] == 1

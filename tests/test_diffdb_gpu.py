@@ -155,11 +155,24 @@ def test_database_capacity_and_argument_errors(gpu_ctx):
     from defslam_amd import nrsfm
     from defslam_amd.sft import DshError
     probs, _ = _pairs(2, 300, 9)
+    # a database grows on demand like the reference's map (WarpDatabase.h:61): a store that overflows the initial capacity keeps every
+    # record, in the same order as a database that was large from the start
     small = nrsfm.DiffDatabase(gpu_ctx, 20)
-    with pytest.raises(DshError, match="full"):
-        nrsfm.calculateSchwarpsBatch(gpu_ctx, probs, db=small)
-    with pytest.raises(DshError, match="full"):
-        small.append(np.zeros((30, 18), np.float32), np.zeros(30, np.int32))
+    big = nrsfm.DiffDatabase(gpu_ctx, 4096)
+    rs = nrsfm.calculateSchwarpsBatch(gpu_ctx, probs, db=small)
+    rb = nrsfm.calculateSchwarpsBatch(gpu_ctx, probs, db=big)
+    assert len(small) == len(big) > 20
+    for a, b in zip(rs, rb):
+        np.testing.assert_array_equal(a[2], b[2])      # drop flags
+    ids = np.unique(np.concatenate([q["point_id"] for q in probs]))
+    ids = ids[ids >= 0].astype(np.int32)
+    z2, z1 = np.zeros((ids.size, 2)), np.zeros(ids.size)
+    ns, nb = (nrsfm.ObtainK1K2Database(gpu_ctx, d, ids, z2, z1, z2) for d in (small, big))
+    np.testing.assert_array_equal(ns.k1k2, nb.k1k2)
+    np.testing.assert_array_equal(ns.rec_point, nb.rec_point)
+    np.testing.assert_array_equal(ns.rec_idx2, nb.rec_idx2)
+    big.close()
+    small.append(np.zeros((30, 18), np.float32), np.zeros(30, np.int32))      # a host append grows it as well
     small.clear()
     small.append(np.zeros((5, 18), np.float32), np.arange(5, dtype=np.int32))
     assert len(small) == 5
@@ -180,3 +193,21 @@ def test_database_capacity_and_argument_errors(gpu_ctx):
     small.append(np.zeros((0, 18), np.float32), np.zeros(0, np.int32))      # nothing to append is fine
     assert len(small) == 5
     small.close()
+
+
+def test_database_outlives_its_context_and_can_be_destroyed_in_either_order():
+    """dsh_destroy detaches the databases of the context: they stay valid objects (calls on them return an error instead of touching freed
+    memory) and dsh_diffdb_destroy works after the context is gone (Context.close() before DiffDatabase.__del__)."""
+    from defslam_amd import nrsfm, sft
+    from defslam_amd.sft import DshError
+    ctx = sft.Context(0)
+    db = nrsfm.DiffDatabase(ctx, 64)
+    db.append(np.zeros((5, 18), np.float32), np.arange(5, dtype=np.int32))
+    db2 = nrsfm.DiffDatabase(ctx, 64)
+    db2.close()                      # database first
+    lib = ctx._L
+    ctx.close()                      # then the context, with `db` still alive
+    assert int(lib.dsh_diffdb_count(db._h)) == 5
+    assert lib.dsh_diffdb_append(db._h, 0, None, None, None, None) != 0      # detached: refused, nothing dereferenced
+    assert lib.dsh_diffdb_destroy(db._h) == 0
+    db._h = None

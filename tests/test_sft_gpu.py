@@ -104,6 +104,44 @@ def test_c5_batch_of_16_equals_singles_bit_for_bit(gpu_ctx):
         assert np.abs(f.nodes_xyz - g["out_xyz"]).max() <= VERT_TOL * np.abs(g["out_xyz"]).max()
 
 
+def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
+    """The configuration bench.py reports, checked against the oracle where it runs: the PRODUCT library, >= 1024 C2 problems in one
+    launch (so that the throughput shape is chosen: four wavefronts per problem, at least two problems resident per CU -- asserted through
+    dsh_sft_batch_problem_info), every compute unit loaded with other problems while the sampled ones are solved.  Sampled ids: first,
+    last, middle, and both co-residents of CU pairs; LM trajectory, vertices, pose, outliers against oracle.sft_solve through _compare.
+    The launch is repeated three times and must reproduce itself bit for bit (no race in the hand-overs between the wavefronts)."""
+    from defslam_amd import sft, synth
+    B = 1024
+    rows, cols, m = synth.CONFIGS["C2"]
+    tmpl = synth.make_grid_template(rows, cols)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = [synth.make_frame(tmpl, m, p) for p in range(B)]
+    frames = [sft.frame_from_synth(fr) for fr in syn]
+    gpu_ctx.batch_upload(frames, *regs, 1, 50)
+    _, counts = gpu_ctx.problem_info(0)
+    assert int(counts[7]) in (1, 4), "a batch of 1024 C2 problems must take the throughput launch shape"
+    snaps = []
+    for _ in range(3):
+        gpu_ctx.batch_run()
+        inl = gpu_ctx.batch_download()
+        snaps.append([(int(i), f.iters, f.trials, f.nodes_xyz.copy(), f.pose7.copy(), f.chi2_obs.copy(), f.mvbOutlier.copy(), f.trace.copy())
+                      for i, f in zip(inl, frames)])
+    for rep in (1, 2):
+        for p in range(B):
+            a, b = snaps[0][p], snaps[rep][p]
+            assert a[:3] == b[:3], (rep, p)
+            for u, v in zip(a[3:], b[3:]):
+                np.testing.assert_array_equal(u, v)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    ids = [0, 1, 2, 3, 255, 256, 257, 510, 511, 512, 513, 767, 768, 1000, 1022, 1023]
+    for p in ids:
+        fr = syn[p]
+        r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+        _compare(frames[p], snaps[2][p][0], r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+        assert frames[p].trials == r.trials
+
+
 @pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0), ("W12", 1), ("W16", 2), ("B272", 3)])
 def test_hip_matches_oracle_seeded(gpu_ctx, oracle_mod, cfg, pid):
     from defslam_amd import synth
