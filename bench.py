@@ -397,9 +397,10 @@ def main():
     parity_ids = sorted(set(parity_ids)) if (rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "C5") else []
     gpu_sample = []
     if parity_ids:                                  # the results of the last timed launch, before any other leg re-uploads
-        import copy
-        ctx.batch_download(only=parity_ids)
-        gpu_sample = [(rank * args.batch + i, copy.copy(frames[i])) for i in parity_ids]
+        ctx.batch_download(only=parity_ids)         # writes the results into the Frame objects (the reference mutates its frame in place) ...
+        gpu_sample = [(rank * args.batch + i, frames[i]) for i in parity_ids]
+        for i in parity_ids:                        # ... so the legs below get fresh inputs for these ids
+            frames[i] = sft.frame_from_synth(synth.make_frame(tmpl, m, rank * args.batch + i))
     infos = [ctx.problem_info(b) for b in range(args.batch)]
     alg_bytes = sum(i[0] for i in infos)
     _, counts = infos[0]

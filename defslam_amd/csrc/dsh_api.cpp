@@ -31,6 +31,7 @@ extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream
 extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_vec_sum2(const double* a, const double* b, double* out_a, double* out_b, int n, hipStream_t stream);
 #ifdef DSH_LAB
+extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int which, double rel, int max_kd, size_t jl_doubles, hipStream_t stream);
 extern "C" hipError_t sft_assembly_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, hipStream_t stream);
 #endif
 
@@ -1214,6 +1215,51 @@ int dsh_lab_sft_assemble_timed(dsh_ctx* c, int launches, double* total_ms) {
   HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *total_ms = ms;
   c->ran = false;   // results of the last full run are gone (state reset, H reassembled at the initial state)
+  return DSH_OK;
+}
+
+int dsh_lab_sft_wave_check(dsh_ctx* c, double rel, int launches, int only, double* x_ref, double* x_new, int32_t* ok2, double* ms2) {
+  if (!c || launches <= 0 || !ms2) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_wave_check: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_wave_check: host-only context, no GPU (there is no CPU fallback)");
+  if (c->B <= 0 || !c->ran) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_wave_check: needs an uploaded batch that has run once");
+  for (int b = 0; b < c->B; b++)
+    if (c->h_probs[b].tile_mode != 1) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_wave_check: register-window problems (half-bandwidth <= 128) only");
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));   // H of the initial state
+  EventPair ev;
+  HIPCHK(c, ev.create());
+  for (int which = 0; which < 2; which++) {
+    if (only == 2 - which) continue;   // only = 1: the four-wavefront solver alone, 2: the one-wavefront solver alone (lambda of the last reference run)
+    HIPCHK(c, sft_wave_lab_launch(c->d_probs, c->B, which, rel, c->max_kd, c->jl_doubles, c->stream));   // (also the warm-up)
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+    for (int i = 0; i < launches; i++) HIPCHK(c, sft_wave_lab_launch(c->d_probs, c->B, which, rel, c->max_kd, c->jl_doubles, c->stream));
+    HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(ev.e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    ms2[which] = (double)ms / launches;
+    double* dst = which == 0 ? x_ref : x_new;
+    size_t off = 0;
+    for (int b = 0; b < c->B; b++) {
+      const SftDev& h = c->h_probs[b];
+      const size_t Dnp = (size_t)((h.Dn + kNB - 1) / kNB) * kNB;
+      if (dst) HIPCHK(c, hipMemcpy(dst + off, h.x, 8 * (Dnp + 6), hipMemcpyDeviceToHost));
+      off += Dnp + 6;
+      double flag = 0.0;
+      if (ok2) { HIPCHK(c, hipMemcpy(&flag, h.dbg + 2, 8, hipMemcpyDeviceToHost)); ok2[2 * b + which] = (int32_t)flag; }
+    }
+  }
+  return DSH_OK;   // (H stays assembled at the initial state: the check can be repeated; the results of the last full run are stale)
+}
+
+int dsh_lab_sft_dump(dsh_ctx* c, int b, int what, int64_t n, double* out) {
+  if (!c || !out || b < 0 || b >= c->B || n <= 0) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_dump: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_dump: host-only context");
+  const SftDev& h = c->h_probs[b];
+  const double* src = what == 0 ? h.Lb : what == 1 ? h.Linv : what == 2 ? h.Lbord : what == 3 ? h.Hc : what == 4 ? h.Hbord : what == 5 ? h.x : what == 6 ? h.Hcorner : h.dbg;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, src, 8 * (size_t)n, hipMemcpyDeviceToHost));
   return DSH_OK;
 }
 

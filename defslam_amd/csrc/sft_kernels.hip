@@ -2278,6 +2278,15 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
 }
 
 #include "sft_wide.h"
+#include "sft_wave.h"
+
+// The register-window factorisation for either launch shape.  (The ONLY call site of factor_tiles_df<NW>: the host pass of hipcc rejects a
+// second instantiation request of that template from another function -- "substitution failure" -- so every user goes through here.)
+template <int NW>
+__device__ __forceinline__ void tile_factor(const SftDev& P, Ctl* ctl, double* panel) {
+  if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel, ctl->lambda, true);
+  else factor_tiles_df<NW>(P, ctl, panel);
+}
 
 // One damping trial at ctl->lambda from the current state: factorisation of H + lambda I, back substitution, state update
 // (sparse_optimizer.cpp:477-491), scale = sum_j x_j (lambda x_j + b_j) (optimization_algorithm_levenberg.cpp:166-176) and the robust
@@ -2311,8 +2320,7 @@ __device__ __forceinline__ double damping_trial(const SftDev& P, Ctl* ctl, doubl
 #endif
     {
       PH_RESET();
-      if constexpr (NW == 8) factor_tiles_df8(P, ctl, panel, ctl->lambda, true);
-      else factor_tiles_df<NW>(P, ctl, panel);
+      tile_factor<NW>(P, ctl, panel);
       PH_ADD(5);
     }
     PH_RESET();
@@ -3109,9 +3117,43 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_assembly_kernel
   if (tid == 0) P.dbg[0] = chi;
 }
 
+// A/B pair for the one-wavefront solver (sft_wave.h): both solve (H + lambda I) x = b on the H that sft_assembly_kernel left in memory,
+// lambda = rel * 1e-5 * max |diag H| (the first damping of the LM loop scaled by rel); x in P.x, lambda in P.dbg[1], "ok" in P.dbg[2].
+template <int NW>
+__device__ __forceinline__ void ref_factor_solve(const SftDev& P, Ctl* ctl, double* panel) {
+  tile_factor<NW>(P, ctl, panel);
+  backsub_tiles<NW>(P, ctl, panel);
+}
+template <int NW>
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_ref_solve_kernel(const SftDev* __restrict__ probs, double rel) {
+  constexpr int NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);
+  double* out = red + 16 * 27 + 5;
+  double* panel = out + 32;
+  const int tid = threadIdx.x;
+  double mx = 0.0;
+  for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+  if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+  mx = block_max(mx, red);
+  if (tid == 0) { ctl->lambda = rel * 1e-5 * mx; P.dbg[1] = ctl->lambda; }
+  __syncthreads();
+  ref_factor_solve<NW>(P, ctl, panel);
+  if (tid == 0) P.dbg[2] = ctl->fact_ok;
+}
+__global__ __launch_bounds__(64, 1) void sft_wave_solve_kernel(const SftDev* __restrict__ probs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  const double lambda = P.dbg[1];
+  const int ok = wv_factor_solve(P, lambda, lambda, to_lds(reinterpret_cast<double*>(smem)));
+  if (threadIdx.x == 0) P.dbg[2] = ok;
+}
 #endif  // DSH_LAB
 
 }  // namespace
+
 
 // LDS bytes the kernel needs for a problem with half-bandwidth kd
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
@@ -3213,3 +3255,18 @@ extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, si
   else hipLaunchKernelGGL(sft_lm_kernel<8>, dim3(B), dim3(512), lds, stream, d_probs);
   return hipGetLastError();
 }
+
+extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
+#ifdef DSH_LAB
+extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int which, double rel, int max_kd, size_t jl_doubles, hipStream_t stream) {
+  if (which == 0) {
+    const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_ref_solve_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sft_ref_solve_kernel<4>, dim3(B), dim3(256), lds, stream, d_probs, rel);
+  } else {
+    hipLaunchKernelGGL(sft_wave_solve_kernel, dim3(B), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs);
+  }
+  return hipGetLastError();
+}
+#endif

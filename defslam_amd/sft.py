@@ -223,6 +223,31 @@ class Context:
         self._check(self._L.dsh_lab_sft_assemble_timed(self._h, int(launches), C.byref(ms)), "dsh_lab_sft_assemble_timed")
         return ms.value
 
+    def wave_check(self, rel: float = 1.0, launches: int = 1, only: int = 0):
+        """A/B of the one-wavefront factorisation against the four-wavefront solver on the normal equations of every uploaded problem at
+        its initial state (dsh_lab_sft_wave_check): (x_ref, x_new, ok[B, 2], ms[2]); x_*: list of per-problem solutions (Dnp + 6)."""
+        self._need_lab("dsh_lab_sft_wave_check")
+        B = len(self._frames)
+        dims = []
+        for b in range(B):
+            _, counts = self.problem_info(b)
+            Dn = int(counts[5]) - 6
+            dims.append(((Dn + 31) // 32) * 32 + 6)
+        tot = int(sum(dims))
+        xr, xn = np.zeros(tot), np.zeros(tot)
+        ok = np.zeros((B, 2), np.int32)
+        ms = np.zeros(2)
+        self._check(self._L.dsh_lab_sft_wave_check(self._h, C.c_double(rel), int(launches), int(only), _ptr(xr, C.c_double), _ptr(xn, C.c_double), _ptr(ok, C.c_int32),
+                                                   _ptr(ms, C.c_double)), "dsh_lab_sft_wave_check")
+        offs = np.concatenate([[0], np.cumsum(dims)])
+        return [xr[offs[b]:offs[b + 1]] for b in range(B)], [xn[offs[b]:offs[b + 1]] for b in range(B)], ok, ms
+
+    def dump(self, b: int, what: int, n: int):
+        self._need_lab("dsh_lab_sft_dump")
+        out = np.zeros(int(n))
+        self._check(self._L.dsh_lab_sft_dump(self._h, int(b), int(what), int(n), _ptr(out, C.c_double)), "dsh_lab_sft_dump")
+        return out
+
     def phase_ms(self, b: int = 0):
         self._need_lab("dsh_lab_sft_phase_ms")
         out = np.zeros(8)

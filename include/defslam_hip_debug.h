@@ -44,6 +44,15 @@ int dsh_lab_sft_run_timed(dsh_ctx* ctx, int launches, double* total_ms);
  * normal-equation assembly at its uploaded initial state and stops; elapsed device milliseconds between two HIP events.
  * Needs a batch that has run once (H keeps the zero pattern of that run); invalidates that run's results. */
 int dsh_lab_sft_assemble_timed(dsh_ctx* ctx, int launches, double* total_ms);
+/* A/B of the one-wavefront factorisation (sft_wave.h) against the four-wavefront solver: the normal equations of every problem of the
+ * batch at its uploaded state (like dsh_lab_sft_assemble_timed) are solved with lambda = rel * 1e-5 * max |diag H| by both; x_ref / x_new
+ * (may be NULL) receive the two solutions problem after problem, Dnp + 6 doubles each (node unknowns padded to a multiple of 32, then the
+ * camera), ok2[2 b + which] the "all pivots positive" flags, ms2[which] the device time of one launch (average over `launches`);
+ * only = 0: both, 1: the four-wavefront solver alone, 2: the one-wavefront solver alone (with the lambda the last reference run left). */
+int dsh_lab_sft_wave_check(dsh_ctx* ctx, double rel, int launches, int only, double* x_ref, double* x_new, int32_t* ok2, double* ms2);
+/* n doubles of a workspace array of problem b: what = 0 L tiles, 1 inverse diagonal tiles, 2 border rows of L, 3 compact H blocks, 4 border rows
+ * of H, 5 x, 6 corner of H, 7 debug slots (tuning aid; no bounds check beyond n > 0). */
+int dsh_lab_sft_dump(dsh_ctx* ctx, int b, int what, int64_t n, double* out);
 /* Per-phase device time of problem b in the last run, milliseconds (constant 100 MHz counter read by one lane):
  * out8[1] residuals, [2] normal-equation assembly, [3] H->L copy, [4] panel factorisation, [5] trailing update,
  * [6] back substitution, [7] state update + LM control.  DSH_ERR_STATE unless built with EXTRA=-DSFT_PHASE_TIMERS. */
