@@ -25,6 +25,7 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
@@ -134,11 +135,17 @@ struct dsh_ctx : dsh_ctx_base {
   int force_waves = 0;                 // set while the shared-camera mode packs its problem (always the 8-wavefront shape)
   bool force_split = false;            // set while the connected-mesh mode packs its problem: the two-sided cut with one workgroup (rank) per part
   size_t lds_configured_cn = 0;
+  // throughput shape (sft_batch.h): rounds of LIN / FACTOR / TRIAL launches over the whole batch, one wavefront per factorisation
+  bool rounds_mode = false;
+  SftRun* d_runs = nullptr;            // B controller states + the done counter behind them, inside d_batch
+  int* d_counters = nullptr;
+  size_t lds_configured_b[2] = {0, 0};
+  int rounds_hint = 24;                // rounds the previous run of this context needed
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -282,7 +289,34 @@ int pack_problem(dsh_ctx* c, const dsh_sft_frame& f, bool wide_off, Packed& P, s
 // One solve of the uploaded batch.  K == 1: the persistent kernel, one launch, asynchronous.  K > 1 (latency mode): one launch
 // per round of K damping trials; an iteration that accepts one of its first K trials takes one launch, so max_iters + 1 launches
 // finish the typical frame; the done flags are read back behind them and further rounds are launched only while needed.
+int run_rounds(dsh_ctx* c) {
+  // Throughput shape: every problem of the batch advances by one damping trial per round (LIN for those that start an iteration, FACTOR,
+  // TRIAL).  As many rounds as the previous run needed are enqueued in one go, then the done counter is read back and rounds are added
+  // in pairs while a problem still runs (a finished problem's workgroups leave at their first instruction).
+  const int B = c->B;
+  auto launch = [&](int phase) { return sftb_launch(c->d_probs, c->d_runs, c->d_counters, B, phase, c->jl_doubles, c->lds_configured_b, c->stream); };
+  HIPCHK(c, launch(SFTB_PH_INIT));
+  const int worst = std::max(1, c->max_iters_batch) * 10 + 1;
+  int rounds = 0, group = std::max(1, std::min(worst, c->rounds_hint));
+  HIPCHK(c, c->spec_done.ensure(64, true));
+  while (true) {
+    for (int i = 0; i < group && rounds < worst; i++, rounds++) {
+      HIPCHK(c, launch(SFTB_PH_LIN));
+      HIPCHK(c, launch(SFTB_PH_FACTOR));
+      HIPCHK(c, launch(SFTB_PH_TRIAL));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->spec_done.p, c->d_counters, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int done = *reinterpret_cast<const int*>(c->spec_done.p);
+    if (done >= B) { c->rounds_hint = rounds; break; }
+    if (rounds >= worst) return fail(c, DSH_ERR_STATE, "batched rounds: a problem did not terminate within its trial budget");
+    group = 2;
+  }
+  return DSH_OK;
+}
+
 int run_once(dsh_ctx* c) {
+  if (c->rounds_mode) return run_rounds(c);
   if (c->spec_k <= 1) {
     HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
     return DSH_OK;
@@ -499,6 +533,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
     if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
     if (c->force_waves == 8) nw = 8;
+    // From two problems per CU upwards the batch runs as rounds of phase kernels with one wavefront per factorisation (sft_batch.h)
+    c->rounds_mode = all_tiles && nw == 4 && c->opt.waves == 0 && c->opt.rounds != 0 && !c->host_only;
   }
   // Latency mode: while CUs would idle anyway, every problem gets K of them and tries K dampings per iteration at once.
   int K = 1;
@@ -591,6 +627,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
+  const size_t o_runs = a.take(c->rounds_mode ? sizeof(SftRun) * (size_t)B + 256 : 0);
   for (int e = 0; e < B * K; e++) {
     const int b = e % B, lane = e / B;
     const SftDev& h = c->packed[b].h;
@@ -711,6 +748,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   HIPCHK(c, hipMemsetAsync(base + c->res_off, 0, c->res_bytes, c->stream));
   c->d_probs = (SftDev*)(base + o_tab);
   c->d_spec = (SftSpec*)(base + o_spec);
+  c->d_runs = (SftRun*)(base + o_runs);
+  c->d_counters = (int*)(base + o_runs + sizeof(SftRun) * (size_t)B);
   c->spec_bytes = sizeof(SftSpec) * (size_t)B * K;
   c->spec_k = K;
   c->any_split = false;
@@ -760,7 +799,7 @@ int dsh_sft_batch_problem_info(dsh_ctx* c, int b, int64_t* bytes, int32_t* count
   const int64_t reads = 60 * M + 24 * n + 88 + 92 * C + 16 * E + 28 * V;
   const int64_t writes = 8 * (30 * M + 21 * C + 6 * E + 9 * V) + 8 * (2 * M + C + E + 3 * V) + 8 * M;
   if (bytes) *bytes = reads + writes;
-  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.g->n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; counts[6] = h.kd; counts[7] = c->nw; counts[8] = P.g->noff; }
+  if (counts) { counts[0] = h.M; counts[1] = h.nA; counts[2] = P.g->n_curv_ref; counts[3] = h.Es; counts[4] = h.V; counts[5] = 6 + h.Dn; counts[6] = h.kd; counts[7] = c->rounds_mode ? 1 : c->nw; counts[8] = P.g->noff; }
   return DSH_OK;
 }
 
@@ -1169,6 +1208,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   if (k == "waves") { if (value != 0 && value != 4 && value != 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: waves is 0 (automatic), 4 or 8"); c->opt.waves = value; }
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
+  else if (k == "rounds") c->opt.rounds = value != 0;
   else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);

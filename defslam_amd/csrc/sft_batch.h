@@ -1,0 +1,170 @@
+// The throughput shape of the batched solver: the Levenberg-Marquardt loop of B independent problems as ROUNDS of phase kernels,
+//   LIN     residuals + Jacobian records + normal equations        (problems that start an iteration;   256 threads)
+//   FACTOR  (H + lambda I) x = b, one wavefront per problem         (every problem that is still running;  64 threads, sft_wave.h)
+//   TRIAL   state update, chi2 of the trial, LM controller          (the same problems;                   256 threads)
+// instead of one persistent kernel per problem (sft_lm_kernel).  Why: the factorisation wants a wave that owns a whole SIMD (512
+// registers, one wave per SIMD), the assembly wants many small waves that cover each other's gather latency -- one launch shape cannot
+// give both.  Between the phases a problem's state lives where it already lived (H as compact blocks, x, the node positions: HBM);
+// what the persistent kernel kept in LDS between phases -- the controller -- is the SftRun record.  The kernel boundary is the only
+// synchronisation.  Included by sft_kernels.hip inside its anonymous namespace; the arithmetic of LIN and TRIAL is the code of the
+// persistent kernel (eval_edges, assemble, pose_oplus, classify), the controller follows sft_lm_kernel line by line
+// (optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:403-475, DefOptimizer.cc:513).
+#pragma once
+
+#define SFTB_NW 4   // wavefronts of a LIN / TRIAL workgroup
+
+__device__ __forceinline__ void sftb_ctl_lds(char* smem, Ctl*& ctl, double*& red, double*& out, double*& panel) {
+  ctl = reinterpret_cast<Ctl*>(smem);
+  red = reinterpret_cast<double*>(smem + 512);
+  out = red + 16 * 27 + 5;
+  panel = out + 32;
+}
+
+__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters) {
+  const SftDev& P = probs[blockIdx.x];
+  init_state<64 * SFTB_NW>(P);
+  if (threadIdx.x == 0) {
+    SftRun& R = runs[blockIdx.x];
+    R.lambda = -1.0; R.ni = 2.0; R.chi_cur = 0.0; R.chi_ini = 0.0; R.rho = 0.0; R.lambda_start = 0.0;
+    R.it = 0; R.qmax = 0; R.nbad = 0; R.accepted = 0; R.all_ok = 1; R.iters = 0; R.trials = 0; R.fact_ok = 1;
+    R.state = P.max_iters > 0 ? SFTB_LIN : SFTB_FINISH;
+    if (blockIdx.x == 0) counters[0] = 0;
+  }
+}
+
+// LIN: a problem that starts an outer iteration is linearised; the first iteration also fixes the initial damping (tau = 1e-5).
+__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_lin_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs) {
+  constexpr int NW = SFTB_NW, NT = 64 * NW;
+  SftRun& R = runs[blockIdx.x];
+  if (R.state != SFTB_LIN) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl; double *red, *out, *panel;
+  sftb_ctl_lds(smem, ctl, red, out, panel);
+  const int tid = threadIdx.x;
+  const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+  double lambda = R.lambda;
+  if (R.it == 0) {
+    double mx = 0.0;
+    for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+    if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+    mx = block_max(mx, red);
+    lambda = 1e-5 * mx;
+  }
+  if (tid == 0) {
+    if (R.it == 0) { R.lambda = lambda; R.ni = 2.0; R.nbad = 0; }
+    R.chi_cur = chi0; R.chi_ini = chi0; R.qmax = 0; R.rho = 0.0; R.accepted = 0; R.all_ok = 1; R.lambda_start = lambda;
+    R.state = SFTB_TRIAL;
+  }
+}
+
+// FACTOR: one wavefront per running problem.
+__global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs) {
+  SftRun& R = runs[blockIdx.x];
+  if (R.state != SFTB_TRIAL) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  const double lambda = R.lambda;
+  const int ok = wv_factor_solve(P, lambda, lambda, to_lds(reinterpret_cast<double*>(smem)));
+  if (threadIdx.x == 0) R.fact_ok = ok;
+}
+
+// TRIAL: push, x applied, scale, chi2 at the trial state, the controller's verdict; pop on rejection; at the end of an iteration the stop
+// rules; at the end of the problem the classification.
+__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters) {
+  constexpr int NW = SFTB_NW, NT = 64 * NW;
+  SftRun& R = runs[blockIdx.x];
+  const int st = R.state;
+  if (st != SFTB_TRIAL && st != SFTB_FINISH) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl; double *red, *out, *panel;
+  sftb_ctl_lds(smem, ctl, red, out, panel);
+  const int tid = threadIdx.x;
+  if (st == SFTB_FINISH) {   // max_iters == 0: nothing but the classification of the initial state (the errors of a first evaluation)
+    (void)eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+    __syncthreads();
+    classify<NT>(P, ctl, panel, 0, 0);
+    if (tid == 0) { R.state = SFTB_DONE; atomicAdd(&counters[0], 1); }
+    return;
+  }
+  const int Dn = P.Dn;
+  const int Dnp = ((Dn + NB - 1) / NB) * NB;
+  const int ok = R.fact_ok;
+  const double lam = R.lambda;
+  // push + update (sparse_optimizer.cpp:477-491); like g2o, x keeps its previous content when the factorisation failed
+  for (int i = tid; i < 3 * P.n; i += NT) {
+    const double v = P.xyz[i];
+    P.xyz_bak[i] = v;
+    const int a = P.act[i / 3];
+    if (a >= 0) P.xyz[i] = v + P.x[3 * a + (i % 3)];
+  }
+  if (tid < 7) R.pose_bak[tid] = P.pose[tid];
+  __syncthreads();
+  if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
+  double sc = 0.0;
+  for (int r = tid; r < Dn; r += NT) { const double xv = P.x[r]; sc += xv * (lam * xv + P.Hbord[(size_t)6 * Dnp + r]); }
+  if (tid < 6) { const double xv = P.x[Dnp + tid]; sc += xv * (lam * xv + P.Hcorner[42 + tid]); }
+  __syncthreads();
+  block_sum<1>(&sc, red, out);
+  const double scale = out[0];
+  __syncthreads();
+  const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+  if (tid == 0) {
+    const double tempChi = ok ? chi_new : DBL_MAX;
+    double rho = (R.chi_cur - tempChi);
+    rho /= (scale + 1e-3);
+    R.rho = rho;
+    if (rho > 0 && isfinite(tempChi)) {
+      double alpha = 1. - pow((2 * rho - 1), 3);
+      alpha = fmin(alpha, 2. / 3.);
+      const double sf = fmax(1. / 3., alpha);
+      R.lambda = lam * sf; R.ni = 2.0; R.chi_cur = tempChi; R.accepted = 1;
+      ctl->stop = 0;
+    } else {
+      R.lambda = lam * R.ni; R.ni *= 2.0;
+      ctl->stop = 1;
+    }
+    R.qmax++;
+    R.all_ok &= ok;
+    ctl->qmax = R.qmax;
+    ctl->rho = rho;
+  }
+  __syncthreads();
+  if (ctl->stop) {  // pop
+    for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
+    if (tid < 7) P.pose[tid] = R.pose_bak[tid];
+  }
+  const bool again = (ctl->rho < 0) && (ctl->qmax < 10);
+  if (again) return;   // the next round factors the same H with the new damping
+  // ---- the outer iteration is over
+  __syncthreads();
+  if (tid == 0) {
+    const int qmax = R.qmax;
+    R.trials += qmax;
+    R.iters++;
+    if (P.trace) {
+      double* t = P.trace + R.it * 8;
+      t[0] = R.chi_ini; t[1] = R.lambda_start; t[2] = qmax; t[3] = R.chi_cur; t[4] = R.lambda; t[5] = R.rho; t[6] = R.accepted; t[7] = R.all_ok;
+    }
+    if (!R.all_ok) P.res->status |= 1;
+    bool term = (qmax == 10) || (R.rho == 0);
+    if (!term) {
+      if ((R.chi_ini - R.chi_cur) * 1e3 < R.chi_ini) R.nbad++; else R.nbad = 0;
+      term = R.nbad >= 3;
+    }
+    R.it++;
+    if (R.it >= P.max_iters) term = true;
+    ctl->nbad = term ? 1 : 0;
+    ctl->it = R.iters;
+    ctl->accepted = R.trials;
+    R.state = term ? SFTB_DONE : SFTB_LIN;
+  }
+  __syncthreads();
+  if (ctl->nbad) {
+    const int iters = ctl->it, trials = ctl->accepted;
+    __syncthreads();
+    classify<NT>(P, ctl, panel, iters, trials);
+    if (tid == 0) atomicAdd(&counters[0], 1);
+  }
+}

@@ -3090,6 +3090,8 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_cn_kernel(const
   }
 }
 
+#include "sft_batch.h"
+
 #ifdef DSH_LAB
 // Measurement kernel of the Jacobian-assembly roofline: one linearisation (residuals + Jacobian records) and one
 // normal-equation assembly per problem at its uploaded initial state, nothing else.  H and the border keep the zero pattern
@@ -3270,3 +3272,31 @@ extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int whic
   return hipGetLastError();
 }
 #endif
+
+// Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the calling context): the dynamic LDS sizes the
+// LIN and TRIAL kernels were last enabled for on that device.
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+  const size_t head = 512 + (16 * 27 + 5 + 32) * sizeof(double) + 64;
+  if (phase == SFTB_PH_INIT) {
+    hipLaunchKernelGGL(sftb_init_kernel, dim3(B), dim3(64 * SFTB_NW), 0, stream, d_probs, d_runs, d_counters);
+  } else if (phase == SFTB_PH_LIN) {
+    const size_t lds = head + jl_doubles * sizeof(double);
+    if (lds > configured[0]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sftb_lin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      configured[0] = lds;
+    }
+    hipLaunchKernelGGL(sftb_lin_kernel, dim3(B), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs);
+  } else if (phase == SFTB_PH_FACTOR) {
+    hipLaunchKernelGGL(sftb_factor_kernel, dim3(B), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs, d_runs);
+  } else {
+    const size_t lds = head + 2048 * sizeof(double);   // classify: the error norms of 2048 observations per pass
+    if (lds > configured[1]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sftb_trial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      configured[1] = lds;
+    }
+    hipLaunchKernelGGL(sftb_trial_kernel, dim3(B), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs, d_counters);
+  }
+  return hipGetLastError();
+}

@@ -86,6 +86,21 @@ struct SftSpec {
   SftSpecRes res[2];
 };
 
+// Batched throughput shape (sft_batch.h): the LM controller of a problem between the phase kernels of a round.
+#define SFTB_LIN 0      // the next launch it takes part in is a linearisation (start of an outer iteration)
+#define SFTB_TRIAL 1    // H is assembled: factor with R.lambda, then the trial
+#define SFTB_DONE 2
+#define SFTB_FINISH 3   // max_iters == 0: classification only
+#define SFTB_PH_INIT 0
+#define SFTB_PH_LIN 1
+#define SFTB_PH_FACTOR 2
+#define SFTB_PH_TRIAL 3
+struct SftRun {
+  double lambda, ni, chi_cur, chi_ini, rho, lambda_start;
+  double pose_bak[8];
+  int32_t it, qmax, nbad, accepted, all_ok, iters, trials, state, fact_ok, pad[3];
+};
+
 // Two-sided factorisation of a wide-band problem (sft_wide.h, latency mode; the connected-mesh mode across two GPUs uses the same cut).
 // The band ordering is cut into  [ part 0 : scalars 0 .. c0 ) [ separator : c0 .. c0+s ) [ part 1 : c0+s .. Dn ).  With s >= the scalar
 // half-bandwidth no element of H joins the two parts, so both can be eliminated at the same time -- part 0 top-down, part 1 in
