@@ -25,7 +25,7 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, hipStream_t stream);
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
@@ -294,7 +294,7 @@ int run_rounds(dsh_ctx* c) {
   // TRIAL).  As many rounds as the previous run needed are enqueued in one go, then the done counter is read back and rounds are added
   // in pairs while a problem still runs (a finished problem's workgroups leave at their first instruction).
   const int B = c->B;
-  auto launch = [&](int phase) { return sftb_launch(c->d_probs, c->d_runs, c->d_counters, B, phase, c->jl_doubles, c->lds_configured_b, c->stream); };
+  auto launch = [&](int phase) { return sftb_launch(c->d_probs, c->d_runs, c->d_counters, B, phase, c->jl_doubles, c->lds_configured_b, c->num_cus, c->stream); };
   HIPCHK(c, launch(SFTB_PH_INIT));
   const int worst = std::max(1, c->max_iters_batch) * 10 + 1;
   int rounds = 0, group = std::max(1, std::min(worst, c->rounds_hint));

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev
     R.lambda = -1.0; R.ni = 2.0; R.chi_cur = 0.0; R.chi_ini = 0.0; R.rho = 0.0; R.lambda_start = 0.0;
     R.it = 0; R.qmax = 0; R.nbad = 0; R.accepted = 0; R.all_ok = 1; R.iters = 0; R.trials = 0; R.fact_ok = 1;
     R.state = P.max_iters > 0 ? SFTB_LIN : SFTB_FINISH;
-    if (blockIdx.x == 0) counters[0] = 0;
+    if (blockIdx.x == 0) { counters[0] = 0; counters[1] = 0; }
   }
 }
 
@@ -58,15 +58,29 @@ __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_lin_kernel(const SftDev*
   }
 }
 
-// FACTOR: one wavefront per running problem.
-__global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs) {
-  SftRun& R = runs[blockIdx.x];
-  if (R.state != SFTB_TRIAL) return;
+// FACTOR: persistent wavefronts (one per SIMD) pull running problems from a counter; the back substitution of a wave's previous problem
+// rides in the factor steps of its next one (sft_wave.h), the last one is solved right away.
+__global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int B) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const SftDev& P = probs[blockIdx.x];
-  const double lambda = R.lambda;
-  const int ok = wv_factor_solve(P, lambda, lambda, to_lds(reinterpret_cast<double*>(smem)));
-  if (threadIdx.x == 0) R.fact_ok = ok;
+  lds_double* lds = to_lds(reinterpret_cast<double*>(smem));
+  const int lane = threadIdx.x;
+  for (int i = lane; i < WV_LDS_DOUBLES; i += 64) lds[i] = 0.0;   // (the landing buffer is multiplied by ring zeros before its first fill)
+  WvPrev Q;
+  Q.Lg = nullptr; Q.Linv = nullptr; Q.x = nullptr; Q.nT = 0; Q.active = 0; Q.xb = 0.0;
+  while (true) {
+    int b = 0;
+    if (lane == 0) b = atomicAdd(&counters[1], 1);
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b >= B) break;
+    if (runs[b].state != SFTB_TRIAL) continue;
+    const SftDev& P = probs[b];
+    const double lambda = runs[b].lambda;
+    double xcam;
+    const int ok = wv_factor(P, lambda, lambda, lds, Q, xcam);   // (Q's back substitution is complete when this returns)
+    if (lane == 0) runs[b].fact_ok = ok;
+    Q = wv_prev_of(P, ok, xcam, lane);
+  }
+  if (Q.active) wv_backsub_now(Q, lane);
 }
 
 // TRIAL: push, x applied, scale, chi2 at the trial state, the controller's verdict; pop on rejection; at the end of an iteration the stop
@@ -75,6 +89,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_trial_kernel(const SftDe
   constexpr int NW = SFTB_NW, NT = 64 * NW;
   SftRun& R = runs[blockIdx.x];
   const int st = R.state;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[1] = 0;   // the work counter of the FACTOR launch in front of this one: ready for the next round
   if (st != SFTB_TRIAL && st != SFTB_FINISH) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const SftDev& P = probs[blockIdx.x];

@@ -3275,7 +3275,7 @@ extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int whic
 
 // Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the calling context): the dynamic LDS sizes the
 // LIN and TRIAL kernels were last enabled for on that device.
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream) {
   const size_t head = 512 + (16 * 27 + 5 + 32) * sizeof(double) + 64;
   if (phase == SFTB_PH_INIT) {
     hipLaunchKernelGGL(sftb_init_kernel, dim3(B), dim3(64 * SFTB_NW), 0, stream, d_probs, d_runs, d_counters);
@@ -3288,7 +3288,7 @@ extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_
     }
     hipLaunchKernelGGL(sftb_lin_kernel, dim3(B), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs);
   } else if (phase == SFTB_PH_FACTOR) {
-    hipLaunchKernelGGL(sftb_factor_kernel, dim3(B), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs, d_runs);
+    hipLaunchKernelGGL(sftb_factor_kernel, dim3(std::min(B, 4 * num_cus)), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs, d_runs, d_counters, B);   // one wave per SIMD
   } else {
     const size_t lds = head + 2048 * sizeof(double);   // classify: the error norms of 2048 observations per pass
     if (lds > configured[1]) {

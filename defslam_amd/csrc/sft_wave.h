@@ -29,9 +29,15 @@
 __host__ __device__ constexpr int wv_phys(int r, int d) {
   return d == 0 ? r : (d <= 3 ? 8 * d + r : (d == 4 ? 32 + (r & 3) : 8 * (8 - d) + ((r + 8 - d) & 7)));
 }
-constexpr int WV_AGPR_TILES = 32;                 // physical tiles 0..31 = a[0:255]; 32..35 = LDS tiles 0..3 (the d = 4 tiles)
-constexpr int WV_LDS_WIN = 4, WV_LDS_BORD = 8;    // LDS tiles 4..11: border tiles Bd(J)^T, ring slot J mod 8
-constexpr int WV_LDS_DOUBLES = (WV_LDS_WIN + WV_LDS_BORD) * 256 + 16 * 17 + 64;   // + W transposition scratch + corner
+constexpr int WV_AGPR_TILES = 32;                 // physical tiles 0..31 = a[0:255]; 32..35 = LDS window tiles 0..3 (the d = 4 tiles)
+// LDS of a wave, in doubles (40 KB: four waves per CU):
+constexpr int WV_L_WIN = 0;                       // 4 window tiles x 256
+constexpr int WV_L_BORD = 1024;                   // 8 border tiles Bd(J)^T, ring slot J mod 8, COMPACT: only the lanes c < 8 hold data (7 rows + a zero row), 128 doubles each
+constexpr int WV_L_WSCR = 2048;                   // 16 x 17 transposition scratch of W (+ pad)
+constexpr int WV_L_CN = 2336;                     // 7 x 7 corner + x_cam
+constexpr int WV_L_XRING = 2400;                  // back substitution of the PREVIOUS problem: ring of the last eight x tiles
+constexpr int WV_L_LAND = 2528;                   // ... and the landing buffer of one block column of its L: [Yb | Y_1 .. Y_8 | W], 10 x 256
+constexpr int WV_LDS_DOUBLES = WV_L_LAND + 10 * 256;   // 5088 doubles = 40704 bytes
 typedef double v2d_w __attribute__((ext_vector_type(2)));
 using lds_v2d = __attribute__((address_space(3))) v2d_w;
 
@@ -54,7 +60,7 @@ __device__ __forceinline__ void wv_upd_agpr(const v4d& A, const v4d& B, int q0 =
 // (the compiler may copy C into the operand registers right in front of the statement -- it keeps the corner elsewhere between steps --:
 // a VALU write needs two wait states before an MFMA reads it, and nothing pads an asm statement)
 __device__ __forceinline__ void wv_upd_vgpr(v4d& C, const v4d& A, const v4d& B, int q0 = 0) {
-#define WV_MF(q) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(C) : "v"(A[q]), "v"(B[q]))
+#define WV_MF(q) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(C) : "v"(A[q]), "v"(B[q]) : "memory")
   asm volatile("s_nop 1" : "+v"(C));
   if (q0 <= 0) WV_MF(0);
   if (q0 <= 1) WV_MF(1);
@@ -97,8 +103,8 @@ __device__ __forceinline__ void wv_mfma_fence() { asm volatile(WV_NOP_MFMA_RESUL
 template <int T>
 __device__ __forceinline__ v4d wv_read_agpr() {
   int r[8];
-  asm volatile(WV_NOP_MFMA_RESULT "\n\t"
-               "v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\tv_accvgpr_read_b32 %3, a[%c11]\n\t"
+  // (the diagonal tile was last written at the head of the previous step's update: thousands of cycles ago)
+  asm volatile("v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\tv_accvgpr_read_b32 %3, a[%c11]\n\t"
                "v_accvgpr_read_b32 %4, a[%c12]\n\tv_accvgpr_read_b32 %5, a[%c13]\n\tv_accvgpr_read_b32 %6, a[%c14]\n\tv_accvgpr_read_b32 %7, a[%c15]"
                : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7])
                : "i"(8 * T), "i"(8 * T + 1), "i"(8 * T + 2), "i"(8 * T + 3), "i"(8 * T + 4), "i"(8 * T + 5), "i"(8 * T + 6), "i"(8 * T + 7));
@@ -132,6 +138,26 @@ __device__ __forceinline__ void wv_lds_store(lds_double* tile, int lane, const v
   lds_v2d* p = reinterpret_cast<lds_v2d*>(tile);
   p[lane] = (v2d_w){v[0], v[1]};
   p[64 + lane] = (v2d_w){v[2], v[3]};
+}
+// border tiles: only the lanes c < 8 carry data (the update leaves the other columns of the accumulator at zero: the B operand Yb is
+// zero there), so the LDS image keeps 32 lanes -- half the bytes, which is what makes room for the landing buffer
+__device__ __forceinline__ v4d wv_bord_load(const lds_double* tile, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  v4d v = {0.0, 0.0, 0.0, 0.0};
+  if (c < 8) {
+    const lds_v2d* p = reinterpret_cast<const lds_v2d*>(tile);
+    const v2d_w a = p[g * 8 + c], b = p[32 + g * 8 + c];
+    v = (v4d){a.x, a.y, b.x, b.y};
+  }
+  return v;
+}
+__device__ __forceinline__ void wv_bord_store(lds_double* tile, int lane, const v4d& v) {
+  const int g = lane >> 4, c = lane & 15;
+  if (c < 8) {
+    lds_v2d* p = reinterpret_cast<lds_v2d*>(tile);
+    p[g * 8 + c] = (v2d_w){v[0], v[1]};
+    p[32 + g * 8 + c] = (v2d_w){v[2], v[3]};
+  }
 }
 
 // ---- 16 x 16 Cholesky + inverse, every MFMA as asm on VGPR tiles (tile_chol.h: chol_inv_blocked is the compiler-scheduled original) --
@@ -239,20 +265,137 @@ __device__ __forceinline__ void wv_row_list(const WvProb& W, int I, int lane, Wv
 #pragma unroll
   for (int d = 0; d < 8; d++) wv_list(W, I, d, lane, L.o[d]);
 }
-// The row's elements: accumulator tiles straight from memory, the d = 4 tile through VGPRs into its LDS tile.  PH = I mod 8; dmax: the
-// prologue rows have fewer tiles (J >= 0).  The caller waits (wv_wait_vm) before the first MFMA on these tiles.
+// The row's elements: accumulator tiles straight from memory; the d = 4 tile (LDS-resident) comes back in `fresh4` and is stored by the
+// caller once it has arrived (storing it here would wait for memory in the middle of a step).  PH = I mod 8; dmax: the prologue rows have
+// fewer tiles (J >= 0).  The caller waits (wv_wait_vm) before the first MFMA on these tiles.
 template <int PH, int D>
-__device__ __forceinline__ void wv_row_fetch_d(const WvProb& W, const WvRowList& L, int dmax, lds_double* ldsw, int lane) {
+__device__ __forceinline__ void wv_row_fetch_d(const WvProb& W, const WvRowList& L, int dmax, v4d& fresh4) {
   if constexpr (D < 8) {
     if (D <= dmax) {
-      if constexpr (D == 4) {
-        const v4d v = wv_gather_vgpr(W, L.o[D]);
-        wv_lds_store(ldsw + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, v);
-      } else {
-        wv_gather_agpr<wv_phys(PH, D)>(W.Hc, L.o[D][0], L.o[D][1], L.o[D][2], L.o[D][3]);
-      }
+      if constexpr (D == 4) fresh4 = wv_gather_vgpr(W, L.o[D]);
+      else wv_gather_agpr<wv_phys(PH, D)>(W.Hc, L.o[D][0], L.o[D][1], L.o[D][2], L.o[D][3]);
     }
-    wv_row_fetch_d<PH, D + 1>(W, L, dmax, ldsw, lane);
+    wv_row_fetch_d<PH, D + 1>(W, L, dmax, fresh4);
+  }
+}
+
+// ---- the back substitution of the PREVIOUS problem of this wave, one block column per factor step of the current one ----------------------
+// All waves of a launch reach their back substitutions at the same time, and the 1.9 MB of L each of them reads back then meet at the HBM
+// limit (measured: 0.19 M cycles alone, 0.8 M with 1024 waves in step -- a quarter of a factorisation).  So a wave defers it: while it
+// factors its next problem, block column J of the previous L arrives in an LDS landing buffer by LDS-DMA (no registers; memory
+// instructions issue in the shadow of the MFMAs) and costs ~110 VALU instructions per step.
+struct WvPrev {
+  const SFT_G double* Lg;     // block columns [Yb | Y_1 .. Y_8], 9 x 2 KB each
+  const SFT_G double* Linv;   // W tiles
+  SFT_G double* x;
+  int nT, active;
+  double xb;                  // per lane: x_cam[c] for c < 6, -1 for c == 6 (the right-hand side column of the border), else 0
+};
+__device__ __forceinline__ void wv_bs_request(const WvPrev& Q, int J, lds_double* land, int lane) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const SFT_G char* col = reinterpret_cast<const SFT_G char*>(Q.Lg + ((size_t)J * (BT + 1)) * 256) + 16 * lane;
+#pragma unroll
+  for (int i = 0; i < 18; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(col + 1024 * i), (lds_void*)(land + 128 * i), 16, 0, 0);
+  const SFT_G char* w = reinterpret_cast<const SFT_G char*>(Q.Linv + (size_t)J * 256) + 16 * lane;
+#pragma unroll
+  for (int i = 0; i < 2; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(w + 1024 * i), (lds_void*)(land + 128 * (18 + i)), 16, 0, 0);
+}
+// Column J from the landing buffer: S_q = sum_d Y_d[q] x_{J+d}[c] + Yb[q] xb[c], summed over the 16 lanes of a row, is (L^T x)_tail + the
+// camera term - y at index g + 4q; x_J[c] = sum_r W[r][c] (-S[r]).  The border tile is a ninth tile whose "x" is (x_cam, -1, 0, ...).
+__device__ __forceinline__ void wv_bs_column(const WvPrev& Q, int J, const lds_double* land, lds_double* xring, int lane) {
+  const int c = lane & 15;
+  const lds_v2d* t2 = reinterpret_cast<const lds_v2d*>(land) + 2 * lane;   // the lane's 32 bytes of tile 0; tile i: + 128 * i
+  double s[4];
+  {
+    const v2d_w a = t2[0], b = t2[1];
+    s[0] = a.x * Q.xb; s[1] = a.y * Q.xb; s[2] = b.x * Q.xb; s[3] = b.y * Q.xb;
+  }
+#pragma unroll
+  for (int d = 1; d <= 8; d++) {
+    const double xr = xring[((J + d) & 7) * 16 + c];   // tile rows behind the matrix: the ring still holds its zeros
+    const v2d_w a = t2[128 * d], b = t2[128 * d + 1];
+    s[0] = fma(a.x, xr, s[0]); s[1] = fma(a.y, xr, s[1]); s[2] = fma(b.x, xr, s[2]); s[3] = fma(b.y, xr, s[3]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {   // all-reduce over the 16 lanes of a row (fixed butterfly: row_ror 8, 4, 2, 1)
+    s[q] += dpp_mov<0x128>(s[q]);
+    s[q] += dpp_mov<0x124>(s[q]);
+    s[q] += dpp_mov<0x122>(s[q]);
+    s[q] += dpp_mov<0x121>(s[q]);
+  }
+  const v2d_w wa = t2[128 * 9], wb = t2[128 * 9 + 1];
+  double p = wa.x * -s[0];
+  p = fma(wa.y, -s[1], p); p = fma(wb.x, -s[2], p); p = fma(wb.y, -s[3], p);
+  p = sum_rows(p);
+  if (lane < TS) { xring[(J & 7) * 16 + lane] = p; Q.x[TS * J + lane] = p; }
+}
+// one column of the deferred back substitution + the request of the next one (call behind a wv_wait_vm: the column has landed)
+__device__ __forceinline__ void wv_bs_step(const WvPrev& Q, int J, lds_double* lds, int lane) {
+  wv_bs_column(Q, J, lds + WV_L_LAND, lds + WV_L_XRING, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the landing buffer has returned before the DMA overwrites it
+  if (J >= 1) wv_bs_request(Q, J - 1, lds + WV_L_LAND, lane);
+}
+__device__ __forceinline__ void wv_bs_begin(const WvPrev& Q, lds_double* lds, int lane) {
+  lds_double* xring = lds + WV_L_XRING;
+  xring[lane] = 0.0; xring[64 + lane] = 0.0;
+  wv_bs_request(Q, Q.nT - 1, lds + WV_L_LAND, lane);
+}
+// The whole back substitution at once (the last problem of a wave; lab A/B): block columns two ahead in registers.
+__device__ __forceinline__ void wv_backsub_now(const WvPrev& Q, int lane) {
+  const int c = lane & 15;
+  (void)c;
+  double xr[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) xr[s] = 0.0;
+  struct Col { v4d t[10]; };   // [0] Yb, [1..8] Y_d, [9] W
+  auto fetch = [&](int J) -> Col {
+    Col C;
+    if (J >= 0) {
+      const SFT_G double* col = Q.Lg + ((size_t)J * (BT + 1)) * 256 + 4 * lane;
+#pragma unroll
+      for (int i = 0; i <= 8; i++) C.t[i] = (i == 0 || J + i < Q.nT) ? *reinterpret_cast<const SFT_G v4d*>(col + 256 * i) : (v4d){0.0, 0.0, 0.0, 0.0};
+      C.t[9] = *reinterpret_cast<const SFT_G v4d*>(Q.Linv + (size_t)J * 256 + 4 * lane);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 10; i++) C.t[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    return C;
+  };
+  auto solve_col = [&](const Col& C, int J, auto phc) {
+    constexpr int ph = decltype(phc)::value;   // J mod 8
+    double s[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) s[q] = C.t[0][q] * Q.xb;
+#pragma unroll
+    for (int dd = 1; dd <= 8; dd++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) s[q] = fma(C.t[dd][q], xr[(ph + dd) & 7], s[q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      s[q] += dpp_mov<0x128>(s[q]);
+      s[q] += dpp_mov<0x124>(s[q]);
+      s[q] += dpp_mov<0x122>(s[q]);
+      s[q] += dpp_mov<0x121>(s[q]);
+    }
+    double p = C.t[9][0] * -s[0];
+#pragma unroll
+    for (int q = 1; q < 4; q++) p = fma(C.t[9][q], -s[q], p);
+    p = sum_rows(p);
+    xr[ph] = p;
+    if (lane < TS) Q.x[TS * J + lane] = p;
+  };
+  int J = Q.nT - 1;
+  Col c0 = fetch(J), c1 = fetch(J - 1);
+#pragma unroll 1
+  for (; J >= 0; J -= 2) {   // nT is even (Dnp is a multiple of 32)
+    const Col n0 = fetch(J - 2), n1 = fetch(J - 3);
+    switch (J & 7) {
+      case 7: solve_col(c0, J, std::integral_constant<int, 7>{}); solve_col(c1, J - 1, std::integral_constant<int, 6>{}); break;
+      case 5: solve_col(c0, J, std::integral_constant<int, 5>{}); solve_col(c1, J - 1, std::integral_constant<int, 4>{}); break;
+      case 3: solve_col(c0, J, std::integral_constant<int, 3>{}); solve_col(c1, J - 1, std::integral_constant<int, 2>{}); break;
+      default: solve_col(c0, J, std::integral_constant<int, 1>{}); solve_col(c1, J - 1, std::integral_constant<int, 0>{}); break;
+    }
+    c0 = n0; c1 = n1;
   }
 }
 
@@ -260,10 +403,10 @@ __device__ __forceinline__ void wv_row_fetch_d(const WvProb& W, const WvRowList&
 struct WvState {
   v4d Y[9];          // Y[i], i = 1..8: X(k+i,k)^T; Y[0]: the border tile Xb^T of column k
   v4d corner;        // 7 x 7 camera corner (+ right-hand side row), accumulator order, lower triangle meaningful
-  v4d araw;          // raw tile (k+8, k)^T of the NEXT step's column (the d = 8 corner of the band)
-  v4d bnext;         // raw border tile of column k+8 (enters the ring this step)
-  WvRowList rl;      // gather lists of the row that enters the window this step (row k+8)
-  unsigned al[4];    // gather list of tile (k+9, k+1): the next araw
+  v4d araw;          // raw tile (k+8, k)^T of this step's column (the d = 8 corner of the band): requested at the head of the step
+  v4d bnext;         // raw border tile of column k+8 (enters the ring this step): requested at the head of the step
+  WvRowList rl;      // gather lists of the row that enters the window this step (row k+8): requested at the head of the step
+  unsigned al[4];    // gather list of tile (k+9, k+1), the next step's araw -- the only request that is carried across the update
   int ok;
 };
 
@@ -284,46 +427,69 @@ __device__ __forceinline__ void wv_trsm_cols(WvState& S, const v4d& Wt, int k, i
   }
 }
 
-// window tiles (k+I, k+J), 1 <= J <= I: rows 1..7 first, row 8 (fetched during this step) last
+// window tiles (k+I, k+J), 1 <= J <= I, that live in the accumulator file (the d = 4 tiles: wv_lds_pipe)
 template <int PH, int I, int J>
-__device__ __forceinline__ void wv_update_tiles(WvState& S, int k, int nT, int q8, lds_double* ldsw, int lane) {
+__device__ __forceinline__ void wv_update_tiles(WvState& S, int k, int nT, int q8) {
   if constexpr (I <= 8) {
-    if (k + I < nT) {
-      constexpr int d = I - J, r = (PH + I) & 7;
-      const int q0 = (I == 8) ? q8 : 0;
-      if constexpr (d == 4) {
-        lds_double* t = ldsw + 256 * (wv_phys(r, 4) - WV_AGPR_TILES);
-        v4d C = wv_lds_load(t, lane);
-        wv_upd_vgpr(C, S.Y[J], S.Y[I], q0);
-        wv_mfma_fence();
-        wv_lds_store(t, lane, C);
-      } else {
-        wv_upd_agpr<wv_phys(r, d)>(S.Y[J], S.Y[I], q0);
-      }
+    constexpr int d = I - J, r = (PH + I) & 7;
+    if constexpr (d != 4) {
+      if (k + I < nT) wv_upd_agpr<wv_phys(r, d)>(S.Y[J], S.Y[I], (I == 8) ? q8 : 0);
     }
-    if constexpr (J < I) wv_update_tiles<PH, I, J + 1>(S, k, nT, q8, ldsw, lane);
+    if constexpr (J < I) wv_update_tiles<PH, I, J + 1>(S, k, nT, q8);
   }
 }
 template <int PH, int I0, int I1>
-__device__ __forceinline__ void wv_update_rows(WvState& S, int k, int nT, int q8, lds_double* ldsw, int lane) {
+__device__ __forceinline__ void wv_update_rows(WvState& S, int k, int nT, int q8) {
   if constexpr (I0 <= I1) {
-    wv_update_tiles<PH, I0, 1>(S, k, nT, q8, ldsw, lane);
-    wv_update_rows<PH, I0 + 1, I1>(S, k, nT, q8, ldsw, lane);
+    wv_update_tiles<PH, I0, 1>(S, k, nT, q8);
+    wv_update_rows<PH, I0 + 1, I1>(S, k, nT, q8);
   }
 }
-// border tiles Bd(k+J)^T -= Y_J^T Yb, J = J0..J1 (LDS ring slot (k+J) mod 8)
-template <int PH, int J, int J1>
-__device__ __forceinline__ void wv_update_border(WvState& S, int k, int nT, int q8, lds_double* ldsb, int lane) {
-  if constexpr (J <= J1) {
-    if (k + J < nT) {
-      lds_double* t = ldsb + 256 * ((PH + J) & 7);
-      v4d C = wv_lds_load(t, lane);
-      wv_upd_vgpr(C, S.Y[J], S.Y[0], (J == 8) ? q8 : 0);
-      wv_mfma_fence();
-      wv_lds_store(t, lane, C);
-    }
-    wv_update_border<PH, J + 1, J1>(S, k, nT, q8, ldsb, lane);
+// The LDS-resident tiles of a step as a list of tasks: T = 0..6 border tiles Bd(k+T+1)^T, T = 7, 8, 9 the d = 4 window tiles of rows 5, 6, 7
+// (first half of the update); T = 10 border tile Bd(k+8)^T, T = 11 window tile (k+8, k+4) (second half: behind the fetch of row k+8).
+// Unconditional -- behind the matrix the Y operands are zero -- and software-pipelined: a tile is written back behind the four MFMAs of
+// the NEXT one, by which time its own have long left the matrix pipe (no wait states spent per tile; one fence at the end of a run).
+template <int PH, int T>
+__device__ __forceinline__ lds_double* wv_task_tile(lds_double* lds) {
+  if constexpr (T < 7) return lds + WV_L_BORD + 128 * ((PH + T + 1) & 7);
+  else if constexpr (T < 10) return lds + WV_L_WIN + 256 * (wv_phys((PH + T - 2) & 7, 4) - WV_AGPR_TILES);   // rows I = 5, 6, 7
+  else if constexpr (T == 10) return lds + WV_L_BORD + 128 * (PH & 7);                                        // column k+8: ring slot k mod 8
+  else return lds + WV_L_WIN + 256 * (wv_phys(PH & 7, 4) - WV_AGPR_TILES);                                     // row 8: ring row k mod 8
+}
+template <int PH, int T>
+__device__ __forceinline__ v4d wv_task_load(lds_double* lds, int lane) {
+  if constexpr (T < 7 || T == 10) return wv_bord_load(wv_task_tile<PH, T>(lds), lane);
+  else return wv_lds_load(wv_task_tile<PH, T>(lds), lane);
+}
+template <int PH, int T>
+__device__ __forceinline__ void wv_task_store(lds_double* lds, int lane, const v4d& C) {
+  if constexpr (T < 7 || T == 10) wv_bord_store(wv_task_tile<PH, T>(lds), lane, C);
+  else wv_lds_store(wv_task_tile<PH, T>(lds), lane, C);
+}
+template <int T>
+__device__ __forceinline__ void wv_task_mfma(v4d& C, const WvState& S, int q8) {
+  if constexpr (T < 7) wv_upd_vgpr(C, S.Y[T + 1], S.Y[0]);
+  else if constexpr (T < 10) wv_upd_vgpr(C, S.Y[T - 6], S.Y[T - 2]);   // (I, J) = (5, 1), (6, 2), (7, 3)
+  else if constexpr (T == 10) wv_upd_vgpr(C, S.Y[8], S.Y[0], q8);
+  else wv_upd_vgpr(C, S.Y[4], S.Y[8], q8);
+}
+template <int PH, int T, int TEND>
+__device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_double* lds, int lane, const v4d& Cprev) {
+  v4d C = wv_task_load<PH, T>(lds, lane);
+  wv_task_mfma<T>(C, S, q8);
+  wv_task_store<PH, T - 1>(lds, lane, Cprev);
+  if constexpr (T < TEND) {
+    wv_lds_pipe_next<PH, T + 1, TEND>(S, q8, lds, lane, C);
+  } else {
+    wv_mfma_fence();
+    wv_task_store<PH, T>(lds, lane, C);
   }
+}
+template <int PH, int T0, int TEND>
+__device__ __forceinline__ void wv_lds_pipe(const WvState& S, int q8, lds_double* lds, int lane) {
+  v4d C = wv_task_load<PH, T0>(lds, lane);
+  wv_task_mfma<T0>(C, S, q8);
+  wv_lds_pipe_next<PH, T0 + 1, TEND>(S, q8, lds, lane, C);
 }
 
 // Part A of a step (before the tile Cholesky): the diagonal tile of column k out of the accumulator file, damped.
@@ -339,16 +505,16 @@ __device__ __forceinline__ v4d wv_step_diag(const WvProb& W, int k, int lane) {
 
 // Part B (behind the tile Cholesky): TRSM of block column k, the row that enters the window, the trailing update.
 template <int PH>
-__device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& Wt, int k, lds_double* lds, int lane) {
-  lds_double* ldsw = lds;                       // LDS tiles 0..3: the d = 4 window tiles
-  lds_double* ldsb = lds + 256 * WV_LDS_WIN;    // LDS tiles 4..11: border ring
+__device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& Wt, int k, lds_double* lds, int lane, const WvPrev& Q) {
+  lds_double* ldsw = lds + WV_L_WIN;
+  lds_double* ldsb = lds + WV_L_BORD;
   const int nT = W.nT;
   // ---- block column k: Y_i = W D(k+i, k), border Yb = W Bd(k)^T
   wv_trsm_cols<PH, 1>(S, Wt, k, nT, ldsw, lane);
   if (k + 8 < nT) wv_trsm_vgpr(S.Y[8], Wt, S.araw, W.q8);
   else S.Y[8] = (v4d){0.0, 0.0, 0.0, 0.0};
   {
-    const v4d Bk = wv_lds_load(ldsb + 256 * PH, lane);
+    const v4d Bk = wv_bord_load(ldsb + 128 * PH, lane);
     wv_trsm_vgpr(S.Y[0], Wt, Bk);
   }
   wv_mfma_fence();
@@ -360,24 +526,26 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
       if (i == 0 || k + i < nT) *reinterpret_cast<SFT_G v4d*>(col + 256 * i) = S.Y[i];
   }
   // ---- the ring row / border slot of column k are free: row k+8 enters (its lists came a step ahead), the lists of row k+9 are requested
-  wv_row_fetch_d<PH, 0>(W, S.rl, 7, ldsw, lane);
-  wv_lds_store(ldsb + 256 * PH, lane, S.bnext);
-  const v4d araw_next = wv_gather_vgpr(W, S.al);          // tile (k+9, k+1)^T for the next step's TRSM
-  wv_row_list(W, k + 9, lane, S.rl);
-  wv_list(W, k + 10, 8, lane, S.al);
-  S.bnext = wv_border_fresh(W, k + 9, lane);
-  // ---- trailing update: rows 1..7, border 1..7, corner; then (the fetched row has landed) row 8 and border 8
+  v4d fresh4;
+  wv_row_fetch_d<PH, 0>(W, S.rl, 7, fresh4);
+  wv_bord_store(ldsb + 128 * PH, lane, S.bnext);
+  // ---- trailing update: corner, rows 1..7, the LDS tiles of the first half; then (everything requested has landed) the deferred back
+  // substitution's column, row 8 and the LDS tiles of the second half
   wv_upd_vgpr(S.corner, S.Y[0], S.Y[0]);
-  wv_update_rows<PH, 1, 7>(S, k, nT, W.q8, ldsw, lane);
-  wv_update_border<PH, 1, 7>(S, k, nT, W.q8, ldsb, lane);
+  wv_update_rows<PH, 1, 7>(S, k, nT, W.q8);
+  wv_lds_pipe<PH, 0, 9>(S, W.q8, lds, lane);
   wv_wait_vm();
-  wv_update_rows<PH, 8, 8>(S, k, nT, W.q8, ldsw, lane);
-  wv_update_border<PH, 8, 8>(S, k, nT, W.q8, ldsb, lane);
+  if (Q.active) {
+    const int J = Q.nT - 1 - k;
+    if (J >= 0) wv_bs_step(Q, J, lds, lane);
+  }
+  wv_lds_store(ldsw + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, fresh4);   // tile (k+8, k+4)
+  wv_update_rows<PH, 8, 8>(S, k, nT, W.q8);
+  wv_lds_pipe<PH, 10, 11>(S, W.q8, lds, lane);
   // The corner's MFMAs were issued at the head of the update: it is long complete here.  This empty statement takes the corner as an
   // operand, so any register copy the compiler makes of it (the merge of the eight phase bodies) sits BEHIND the whole update -- a copy
   // right behind the MFMA statement would read the registers before the matrix pipe has written them (no hazard padding around asm).
   asm volatile("" : "+v"(S.corner));
-  S.araw = araw_next;
 }
 
 // prologue: tile rows 0..7 of H into the window
@@ -385,14 +553,16 @@ template <int PH>
 __device__ __forceinline__ void wv_prologue_row(const WvProb& W, lds_double* lds, int lane) {
   WvRowList L;
   wv_row_list(W, PH, lane, L);
-  wv_row_fetch_d<PH, 0>(W, L, PH, lds, lane);
-  wv_lds_store(lds + 256 * (WV_LDS_WIN + PH), lane, wv_border_fresh(W, PH, lane));
+  v4d fresh4 = {0.0, 0.0, 0.0, 0.0};
+  wv_row_fetch_d<PH, 0>(W, L, PH, fresh4);
+  if constexpr (PH >= 4) wv_lds_store(lds + WV_L_WIN + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, fresh4);
+  wv_bord_store(lds + WV_L_BORD + 128 * PH, lane, wv_border_fresh(W, PH, lane));
 }
 
-// ---- the factorisation + back substitution of one problem by one wavefront --------------------------------------------------------------
-// lds: WV_LDS_DOUBLES doubles of this wave.  Returns the "all pivots positive" flag; x (P.x) = solution in the natural ordering
-// (node unknowns, then the 6 camera unknowns at Dnp).
-__device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, double lam_corner, lds_double* lds) {
+// ---- the factorisation of one problem by one wavefront (+ the deferred back substitution of the wave's previous problem) ----------------------
+// lds: WV_LDS_DOUBLES doubles of this wave.  Returns the "all pivots positive" flag and, per lane c < 6, the camera solution x_cam[c];
+// L = block columns [Yb | Y_1 .. Y_8] in P.Lb + W tiles in P.Linv.  When it returns, Q's back substitution is complete (Q.x written).
+__device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double lam_corner, lds_double* lds, const WvPrev& Q, double& xcam_out) {
   asm volatile("" ::: "a0", "a255");   // the accumulator file is ours (the kernel descriptor allocates all of it)
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
@@ -404,12 +574,12 @@ __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, d
   W.lambda = lambda;
   W.lam_corner = lam_corner;
   W.Hc = uni(P.Hc); W.hgl = uni(P.hgather); W.Hbord = uni(P.Hbord); W.Lg = uni(P.Lb); W.Linv = uni(P.Linv);
-  lds_double* wscr = lds + 256 * (WV_LDS_WIN + WV_LDS_BORD);   // 16 x 17 transposition scratch of W
-  lds_double* Cn = wscr + 16 * 17;                              // 7 x 7 corner
-
+  lds_double* wscr = lds + WV_L_WSCR;
+  lds_double* Cn = lds + WV_L_CN;
 #ifdef DSH_LAB
   const long long wv_t0 = clock64();
 #endif
+  if (Q.active) wv_bs_begin(Q, lds, lane);
   WvState S;
 #pragma unroll
   for (int i = 0; i < 9; i++) S.Y[i] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -422,14 +592,7 @@ __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, d
   S.ok = 1;
   wv_prologue_row<0>(W, lds, lane); wv_prologue_row<1>(W, lds, lane); wv_prologue_row<2>(W, lds, lane); wv_prologue_row<3>(W, lds, lane);
   wv_prologue_row<4>(W, lds, lane); wv_prologue_row<5>(W, lds, lane); wv_prologue_row<6>(W, lds, lane); wv_prologue_row<7>(W, lds, lane);
-  {
-    unsigned a0[4];
-    wv_list(W, 8, 8, lane, a0);
-    S.araw = wv_gather_vgpr(W, a0);
-  }
-  wv_row_list(W, 8, lane, S.rl);
-  wv_list(W, 9, 8, lane, S.al);
-  S.bnext = wv_border_fresh(W, 8, lane);
+  wv_list(W, 8, 8, lane, S.al);
   wv_wait_vm();
 #ifdef DSH_LAB
   const long long wv_t1 = clock64();
@@ -438,6 +601,12 @@ __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, d
 #pragma unroll 1
   for (int k = 0; k < W.nT; k++) {
     const int ph = k & 7;
+    // Requests of this step, issued in front of the tile Cholesky (2 us of vector-ALU work: they arrive behind it) and consumed behind the
+    // TRSM -- nothing of them is alive during the trailing update, where the 9 Y tiles and the pipelined LDS tiles need the registers.
+    S.araw = wv_gather_vgpr(W, S.al);            // tile (k+8, k)^T through the list that came a step ahead
+    wv_row_list(W, k + 8, lane, S.rl);
+    S.bnext = wv_border_fresh(W, k + 8, lane);
+    wv_list(W, k + 9, 8, lane, S.al);
     v4d d;
     switch (ph) {
       case 0: d = wv_step_diag<0>(W, k, lane); break;
@@ -466,17 +635,20 @@ __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, d
       for (int q = 0; q < 4; q++) Wt[q] = wscr[c * 17 + g + 4 * q];
     }
     switch (ph) {
-      case 0: wv_step_rest<0>(W, S, Wt, k, lds, lane); break;
-      case 1: wv_step_rest<1>(W, S, Wt, k, lds, lane); break;
-      case 2: wv_step_rest<2>(W, S, Wt, k, lds, lane); break;
-      case 3: wv_step_rest<3>(W, S, Wt, k, lds, lane); break;
-      case 4: wv_step_rest<4>(W, S, Wt, k, lds, lane); break;
-      case 5: wv_step_rest<5>(W, S, Wt, k, lds, lane); break;
-      case 6: wv_step_rest<6>(W, S, Wt, k, lds, lane); break;
-      default: wv_step_rest<7>(W, S, Wt, k, lds, lane); break;
+      case 0: wv_step_rest<0>(W, S, Wt, k, lds, lane, Q); break;
+      case 1: wv_step_rest<1>(W, S, Wt, k, lds, lane, Q); break;
+      case 2: wv_step_rest<2>(W, S, Wt, k, lds, lane, Q); break;
+      case 3: wv_step_rest<3>(W, S, Wt, k, lds, lane, Q); break;
+      case 4: wv_step_rest<4>(W, S, Wt, k, lds, lane, Q); break;
+      case 5: wv_step_rest<5>(W, S, Wt, k, lds, lane, Q); break;
+      case 6: wv_step_rest<6>(W, S, Wt, k, lds, lane, Q); break;
+      default: wv_step_rest<7>(W, S, Wt, k, lds, lane, Q); break;
     }
   }
-
+  // columns of the previous problem's back substitution that are left (it had more tile rows than this one)
+  if (Q.active) {
+    for (int J = Q.nT - 1 - W.nT; J >= 0; J--) { wv_wait_vm(); wv_bs_step(Q, J, lds, lane); }
+  }
 #ifdef DSH_LAB
   const long long wv_t2 = clock64();
 #endif
@@ -487,9 +659,6 @@ __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, d
     const int r = g + 4 * q;
     if (r < SFT_BORDER && c < SFT_BORDER) Cn[r * 7 + c] = S.corner[q];
   }
-#ifdef DSH_LAB
-  if (lane < 49) P.dbg[8 + lane] = Cn[lane];   // the Schur complement of the camera before its Cholesky
-#endif
   double xcam = 0.0;
   {
     int okc = 1;
@@ -517,77 +686,44 @@ __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, d
       for (int kk = 0; kk < 6; kk++) Cn[49 + kk] = xc[kk];
     }
     okc = __builtin_amdgcn_readfirstlane(okc);
-#ifdef DSH_LAB
-    if (lane == 0) P.dbg[4] = okc;
-#endif
     if (!okc) S.ok = 0;
     if (c < 6) xcam = Cn[49 + c];
   }
-  const int ok = __builtin_amdgcn_readfirstlane(S.ok);
-  if (!ok) return 0;     // like g2o, x keeps its previous content when the factorisation failed
-  if (lane < 6) P.x[W.Dnp + lane] = xcam;
-
-  // ---- back substitution.  Column J: S_q = sum_d Y_d[q] x_{J+d}[c] + Yb[q] xb[c] summed over the 16 lanes of a row = (L^T x)_tail + camera
-  // term - y at index g + 4q;  z = -S;  x_J[c] = sum_r W[r][c] z[r].  The border tile is a ninth tile whose "x" is (x_cam, -1, 0..).
-  const double xb = (c < 6) ? xcam : ((c == 6) ? -1.0 : 0.0);
-  double xr[8];          // xr[s]: x of tile row with (row mod 8) == s, element c (every lane group holds the 16 values)
-#pragma unroll
-  for (int s = 0; s < 8; s++) xr[s] = 0.0;
-  struct Col { v4d t[10]; };   // [0] Yb, [1..8] Y_d, [9] W
-  auto fetch = [&](int J) -> Col {
-    Col C;
-    if (J >= 0) {
-      const SFT_G double* col = W.Lg + ((size_t)J * (BT + 1)) * 256 + 4 * lane;
-#pragma unroll
-      for (int i = 0; i <= 8; i++) C.t[i] = (i == 0 || J + i < W.nT) ? *reinterpret_cast<const SFT_G v4d*>(col + 256 * i) : (v4d){0.0, 0.0, 0.0, 0.0};
-      C.t[9] = *reinterpret_cast<const SFT_G v4d*>(W.Linv + (size_t)J * 256 + 4 * lane);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 10; i++) C.t[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-    }
-    return C;
-  };
-  auto solve_col = [&](const Col& C, int J, auto phc) {
-    constexpr int ph = decltype(phc)::value;   // J mod 8
-    double s[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) s[q] = C.t[0][q] * xb;
-#pragma unroll
-    for (int dd = 1; dd <= 8; dd++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) s[q] = fma(C.t[dd][q], xr[(ph + dd) & 7], s[q]);
-    // all-reduce over the 16 lanes of a row (fixed butterfly: row_ror 8, 4, 2, 1)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      s[q] += dpp_mov<0x128>(s[q]);
-      s[q] += dpp_mov<0x124>(s[q]);
-      s[q] += dpp_mov<0x122>(s[q]);
-      s[q] += dpp_mov<0x121>(s[q]);
-    }
-    double p = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) p = fma(C.t[9][q], -s[q], p);
-    p = sum_rows(p);
-    xr[ph] = p;
-    if (lane < TS) P.x[TS * J + lane] = p;
-  };
-  {
-    int J = W.nT - 1;
-    Col c0 = fetch(J), c1 = fetch(J - 1);
-#pragma unroll 1
-    for (; J >= 0; J -= 2) {   // nT is even (Dnp is a multiple of 32)
-      const Col n0 = fetch(J - 2), n1 = fetch(J - 3);
-      switch (J & 7) {
-        case 7: solve_col(c0, J, std::integral_constant<int, 7>{}); solve_col(c1, J - 1, std::integral_constant<int, 6>{}); break;
-        case 5: solve_col(c0, J, std::integral_constant<int, 5>{}); solve_col(c1, J - 1, std::integral_constant<int, 4>{}); break;
-        case 3: solve_col(c0, J, std::integral_constant<int, 3>{}); solve_col(c1, J - 1, std::integral_constant<int, 2>{}); break;
-        default: solve_col(c0, J, std::integral_constant<int, 1>{}); solve_col(c1, J - 1, std::integral_constant<int, 0>{}); break;
-      }
-      c0 = n0; c1 = n1;
-    }
-  }
+  xcam_out = xcam;
 #ifdef DSH_LAB
-  if (lane == 0) { const long long t3 = clock64(); P.dbg[5] = (double)(wv_t1 - wv_t0); P.dbg[6] = (double)(wv_t2 - wv_t1); P.dbg[7] = (double)(t3 - wv_t2); }
+  if (lane == 0) { P.dbg[5] = (double)(wv_t1 - wv_t0); P.dbg[6] = (double)(wv_t2 - wv_t1); }
 #endif
-  return 1;
+  return __builtin_amdgcn_readfirstlane(S.ok);
+}
+
+// what a finished factorisation hands to its (deferred or immediate) back substitution; like g2o, x keeps its previous content when the
+// factorisation failed (ok == 0: nothing is written)
+__device__ __forceinline__ WvPrev wv_prev_of(const SftDev& P, int ok, double xcam, int lane) {
+  const int c = lane & 15;
+  WvPrev Q;
+  const int Dn = uni(P.Dn), Dnp = ((Dn + NB - 1) / NB) * NB;
+  Q.Lg = uni(P.Lb); Q.Linv = uni(P.Linv); Q.x = uni(P.x);
+  Q.nT = Dnp / TS;
+  Q.active = ok;
+  Q.xb = (c < 6) ? xcam : ((c == 6) ? -1.0 : 0.0);
+  if (ok && lane < 6) P.x[Dnp + lane] = xcam;
+  return Q;
+}
+
+// factorisation + back substitution of one problem right away (lab A/B kernel)
+__device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, double lam_corner, lds_double* lds) {
+  const int lane = threadIdx.x & 63;
+  WvPrev none;
+  none.Lg = nullptr; none.Linv = nullptr; none.x = nullptr; none.nT = 0; none.active = 0; none.xb = 0.0;
+  double xcam;
+  const int ok = wv_factor(P, lambda, lam_corner, lds, none, xcam);
+  const WvPrev Q = wv_prev_of(P, ok, xcam, lane);
+#ifdef DSH_LAB
+  const long long t2 = clock64();
+#endif
+  if (ok) wv_backsub_now(Q, lane);
+#ifdef DSH_LAB
+  if (lane == 0) P.dbg[7] = (double)(clock64() - t2);
+#endif
+  return ok;
 }
