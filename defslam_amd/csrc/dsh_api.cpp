@@ -242,11 +242,13 @@ int graph_for(dsh_ctx* c, const std::vector<uint8_t>& opt, dsh::SftGraph** out, 
     o.str_nodes = reserve(a, g->str_nodes); o.str_L0 = reserve(a, g->str_L0); o.off_ptr = reserve(a, g->off_ptr); o.off_rc = reserve(a, g->off_rc);
     o.sh_ptr = reserve(a, g->sh_ptr); o.sh_rec = reserve(a, g->sh_rec); o.sh_cf = reserve(a, g->sh_cf); o.tmask = reserve(a, g->tmask);
     o.hgather = reserve(a, g->hgather);
+    o.hgatherT = reserve(a, g->hgatherT);
     std::vector<char> st(a.size, 0);
     put(st.data(), o.act, g->act); put(st.data(), o.actnode, g->actnode); put(st.data(), o.star_node, g->star_node); put(st.data(), o.star_sL, g->star_sL);
     put(st.data(), o.str_nodes, g->str_nodes); put(st.data(), o.str_L0, g->str_L0); put(st.data(), o.off_ptr, g->off_ptr); put(st.data(), o.off_rc, g->off_rc);
     put(st.data(), o.sh_ptr, g->sh_ptr); put(st.data(), o.sh_rec, g->sh_rec); put(st.data(), o.sh_cf, g->sh_cf); put(st.data(), o.tmask, g->tmask);
     put(st.data(), o.hgather, g->hgather);
+    put(st.data(), o.hgatherT, g->hgatherT);
     if (hipMalloc((void**)&g->d_base, a.size) != hipSuccess) { err = "out of device memory (graph)"; return DSH_ERR_HIP; }
     g->d_bytes = a.size;
     if (hipMemcpy(g->d_base, st.data(), a.size, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(g->d_base); err = "graph upload failed"; return DSH_ERR_HIP; }
@@ -701,6 +703,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     h.off_ptr = (const int32_t*)(gb + g.o.off_ptr); h.off_rc = (const int32_t*)(gb + g.o.off_rc); h.sh_ptr = (const int32_t*)(gb + g.o.sh_ptr);
     h.sh_rec = (const uint32_t*)(gb + g.o.sh_rec); h.sh_cf = (const double*)(gb + g.o.sh_cf); h.tmask = (const int32_t*)(gb + g.o.tmask);
     h.hgather = (const uint32_t*)(gb + g.o.hgather);
+    h.hgatherT = (const uint32_t*)(gb + g.o.hgatherT);
     h.obs_nodes = (const int32_t*)(base + o.obs_nodes); h.obs_bary = (const double*)(base + o.obs_bary);
     h.obs_uv = (const double*)(base + o.obs_uv); h.obs_w = (const double*)(base + o.obs_w);
     h.ob_ptr = (const int32_t*)(base + o.ob_ptr); h.ob_m = (const int32_t*)(base + o.ob_m); h.ob_c = (const double*)(base + o.ob_c);

@@ -210,10 +210,12 @@ int build_graph(const TemplateHost& t, const std::vector<uint8_t>& opt, SftGraph
     g.max_slots = 0;
     for (int I = 0; I < nT_; I++) g.max_slots = std::max(g.max_slots, __builtin_popcount((unsigned)g.tmask[I]));
     g.hgather.clear();
+    g.hgatherT.clear();
     if (g.kd <= kTS * 8) {   // register-window solver: the gather lists of its tiles (sft_pack.h)
       if (9 * (size_t)(nA + noff) + 2 >= (1u << 28)) { err = "template too large for the 32-bit gather offsets"; return DSH_ERR_ARG; }
       const uint32_t ZERO = (uint32_t)(8 * 9 * (size_t)(nA + noff)), ONE = ZERO + 8;   // byte offsets into Hc
       g.hgather.assign((size_t)(nT_ + 1) * 9 * 256, ZERO);
+      g.hgatherT.assign((size_t)(nT_ + 1) * 9 * 256, ZERO);
       auto elem = [&](int r, int c) -> uint32_t {   // element (r, c) of the symmetric matrix, r, c < Dn_
         int bi = r / 3, bj = c / 3, er = r % 3, ec = c % 3;
         if (bj > bi) { std::swap(bi, bj); std::swap(er, ec); }
@@ -234,6 +236,12 @@ int build_graph(const TemplateHost& t, const std::vector<uint8_t>& opt, SftGraph
             for (int q = 0; q < 4; q++) {
               const int r = kTS * I + (l >> 4) + 4 * q, c = kTS * (I - d) + (l & 15);
               tl[4 * l + q] = (r >= Dn_ || c >= Dn_) ? (r == c ? ONE : ZERO) : elem(r, c);
+            }
+          uint32_t* tt = g.hgatherT.data() + ((size_t)I * 9 + d) * 256;
+          for (int l = 0; l < 64; l++)
+            for (int q = 0; q < 4; q++) {
+              const int r = kTS * I + (l & 15), c = kTS * (I - d) + (l >> 4) + 4 * q;
+              tt[4 * l + q] = (r >= Dn_ || c >= Dn_) ? (r == c ? ONE : ZERO) : elem(r, c);
             }
         }
     }

@@ -43,13 +43,14 @@ struct SftGraph {
   // each (lane, register) of the MFMA accumulator layout takes -- 256 entries, entry 4 * lane + q = element (row (lane >> 4) + 4 q,
   // column lane & 15); the factorisation gathers its tiles through it, the padded tile form never exists in memory.
   std::vector<uint32_t> hgather;
+  std::vector<uint32_t> hgatherT;   // the same lists for the TRANSPOSED tile (one-wavefront solver, sft_wave.h): lane (g, c), register q takes element [row c][column g + 4q]
   size_t hc_elems() const { return 9 * (size_t)(nA + noff) + 2; }
   int nblk() const { return nA + noff; }
   uint64_t last_use = 0;             // serial of the last upload that used the graph (cache eviction)
   // device copy (owned by the context)
   char* d_base = nullptr;
   size_t d_bytes = 0;
-  struct { size_t act, actnode, star_node, star_sL, str_nodes, str_L0, off_ptr, off_rc, sh_ptr, sh_rec, sh_cf, tmask, hgather; } o{};
+  struct { size_t act, actnode, star_node, star_sL, str_nodes, str_L0, off_ptr, off_rc, sh_ptr, sh_rec, sh_cf, tmask, hgather, hgatherT; } o{};
 };
 
 // Node degree limit of the device kernels (slot fields of SFT_REC are 4 bits: centre + 14 neighbours).

@@ -155,6 +155,7 @@ struct SftDev {
   const SFT_G uint32_t* sh_rec;   // SFT_REC
   const SFT_G double* sh_cf;      // 2 per contribution: H and b factors without the regulariser weight
   const SFT_G int32_t* tmask;     // tile mode 1: per tile row I (nT + SFT_H_PAD_TILE_ROWS entries) bit d set if tile (I, I-d) holds any element of H
+  const SFT_G uint32_t* hgatherT; // tile mode 1: the same lists for the transposed tile, lane (g, c), register q: element [row c][column g + 4q] (sft_wave.h)
   const SFT_G uint32_t* hgather;  // tile mode 1: the element of Hc every (lane, register) of tile (I, I-d) takes: ((I*9 + d)*64 + lane)*4 + q (sft_pack.h)
   // frame
   const SFT_G int32_t* obs_nodes; // M*3

@@ -25,6 +25,23 @@
 // The 7 camera / right-hand-side rows ride along as border tiles Bd(J)^T (16 x 7) with the same two formulas, the corner as Yb^T Yb.
 #pragma once
 
+// Section timers of a factorisation (shader clock, accumulated over the steps of problem; lab builds with EXTRA=-DWV_STEP_TRACE): P.dbg[40 + e],
+// e = 0 head requests + diagonal read, 1 tile Cholesky, 2 W transposition, 3 TRSM, 4 L stores + row fetch, 5 corner + rows 1-7 + first LDS run,
+// 6 wait for memory, 7 deferred back substitution column, 8 row 8 + second LDS run
+#if defined(WV_STEP_TRACE) && defined(DSH_LAB)
+#define WV_T_DECL long long wv_tr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wv_tl = clock64()
+#define WV_T(e) do { const long long t__ = clock64(); wv_tr[e] += t__ - wv_tl; wv_tl = t__; } while (0)
+#define WV_T_ARG , long long (&wv_tr)[9], long long& wv_tl
+#define WV_T_PASS , wv_tr, wv_tl
+#define WV_T_DUMP(P) do { if ((threadIdx.x & 63) == 0) for (int e__ = 0; e__ < 9; e__++) (P).dbg[40 + e__] = (double)wv_tr[e__]; } while (0)
+#else
+#define WV_T_DECL do {} while (0)
+#define WV_T(e) do {} while (0)
+#define WV_T_ARG
+#define WV_T_PASS
+#define WV_T_DUMP(P) do {} while (0)
+#endif
+
 // ---- physical tile of window tile (ring row r = I mod 8, d = I - J in 0..7) ------------------------------------------------------
 __host__ __device__ constexpr int wv_phys(int r, int d) {
   return d == 0 ? r : (d <= 3 ? 8 * d + r : (d == 4 ? 32 + (r & 3) : 8 * (8 - d) + ((r + 8 - d) & 7)));
@@ -49,7 +66,7 @@ using lds_v2d = __attribute__((address_space(3))) v2d_w;
 template <int T>
 __device__ __forceinline__ void wv_upd_agpr(const v4d& A, const v4d& B, int q0 = 0) {   // a[T] -= A^T-chunks x B-chunks
   static_assert(T >= 0 && T < WV_AGPR_TILES, "accumulator tile");
-#define WV_MF(q) asm volatile("v_mfma_f64_16x16x4_f64 a[%c0:%c1], %2, %3, a[%c0:%c1] neg:[1,0,0]" ::"i"(8 * T), "i"(8 * T + 7), "v"(A[q]), "v"(B[q]))
+#define WV_MF(q) asm volatile("v_mfma_f64_16x16x4_f64 a[%c0:%c1], %2, %3, a[%c0:%c1] neg:[1,0,0]" ::"i"(8 * T), "i"(8 * T + 7), "v"(A[q]), "v"(B[q]) : "memory")
   if (q0 <= 0) WV_MF(0);
   if (q0 <= 1) WV_MF(1);
   if (q0 <= 2) WV_MF(2);
@@ -125,6 +142,11 @@ __device__ __forceinline__ void wv_gather_agpr(const SFT_G double* base, unsigne
                : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "i"(8 * T), "i"(8 * T + 1), "i"(8 * T + 2), "i"(8 * T + 3), "i"(8 * T + 4), "i"(8 * T + 5),
                  "i"(8 * T + 6), "i"(8 * T + 7)
                : "memory");
+}
+// one register (8 bytes per lane) of it: the gathers of a row are issued one at a time between the MFMAs of the update
+template <int T, int Q>
+__device__ __forceinline__ void wv_gather1_agpr(const SFT_G double* base, unsigned off) {
+  asm volatile("global_load_dwordx2 a[%c2:%c3], %0, %1" : : "v"(off), "s"(base), "i"(8 * T + 2 * Q), "i"(8 * T + 2 * Q + 1) : "memory");
 }
 __device__ __forceinline__ void wv_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -226,19 +248,20 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
 struct WvProb {
   int Dn, Dnp, nT, q8;                    // q8: leading row chunks of the d = 8 corner tile that are structurally zero (kd = 122: 1)
   double lambda, lam_corner;
+  unsigned bofs;                          // per lane: c * Dnp + g, the lane's element of a border tile relative to column 16 J (doubles)
   const SFT_G double* Hc;
-  const SFT_G uint32_t* hgl;
+  const SFT_G uint32_t* hgl;              // the TRANSPOSED gather lists (SftDev::hgatherT): 16 bytes per lane and tile
   const SFT_G double* Hbord;
   SFT_G double *Lg, *Linv;
 };
 
-// gather list of tile (I, d) for the TRANSPOSED tile: lane (g, c), register q takes element [row c][column g + 4q] of H(I, I-d), i.e. the
-// entry the packer wrote for lane (c & 3) * 16 + g + 4q, register c >> 2.  Rows behind the matrix take the all-zero list row nT.
+// gather list of tile (I, d) (transposed lists: lane (g, c), register q takes element [row c][column g + 4q] of H(I, I-d)): one 16-byte load
+// per lane, wave-uniform base + lane * 16.  Rows behind the matrix take the all-zero list row nT.
+typedef unsigned v4u_w __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wv_list(const WvProb& W, int I, int d, int lane, unsigned (&o)[4]) {
-  const int g = lane >> 4, c = lane & 15;
-  const SFT_G uint32_t* row = W.hgl + ((size_t)(I < W.nT ? I : W.nT) * (BT + 1) + d) * 256;
-#pragma unroll
-  for (int q = 0; q < 4; q++) o[q] = row[4 * ((c & 3) * 16 + g + 4 * q) + (c >> 2)];
+  const SFT_G v4u_w* row = reinterpret_cast<const SFT_G v4u_w*>(W.hgl + ((size_t)(I < W.nT ? I : W.nT) * (BT + 1) + d) * 256);
+  const v4u_w v = row[lane];
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 __device__ __forceinline__ v4d wv_gather_vgpr(const WvProb& W, const unsigned (&o)[4]) {
   const auto b8 = reinterpret_cast<const SFT_G char*>(W.Hc);
@@ -249,12 +272,12 @@ __device__ __forceinline__ v4d wv_gather_vgpr(const WvProb& W, const unsigned (&
 }
 // border tile Bd(J)^T from the 8-row border of H (rows 0-5 camera, 6 right-hand side, 7 zero): lane (g, c), register q = Hbord[c][16 J + g + 4q]
 __device__ __forceinline__ v4d wv_border_fresh(const WvProb& W, int J, int lane) {
-  const int g = lane >> 4, c = lane & 15;
+  const int c = lane & 15;
   v4d v = {0.0, 0.0, 0.0, 0.0};
   if (c < 8 && J < W.nT) {
-    const SFT_G double* p = W.Hbord + (size_t)c * W.Dnp + TS * J + g;
+    const SFT_G double* p = W.Hbord + TS * J;
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = p[4 * q];
+    for (int q = 0; q < 4; q++) v[q] = p[W.bofs + 4 * q];
   }
   return v;
 }
@@ -427,22 +450,53 @@ __device__ __forceinline__ void wv_trsm_cols(WvState& S, const v4d& Wt, int k, i
   }
 }
 
-// window tiles (k+I, k+J), 1 <= J <= I, that live in the accumulator file (the d = 4 tiles: wv_lds_pipe)
+// window tiles (k+I, k+J), 1 <= J <= I, that live in the accumulator file (the d = 4 tiles: wv_lds_pipe).  Behind the n-th tile of rows
+// 1..7 one 1 KB half of block column k of L is stored (18 halves: Yb, Y_1 .. Y_8) -- a wave has 63 memory operations in flight at most,
+// and stores retire slowly when HBM is busy: issued as one burst behind the TRSM (with the 36 gathers of the entering row) they stalled the
+// in-order instruction stream, MFMAs included, for thousands of cycles per step; one at a time between MFMAs they cost nothing.
+__host__ __device__ constexpr int wv_tile_index(int I, int J) {   // rank of (I, J) among the accumulator-file tiles of rows 1..7, row-major
+  int n = 0;
+  for (int i = 1; i <= 7; i++)
+    for (int j = 1; j <= i; j++) {
+      if (i == I && j == J) return n;
+      if (i - j != 4) n++;
+    }
+  return n;
+}
+// request number SLOT (0..27) of the row that enters the window: register SLOT % 4 of its accumulator-file tile number SLOT / 4 (d = 0..3, 5..7)
+template <int PH, int SLOT>
+__device__ __forceinline__ void wv_fetch_slot(const WvProb& W, const WvRowList& L) {
+  if constexpr (SLOT < 28) {
+    constexpr int t = SLOT / 4, q = SLOT % 4, d = t < 4 ? t : t + 1;
+    wv_gather1_agpr<wv_phys(PH, d), q>(W.Hc, L.o[d][q]);
+  }
+}
 template <int PH, int I, int J>
-__device__ __forceinline__ void wv_update_tiles(WvState& S, int k, int nT, int q8) {
+__device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int k, int nT, int q8, SFT_G double* col) {
   if constexpr (I <= 8) {
     constexpr int d = I - J, r = (PH + I) & 7;
     if constexpr (d != 4) {
       if (k + I < nT) wv_upd_agpr<wv_phys(r, d)>(S.Y[J], S.Y[I], (I == 8) ? q8 : 0);
+      if constexpr (I <= 7) {
+        constexpr int n = wv_tile_index(I, J);
+        if constexpr (n < 18) {   // half (n & 1) of tile n / 2: lanes' registers 2 (n & 1), 2 (n & 1) + 1
+          const v4d& y = S.Y[n >> 1];
+          *reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+        }
+        // ... and two of the 28 gathers of the row that enters the window (the tiles of ring row PH are free since the TRSM): like the
+        // stores, one burst of them holds up the instruction stream (each scattered 8-byte load keeps the address unit busy ~100 cycles)
+        wv_fetch_slot<PH, 2 * n>(W, S.rl);
+        wv_fetch_slot<PH, 2 * n + 1>(W, S.rl);
+      }
     }
-    if constexpr (J < I) wv_update_tiles<PH, I, J + 1>(S, k, nT, q8);
+    if constexpr (J < I) wv_update_tiles<PH, I, J + 1>(W, S, k, nT, q8, col);
   }
 }
 template <int PH, int I0, int I1>
-__device__ __forceinline__ void wv_update_rows(WvState& S, int k, int nT, int q8) {
+__device__ __forceinline__ void wv_update_rows(const WvProb& W, WvState& S, int k, int nT, int q8, SFT_G double* col) {
   if constexpr (I0 <= I1) {
-    wv_update_tiles<PH, I0, 1>(S, k, nT, q8);
-    wv_update_rows<PH, I0 + 1, I1>(S, k, nT, q8);
+    wv_update_tiles<PH, I0, 1>(W, S, k, nT, q8, col);
+    wv_update_rows<PH, I0 + 1, I1>(W, S, k, nT, q8, col);
   }
 }
 // The LDS-resident tiles of a step as a list of tasks: T = 0..6 border tiles Bd(k+T+1)^T, T = 7, 8, 9 the d = 4 window tiles of rows 5, 6, 7
@@ -473,14 +527,17 @@ __device__ __forceinline__ void wv_task_mfma(v4d& C, const WvState& S, int q8) {
   else if constexpr (T == 10) wv_upd_vgpr(C, S.Y[8], S.Y[0], q8);
   else wv_upd_vgpr(C, S.Y[4], S.Y[8], q8);
 }
+// C: tile T, already loaded; Cprev: tile T-1, its MFMAs issued.  The load of tile T+1 is requested in front of T's MFMAs.
 template <int PH, int T, int TEND>
-__device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_double* lds, int lane, const v4d& Cprev) {
-  v4d C = wv_task_load<PH, T>(lds, lane);
-  wv_task_mfma<T>(C, S, q8);
-  wv_task_store<PH, T - 1>(lds, lane, Cprev);
+__device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_double* lds, int lane, v4d& C, const v4d& Cprev) {
   if constexpr (T < TEND) {
-    wv_lds_pipe_next<PH, T + 1, TEND>(S, q8, lds, lane, C);
+    v4d Cn = wv_task_load<PH, T + 1>(lds, lane);
+    wv_task_mfma<T>(C, S, q8);
+    wv_task_store<PH, T - 1>(lds, lane, Cprev);
+    wv_lds_pipe_next<PH, T + 1, TEND>(S, q8, lds, lane, Cn, C);
   } else {
+    wv_task_mfma<T>(C, S, q8);
+    wv_task_store<PH, T - 1>(lds, lane, Cprev);
     wv_mfma_fence();
     wv_task_store<PH, T>(lds, lane, C);
   }
@@ -488,8 +545,9 @@ __device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_d
 template <int PH, int T0, int TEND>
 __device__ __forceinline__ void wv_lds_pipe(const WvState& S, int q8, lds_double* lds, int lane) {
   v4d C = wv_task_load<PH, T0>(lds, lane);
+  v4d Cn = wv_task_load<PH, T0 + 1>(lds, lane);
   wv_task_mfma<T0>(C, S, q8);
-  wv_lds_pipe_next<PH, T0 + 1, TEND>(S, q8, lds, lane, C);
+  wv_lds_pipe_next<PH, T0 + 1, TEND>(S, q8, lds, lane, Cn, C);
 }
 
 // Part A of a step (before the tile Cholesky): the diagonal tile of column k out of the accumulator file, damped.
@@ -505,7 +563,7 @@ __device__ __forceinline__ v4d wv_step_diag(const WvProb& W, int k, int lane) {
 
 // Part B (behind the tile Cholesky): TRSM of block column k, the row that enters the window, the trailing update.
 template <int PH>
-__device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& Wt, int k, lds_double* lds, int lane, const WvPrev& Q) {
+__device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& Wt, int k, lds_double* lds, int lane, const WvPrev& Q WV_T_ARG) {
   lds_double* ldsw = lds + WV_L_WIN;
   lds_double* ldsb = lds + WV_L_BORD;
   const int nT = W.nT;
@@ -518,34 +576,42 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
     wv_trsm_vgpr(S.Y[0], Wt, Bk);
   }
   wv_mfma_fence();
-  // L leaves from the registers it was computed in: block column k = [Yb | Y_1 .. Y_8] at slots (k, 0..8), 2 KB each
-  {
-    SFT_G double* col = W.Lg + ((size_t)k * (BT + 1)) * 256 + 4 * lane;
-#pragma unroll
-    for (int i = 0; i <= 8; i++)
-      if (i == 0 || k + i < nT) *reinterpret_cast<SFT_G v4d*>(col + 256 * i) = S.Y[i];
-  }
+  WV_T(3);
+  // L leaves from the registers it was computed in: block column k = [Yb | Y_1 .. Y_8] at slots (k, 0..8), 2 KB each (lane l: 32 bytes at
+  // 32 l) -- stored half by half between the MFMAs of the update below (wv_update_tiles); tiles behind the matrix are stored as the
+  // zeros they are
+  SFT_G double* col = W.Lg + ((size_t)k * (BT + 1)) * 256 + 4 * lane;
   // ---- the ring row / border slot of column k are free: row k+8 enters (its lists came a step ahead), the lists of row k+9 are requested
-  v4d fresh4;
-  wv_row_fetch_d<PH, 0>(W, S.rl, 7, fresh4);
+  v4d fresh4 = wv_gather_vgpr(W, S.rl.o[4]);   // (the accumulator-file tiles of the row: wv_update_tiles)
   wv_bord_store(ldsb + 128 * PH, lane, S.bnext);
+  WV_T(4);
   // ---- trailing update: corner, rows 1..7, the LDS tiles of the first half; then (everything requested has landed) the deferred back
   // substitution's column, row 8 and the LDS tiles of the second half
   wv_upd_vgpr(S.corner, S.Y[0], S.Y[0]);
-  wv_update_rows<PH, 1, 7>(S, k, nT, W.q8);
+  wv_update_rows<PH, 1, 7>(W, S, k, nT, W.q8, col);
   wv_lds_pipe<PH, 0, 9>(S, W.q8, lds, lane);
+  WV_T(5);
   wv_wait_vm();
+  WV_T(6);
   if (Q.active) {
     const int J = Q.nT - 1 - k;
     if (J >= 0) wv_bs_step(Q, J, lds, lane);
   }
-  wv_lds_store(ldsw + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, fresh4);   // tile (k+8, k+4)
-  wv_update_rows<PH, 8, 8>(S, k, nT, W.q8);
-  wv_lds_pipe<PH, 10, 11>(S, W.q8, lds, lane);
+  WV_T(7);
+  {   // second half: border tile Bd(k+8)^T and window tile (k+8, k+4) -- the latter straight from the registers it was fetched into
+    v4d C10 = wv_task_load<PH, 10>(lds, lane);
+    wv_update_rows<PH, 8, 8>(W, S, k, nT, W.q8, col);
+    wv_task_mfma<10>(C10, S, W.q8);
+    wv_task_mfma<11>(fresh4, S, W.q8);
+    wv_task_store<PH, 10>(lds, lane, C10);
+    wv_mfma_fence();
+    wv_task_store<PH, 11>(lds, lane, fresh4);
+  }
   // The corner's MFMAs were issued at the head of the update: it is long complete here.  This empty statement takes the corner as an
   // operand, so any register copy the compiler makes of it (the merge of the eight phase bodies) sits BEHIND the whole update -- a copy
   // right behind the MFMA statement would read the registers before the matrix pipe has written them (no hazard padding around asm).
   asm volatile("" : "+v"(S.corner));
+  WV_T(8);
 }
 
 // prologue: tile rows 0..7 of H into the window
@@ -573,7 +639,8 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   W.q8 = min(3, max(0, (TS * BT - uni(P.kd)) / 4));
   W.lambda = lambda;
   W.lam_corner = lam_corner;
-  W.Hc = uni(P.Hc); W.hgl = uni(P.hgather); W.Hbord = uni(P.Hbord); W.Lg = uni(P.Lb); W.Linv = uni(P.Linv);
+  W.bofs = (unsigned)(c * W.Dnp + g);
+  W.Hc = uni(P.Hc); W.hgl = uni(P.hgatherT); W.Hbord = uni(P.Hbord); W.Lg = uni(P.Lb); W.Linv = uni(P.Linv);
   lds_double* wscr = lds + WV_L_WSCR;
   lds_double* Cn = lds + WV_L_CN;
 #ifdef DSH_LAB
@@ -598,6 +665,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   const long long wv_t1 = clock64();
 #endif
 
+  WV_T_DECL;
 #pragma unroll 1
   for (int k = 0; k < W.nT; k++) {
     const int ph = k & 7;
@@ -618,6 +686,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
       case 6: d = wv_step_diag<6>(W, k, lane); break;
       default: d = wv_step_diag<7>(W, k, lane); break;
     }
+    WV_T(0);
     v4d w;
     if (!wv_chol_inv(d, w)) {
 #ifdef DSH_LAB
@@ -625,6 +694,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
 #endif
       S.ok = 0;
     }
+    WV_T(1);
     *reinterpret_cast<SFT_G v4d*>(W.Linv + (size_t)k * 256 + 4 * lane) = w;
     // W^T in accumulator order: through LDS (element [row][col] at row * 17 + col)
     v4d Wt;
@@ -634,17 +704,19 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
 #pragma unroll
       for (int q = 0; q < 4; q++) Wt[q] = wscr[c * 17 + g + 4 * q];
     }
+    WV_T(2);
     switch (ph) {
-      case 0: wv_step_rest<0>(W, S, Wt, k, lds, lane, Q); break;
-      case 1: wv_step_rest<1>(W, S, Wt, k, lds, lane, Q); break;
-      case 2: wv_step_rest<2>(W, S, Wt, k, lds, lane, Q); break;
-      case 3: wv_step_rest<3>(W, S, Wt, k, lds, lane, Q); break;
-      case 4: wv_step_rest<4>(W, S, Wt, k, lds, lane, Q); break;
-      case 5: wv_step_rest<5>(W, S, Wt, k, lds, lane, Q); break;
-      case 6: wv_step_rest<6>(W, S, Wt, k, lds, lane, Q); break;
-      default: wv_step_rest<7>(W, S, Wt, k, lds, lane, Q); break;
+      case 0: wv_step_rest<0>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 1: wv_step_rest<1>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 2: wv_step_rest<2>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 3: wv_step_rest<3>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 4: wv_step_rest<4>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 5: wv_step_rest<5>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 6: wv_step_rest<6>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      default: wv_step_rest<7>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
     }
   }
+  WV_T_DUMP(P);
   // columns of the previous problem's back substitution that are left (it had more tile rows than this one)
   if (Q.active) {
     for (int J = Q.nT - 1 - W.nT; J >= 0; J--) { wv_wait_vm(); wv_bs_step(Q, J, lds, lane); }
