@@ -161,25 +161,21 @@ __device__ __forceinline__ void wv_lds_store(lds_double* tile, int lane, const v
   p[lane] = (v2d_w){v[0], v[1]};
   p[64 + lane] = (v2d_w){v[2], v[3]};
 }
-// border tiles: only the lanes c < 8 carry data (the update leaves the other columns of the accumulator at zero: the B operand Yb is
-// zero there), so the LDS image keeps 32 lanes -- half the bytes, which is what makes room for the landing buffer
+// border tiles: 7 columns (+ a zero one) carry data.  The LDS image keeps the 32 lanes c < 8 -- half the bytes, which is what makes room for
+// the landing buffer -- and the lanes c >= 8 MIRROR the lanes c - 8 (same address): every lane holds finite numbers without a zero fill or
+// an execution mask, the duplicate columns ride through TRSM and update untouched by anything that is read (corner: rows / columns < 7;
+// back substitution: multiplied by xb = 0), and the duplicate lanes store the same values to the same place.
 __device__ __forceinline__ v4d wv_bord_load(const lds_double* tile, int lane) {
-  const int g = lane >> 4, c = lane & 15;
-  v4d v = {0.0, 0.0, 0.0, 0.0};
-  if (c < 8) {
-    const lds_v2d* p = reinterpret_cast<const lds_v2d*>(tile);
-    const v2d_w a = p[g * 8 + c], b = p[32 + g * 8 + c];
-    v = (v4d){a.x, a.y, b.x, b.y};
-  }
-  return v;
+  const int li = (lane >> 4) * 8 + (lane & 7);
+  const lds_v2d* p = reinterpret_cast<const lds_v2d*>(tile);
+  const v2d_w a = p[li], b = p[32 + li];
+  return (v4d){a.x, a.y, b.x, b.y};
 }
 __device__ __forceinline__ void wv_bord_store(lds_double* tile, int lane, const v4d& v) {
-  const int g = lane >> 4, c = lane & 15;
-  if (c < 8) {
-    lds_v2d* p = reinterpret_cast<lds_v2d*>(tile);
-    p[g * 8 + c] = (v2d_w){v[0], v[1]};
-    p[32 + g * 8 + c] = (v2d_w){v[2], v[3]};
-  }
+  const int li = (lane >> 4) * 8 + (lane & 7);
+  lds_v2d* p = reinterpret_cast<lds_v2d*>(tile);
+  p[li] = (v2d_w){v[0], v[1]};
+  p[32 + li] = (v2d_w){v[2], v[3]};
 }
 
 // ---- 16 x 16 Cholesky + inverse, every MFMA as asm on VGPR tiles (tile_chol.h: chol_inv_blocked is the compiler-scheduled original) --
@@ -272,13 +268,10 @@ __device__ __forceinline__ v4d wv_gather_vgpr(const WvProb& W, const unsigned (&
 }
 // border tile Bd(J)^T from the 8-row border of H (rows 0-5 camera, 6 right-hand side, 7 zero): lane (g, c), register q = Hbord[c][16 J + g + 4q]
 __device__ __forceinline__ v4d wv_border_fresh(const WvProb& W, int J, int lane) {
-  const int c = lane & 15;
-  v4d v = {0.0, 0.0, 0.0, 0.0};
-  if (c < 8 && J < W.nT) {
-    const SFT_G double* p = W.Hbord + TS * J;
+  v4d v;
+  const SFT_G double* p = W.Hbord + TS * (J < W.nT ? J : W.nT);   // (behind the matrix: the zero padding of the border rows; lanes c >= 8 mirror c - 8)
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = p[W.bofs + 4 * q];
-  }
+  for (int q = 0; q < 4; q++) v[q] = p[W.bofs + 4 * q];
   return v;
 }
 
@@ -583,6 +576,9 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
   SFT_G double* col = W.Lg + ((size_t)k * (BT + 1)) * 256 + 4 * lane;
   // ---- the ring row / border slot of column k are free: row k+8 enters (its lists came a step ahead), the lists of row k+9 are requested
   v4d fresh4 = wv_gather_vgpr(W, S.rl.o[4]);   // (the accumulator-file tiles of the row: wv_update_tiles)
+  // A value that is only loaded and stored may be allocated to the accumulator file by the compiler (memory instructions address it) --
+  // onto a window tile.  Naming it as a VGPR operand where it is consumed keeps it out (tools/wave_audit.py checks the ISA for such accesses).
+  asm volatile("" : "+v"(S.bnext));
   wv_bord_store(ldsb + 128 * PH, lane, S.bnext);
   WV_T(4);
   // ---- trailing update: corner, rows 1..7, the LDS tiles of the first half; then (everything requested has landed) the deferred back
@@ -639,7 +635,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   W.q8 = min(3, max(0, (TS * BT - uni(P.kd)) / 4));
   W.lambda = lambda;
   W.lam_corner = lam_corner;
-  W.bofs = (unsigned)(c * W.Dnp + g);
+  W.bofs = (unsigned)((c & 7) * W.Dnp + g);
   W.Hc = uni(P.Hc); W.hgl = uni(P.hgatherT); W.Hbord = uni(P.Hbord); W.Lg = uni(P.Lb); W.Linv = uni(P.Linv);
   lds_double* wscr = lds + WV_L_WSCR;
   lds_double* Cn = lds + WV_L_CN;

@@ -12,11 +12,13 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-want = sys.argv[1] if len(sys.argv) > 1 else "sft_wave_solve_kernel"
-extra = sys.argv[2:]   # e.g. -UDSH_LAB
+args = [a for a in sys.argv[1:] if a != "--product"]
+product = "--product" in sys.argv[1:]      # audit the code of libdefslam_hip.so (no -DDSH_LAB) instead of the lab build
+want = args[0] if args else ("sftb_factor_kernel" if product else "sft_wave_solve_kernel")
+extra = args[1:]
 out = os.path.join(tempfile.gettempdir(), "wave_audit.s")
-subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-w", "--offload-arch=gfx950", "-DDSH_LAB", "--cuda-device-only", "-S",
-                       os.path.join(ROOT, "defslam_amd", "csrc", "sft_kernels.hip"), "-o", out] + extra)
+subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-w", "--offload-arch=gfx950"] + ([] if product else ["-DDSH_LAB"]) +
+                      ["--cuda-device-only", "-S", os.path.join(ROOT, "defslam_amd", "csrc", "sft_kernels.hip"), "-o", out] + extra)
 txt = open(out).read().split("\n")
 start = next(i for i, l in enumerate(txt) if re.match(r"^_Z\S*" + re.escape(want) + r"\S*:", l))
 end = next(i for i in range(start, len(txt)) if ".end_amdhsa_kernel" in txt[i])
@@ -67,14 +69,16 @@ for n, (i, a, t) in enumerate(stream):
             if regs(dst) & read:
                 bad3.append((i, t2, t))
         states += 1
-meta = {k: None for k in (".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size", ".vgpr_count", ".agpr_count", ".sgpr_count")}
-for l in txt:
-    for k in meta:
-        if k + ":" in l and want in "".join(txt[max(0, txt.index(l) - 40):txt.index(l) + 40]):
-            meta[k] = l.split(":")[1].strip()
+meta = {}
+for l in txt[start:end + 60]:
+    m = re.match(r"\s*\.amdhsa_(next_free_vgpr|accum_offset|private_segment_fixed_size|next_free_sgpr)\s+(\d+)", l)
+    if m:
+        meta[m.group(1)] = int(m.group(2))
+scratch = sum(1 for _, a, t in stream if t.startswith("scratch_"))
+in_loop_scratch = sum(1 for n, (_, a, t) in enumerate(stream) if t.startswith("scratch_") and n < last_mfma and any("v_mfma" in stream[j][2] for j in range(max(0, n - 400), n)))
 nm = sum(1 for _, _, t in stream if "v_mfma" in t)
 print(f"{want}: {len(stream)} instructions, {nm} MFMAs")
-print("  metadata:", meta)
+print("  kernel descriptor:", meta, f"; scratch instructions: {scratch} ({in_loop_scratch} between MFMAs)")
 print(f"  compiler instructions on accumulator registers in front of the last MFMA: {len(bad1)}", bad1[:3])
 print(f"  VALU writes within two slots in front of an MFMA statement that reads them: {len(bad3)}")
 for b in bad3[:6]:
