@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector == matrix peak
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def kernel_source_hash() -> str:
@@ -518,8 +518,10 @@ def main():
             "lm_trials_per_s": g_trials * args.steps / wall,
             "iters_per_frame": g_iters / g_problems,
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "sft_lm_kernel", "kernel_ms": kern_ms,
-                         "timing": "HIP events recorded by bench.py on dsh_stream() around the K launches of the product library",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": ("all launches of a step (sftb_lin / sftb_factor / sftb_trial kernels)" if int(counts[7]) == 1 else
+                                    ("sft_lm_kernel<4>" if int(counts[7]) == 4 else "sft_lm_kernel<8> / sft_spec_kernel<8>")), "kernel_ms": kern_ms,
+                         "timing": "HIP events recorded by bench.py on dsh_stream() around the K steps of the product library",
                          "algorithmic_flops_per_launch": flops_per_launch, "flops_per_lm_trial": flops_trial, "dim": Dn + 6, "half_bandwidth": kd,
                          "hbm_assembly": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                                           "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -559,6 +561,29 @@ def main():
             lab.batch_upload(frames, *regs, 1, 50)
             lab.batch_run()
             lab.synchronize()
+            if int(counts[7]) == 1:
+                # Throughput shape = rounds of phase kernels: the step's time by kernel, from per-launch HIP events of the lab build (the same
+                # device code; the product library has no timing entry points).  The dominant kernel is the one-wavefront factorisation
+                # (FP64 roofline); the Jacobian assembly is its own kernel now, so its HBM roofline is a production number.
+                ph, n_rounds = lab.rounds_timed()
+                rf = out["roofline"]
+                tf = flops_per_launch / (ph["factor"] * 1e-3) / 1e12
+                rf.update({"kernel": "sftb_factor_kernel", "kernel_ms": ph["factor"], "achieved": tf, "frac": tf / FP64_PEAK_TFLOPS,
+                           "timing": "HIP events in front of and behind every launch of one step (dsh_lab_sft_rounds_timed, libdefslam_hip_lab.so: the device code of "
+                                     "the timed product run); kernel_ms = the sum over the step's sftb_factor_kernel launches",
+                           "phases_ms": ph, "rounds_per_step": n_rounds, "phases_sum_over_step": sum(ph.values()) / ms_per_step,
+                           "note": "a step = rounds of LIN (residuals + Jacobian assembly), FACTOR (banded-arrowhead Cholesky + back substitution, one wavefront per "
+                                   "problem, FP64 MFMA) and TRIAL (update, chi2, LM control) launches; frac = algorithmic solve flops / FP64 peak over the FACTOR "
+                                   "kernel's own time; hbm_assembly = SURVEY 8d assembly bytes over the LIN kernel's own time"})
+                lin_gbs = bytes_per_launch / (ph["lin"] * 1e-3) / 1e9
+                rf["hbm_assembly"] = {"kernel": "sftb_lin_kernel", "kernel_ms": ph["lin"], "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
+                                      "what": "every linearisation of a step (residuals + records + normal equations of the problems that start an iteration), "
+                                              "algorithmic bytes over the kernel's own time"}
+                fs = (stream_bytes) / (ph["factor"] * 1e-3) / 1e9
+                rf["hbm_solver_stream"] = {"kernel": "sftb_factor_kernel", "achieved": fs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fs / HBM_PEAK_GBS,
+                                           "bytes_per_trial": stream_trial, "achievable_stream_GBps_this_box": 5400.0,
+                                           "what": "per damping trial the compact H blocks read once, L written once and read once by the deferred back substitution"}
             asm_ms = lab.batch_assemble_timed(5) / 5
             lab.close()
             out["roofline"]["hbm_assembly_isolated"] = {

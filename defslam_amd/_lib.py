@@ -105,7 +105,7 @@ DSH_COMM_ID_BYTES = 128
 
 # include/defslam_hip_debug.h: only libdefslam_hip_lab.so exports these
 LAB_SYMBOLS = ["dsh_lab_set_option", "dsh_lab_sft_run_timed", "dsh_lab_sft_assemble_timed", "dsh_lab_sft_phase_ms", "dsh_lab_sft_step_trace",
-               "dsh_lab_sft_system", "dsh_lab_sft_solver_info", "dsh_lab_sft_wave_check", "dsh_lab_sft_dump"]
+               "dsh_lab_sft_system", "dsh_lab_sft_solver_info", "dsh_lab_sft_wave_check", "dsh_lab_sft_dump", "dsh_lab_sft_rounds_timed"]
 
 _lib = None
 _lab = None
@@ -205,6 +205,7 @@ def _bind(path: str, lab: bool) -> C.CDLL:
         L.dsh_lab_sft_solver_info.argtypes = [vp, C.c_int, c_i32_p]
         L.dsh_lab_sft_wave_check.argtypes = [vp, C.c_double, C.c_int, C.c_int, c_double_p, c_double_p, c_i32_p, c_double_p]
         L.dsh_lab_sft_dump.argtypes = [vp, C.c_int, C.c_int, C.c_int64, c_double_p]
+        L.dsh_lab_sft_rounds_timed.argtypes = [vp, c_double_p, c_i32_p]
         for name in LAB_SYMBOLS:
             getattr(L, name).restype = C.c_int
     return L

@@ -141,6 +141,7 @@ struct dsh_ctx : dsh_ctx_base {
   int* d_counters = nullptr;
   size_t lds_configured_b[2] = {0, 0};
   int rounds_hint = 24;                // rounds the previous run of this context needed
+  std::vector<hipEvent_t>* phase_events = nullptr;   // lab builds (dsh_lab_sft_rounds_timed): an event in front of and behind every phase launch
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
@@ -296,7 +297,12 @@ int run_rounds(dsh_ctx* c) {
   // TRIAL).  As many rounds as the previous run needed are enqueued in one go, then the done counter is read back and rounds are added
   // in pairs while a problem still runs (a finished problem's workgroups leave at their first instruction).
   const int B = c->B;
-  auto launch = [&](int phase) { return sftb_launch(c->d_probs, c->d_runs, c->d_counters, B, phase, c->jl_doubles, c->lds_configured_b, c->num_cus, c->stream); };
+  auto launch = [&](int phase) {
+    if (c->phase_events) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
+    const hipError_t r = sftb_launch(c->d_probs, c->d_runs, c->d_counters, B, phase, c->jl_doubles, c->lds_configured_b, c->num_cus, c->stream);
+    if (c->phase_events) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
+    return r;
+  };
   HIPCHK(c, launch(SFTB_PH_INIT));
   const int worst = std::max(1, c->max_iters_batch) * 10 + 1;
   int rounds = 0, group = std::max(1, std::min(worst, c->rounds_hint));
@@ -1293,6 +1299,30 @@ int dsh_lab_sft_wave_check(dsh_ctx* c, double rel, int launches, int only, doubl
     }
   }
   return DSH_OK;   // (H stays assembled at the initial state: the check can be repeated; the results of the last full run are stale)
+}
+
+int dsh_lab_sft_rounds_timed(dsh_ctx* c, double* ms4, int32_t* rounds) {
+  if (!c || !ms4) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_rounds_timed: bad argument");
+  if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_rounds_timed: host-only context, no GPU (there is no CPU fallback)");
+  if (c->B <= 0 || !c->rounds_mode) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_rounds_timed: needs an uploaded batch that runs as rounds of phase kernels");
+  (void)hipSetDevice(c->device);
+  std::vector<hipEvent_t> ev;
+  c->phase_events = &ev;
+  const int rc = run_rounds(c);
+  c->phase_events = nullptr;
+  (void)hipStreamSynchronize(c->stream);
+  // launches in order: INIT, then (LIN, FACTOR, TRIAL) per round
+  for (int i = 0; i < 4; i++) ms4[i] = 0.0;
+  for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+    const size_t l = i / 2;
+    ms4[l == 0 ? 0 : 1 + (l - 1) % 3] += ms;
+  }
+  if (rounds) *rounds = ev.size() >= 2 ? (int32_t)((ev.size() / 2 - 1) / 3) : 0;
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  if (rc == DSH_OK) c->ran = true;
+  return rc;
 }
 
 int dsh_lab_sft_dump(dsh_ctx* c, int b, int what, int64_t n, double* out) {
