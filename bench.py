@@ -239,8 +239,9 @@ def e2e_legs(ctx, tmpl, m, frames, regs):
     out["seq_mapping"] = {"frames": st["frames"], "keyframes": st["keyframes"], "templates": st["templates"], "frames_e2e_per_s": st["frames"] / tot,
                           "ms_tracking_per_frame": 1e3 * st["t_track"] / st["frames"], "ms_mapping_per_keyframe": 1e3 * st["t_map"] / max(st["keyframes"], 1),
                           "iters_per_frame": st["iters"] / st["frames"], "min_inlier_fraction": float(min(st["inliers"])),
+                          "switch_frames": len(st["switch_frames"]), "solves": st["frames"] + len(st["switch_frames"]),
                           "what": "synth.SEQMAP: wall clock inside the C-ABI calls of defslam_amd/seqmap.py (tracking every frame, the whole mapping chain every "
-                                  "10th frame, template switch on the next one); synthetic data generation excluded; tests/test_seqmap_gpu.py checks every stage "
+                                  "10th frame, template switch on the next one -- that frame is solved twice like DefTracking.cc:109-123 + :244-247: RegTemp = 0 first, then the regular solve without the observations the first one flagged); synthetic data generation excluded; tests/test_seqmap_gpu.py checks every stage "
                                   "of this loop against its oracle"}
     return out
 

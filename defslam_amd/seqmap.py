@@ -6,7 +6,9 @@ updateTemplate, DefLocalMapping.cc:115-234), with every numeric stage on the GPU
     every frame        DefPoseOptimization(frame, template, RegLap, RegInex, RegTemp)      DefTracking.cc:244  (dsh_sft_solve)
     every 10th frame   keyframe (DefTracking.cc:175) -> SchwarpDatabase::add: Warp::initialize, searchBySchwarp, calculateSchwarps
                        -> NormalEstimator::ObtainK1K2 -> ShapeFromNormals -> SurfaceRegistration -> createTemplate
-    the frame after    updateTemplate + DefPoseOptimization(..., RegTemp = 0) on the NEW template  DefTracking.cc:109-115
+    the frame after    updateTemplate + DefPoseOptimization(..., RegTemp = 0) on the NEW template  DefTracking.cc:109-117
+                       and then, on the SAME frame, TrackLocalMap -> DefPoseOptimization(..., RegTemp)    DefTracking.cc:123, 244-247
+                       without the observations the first solve flagged (pFrame->mvbOutlier, DefOptimizer.cc:295)
 
 `hooks` (optional) is called with the inputs and outputs of every stage -- tests/test_seqmap_gpu.py passes a checker that runs the
 oracle of the stage on the same inputs; bench.py passes nothing and times the loop.
@@ -83,7 +85,7 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
                 recs_per_point[p].append(dg[j])
         return dt
 
-    stats = dict(frames=0, keyframes=0, templates=1, iters=0, trials=0, inliers=[], switch_frames=[], schwarp_fits=0, normals=0)
+    stats = dict(frames=0, keyframes=0, templates=1, iters=0, trials=0, inliers=[], switch_frames=[], switch_solves=0, switch_dropped=0, schwarp_fits=0, normals=0)
     t_map += add_keyframe(-1)                                              # the keyframe the map was bootstrapped with
     for k in range(1, seq["n_frames"]):
         fk = seq["frames"][k]
@@ -92,11 +94,33 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         uv = np.stack([fx * Xc[:, 0] / Xc[:, 2] + cam[2], fy * Xc[:, 1] / Xc[:, 2] + cam[3]], 1) + seq["noise"][k][inside]
         f = sft.Frame(Tcw=T.copy(), K=K, N=1200, obs_nodes=enodes[inside], obs_bary=bary[inside].astype(np.float64), obs_uv=uv.astype(np.float32).astype(np.float64),
                       obs_invsig2=(seq["invsig"][inside].astype(np.float64)) ** 2, nodes_xyz=x.copy())
-        reg_temp = 0.0 if switch else regs[2]                              # DefTracking.cc:115: RegTemp = 0 on the template switch
-        t0 = time.perf_counter()
-        inl = sft.DefPoseOptimization(ctx, f, regs[0], regs[1], reg_temp)
-        t_track += time.perf_counter() - t0
-        hooks.tracking(k, T, x, f, inl, (regs[0], regs[1], reg_temp), switch)
+        if switch:
+            # The frame right behind a template switch is solved TWICE (DefTracking.cc:109-123): first against the new template with RegTemp = 0
+            # (it is at its rest shape: no temporal term) ...
+            t0 = time.perf_counter()
+            inl = sft.DefPoseOptimization(ctx, f, regs[0], regs[1], 0.0)
+            t_track += time.perf_counter() - t0
+            hooks.tracking(k, T, x, f, inl, (regs[0], regs[1], 0.0), 1)
+            stats["switch_solves"] += 1
+            stats["iters"] += f.iters
+            stats["trials"] += f.trials
+            # ... then TrackLocalMap runs the regular solve on the same frame: from the pose and the mesh the first one left, WITHOUT the
+            # observations it flagged (DefOptimizer.cc:295 skips key points with mvbOutlier set; their flags stay set)
+            keep = ~f.mvbOutlier
+            T1, x1, flagged = f.Tcw.copy(), f.nodes_xyz.copy(), f.mvbOutlier.copy()
+            f = sft.Frame(Tcw=T1.copy(), K=K, N=1200, obs_nodes=f.obs_nodes[keep], obs_bary=f.obs_bary[keep], obs_uv=f.obs_uv[keep],
+                          obs_invsig2=f.obs_invsig2[keep], nodes_xyz=x1.copy())
+            t0 = time.perf_counter()
+            inl = sft.DefPoseOptimization(ctx, f, regs[0], regs[1], regs[2])
+            t_track += time.perf_counter() - t0
+            hooks.tracking(k, T1, x1, f, inl, regs, 2)
+            stats["switch_solves"] += 1
+            stats["switch_dropped"] += int(flagged.sum())
+        else:
+            t0 = time.perf_counter()
+            inl = sft.DefPoseOptimization(ctx, f, regs[0], regs[1], regs[2])
+            t_track += time.perf_counter() - t0
+            hooks.tracking(k, T, x, f, inl, regs, 0)
         if switch:
             stats["switch_frames"].append(k)
         switch = False

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <string>
 #include <iomanip>
 #include <memory>
 
@@ -78,24 +79,36 @@ int main(int argc, char** argv) {
   dsh_ctx* ctx = nullptr;
   if (dsh_create(&ctx, argc > 4 ? std::atoi(argv[4]) : 0) != DSH_OK) { std::fprintf(stderr, "no device\n"); return 3; }
   defslam_hip::TemplateBinding<Template, Node> binding;
-  const int inliers = defslam_hip::DefPoseOptimizationHIP<Frame, DefMap, Template, Node, DefMapPoint>(ctx, binding, &frame, &map, RegLap, RegInex, RegTemp, layers);
-  std::ofstream out(argv[2]);
-  out << std::setprecision(17);
-  int under_lock = 0;
-  for (auto* p : map.points) under_lock += static_cast<DefMapPoint*>(p)->recalculated_under_lock;
-  out << inliers << " " << frame.repError << " " << frame.pose_sets << " " << MapPoint::mGlobalMutex.locks << " " << (int)MapPoint::mGlobalMutex.held << " " << under_lock << "\n";
-  for (int i = 0; i < 16; i++) out << frame.mTcw[i] << (i == 15 ? "\n" : " ");
-  for (int i = 0; i < n; i++) {
-    double x, y, z;
-    nodes[i].getXYZ(x, y, z);
-    out << x << " " << y << " " << z << " " << nodes[i].getIndex() << " " << (int)nodes[i].viewed << " " << (int)nodes[i].local << " " << (int)nodes[i].role << "\n";
+  // What one call leaves behind, in the layout the tests parse.
+  auto dump = [&](const std::string& path, int inliers) {
+    std::ofstream out(path);
+    out << std::setprecision(17);
+    int under_lock = 0;
+    for (auto* p : map.points) under_lock += static_cast<DefMapPoint*>(p)->recalculated_under_lock;
+    out << inliers << " " << frame.repError << " " << frame.pose_sets << " " << MapPoint::mGlobalMutex.locks << " " << (int)MapPoint::mGlobalMutex.held << " " << under_lock << "\n";
+    for (int i = 0; i < 16; i++) out << frame.mTcw[i] << (i == 15 ? "\n" : " ");
+    for (int i = 0; i < n; i++) {
+      double x, y, z;
+      nodes[i].getXYZ(x, y, z);
+      out << x << " " << y << " " << z << " " << nodes[i].getIndex() << " " << (int)nodes[i].viewed << " " << (int)nodes[i].local << " " << (int)nodes[i].role << "\n";
+    }
+    for (int i = 0; i < frame.N; i++) out << (int)frame.mvbOutlier[i] << (i + 1 == frame.N ? "\n" : " ");
+    for (auto* p : map.points) {
+      auto* mp = static_cast<DefMapPoint*>(p);
+      out << mp->mWorldPos[0] << " " << mp->mWorldPos[1] << " " << mp->mWorldPos[2] << " " << mp->recalculated << "\n";
+    }
+  };
+  const bool switch_frame = argc > 5 && std::string(argv[5]) == "switch";
+  int inliers;
+  if (switch_frame) {
+    // The frame right behind a template switch (DefTracking.cc:109-123): DefPoseOptimization with RegTemp = 0, then -- TrackLocalMap,
+    // :244-247 -- the regular call on the SAME frame: it starts from the pose and the nodes the first call wrote and skips the key points
+    // the first call flagged (pFrame->mvbOutlier, DefOptimizer.cc:295).
+    inliers = defslam_hip::DefPoseOptimizationHIP<Frame, DefMap, Template, Node, DefMapPoint>(ctx, binding, &frame, &map, RegLap, RegInex, 0.0, layers);
+    dump(std::string(argv[2]) + ".first", inliers);
   }
-  for (int i = 0; i < frame.N; i++) out << (int)frame.mvbOutlier[i] << (i + 1 == frame.N ? "\n" : " ");
-  for (auto* p : map.points) {
-    auto* mp = static_cast<DefMapPoint*>(p);
-    out << mp->mWorldPos[0] << " " << mp->mWorldPos[1] << " " << mp->mWorldPos[2] << " " << mp->recalculated << "\n";
-  }
-  out.close();
+  inliers = defslam_hip::DefPoseOptimizationHIP<Frame, DefMap, Template, Node, DefMapPoint>(ctx, binding, &frame, &map, RegLap, RegInex, RegTemp, layers);
+  dump(argv[2], inliers);
   defslam_hip::MatchesWriter mw(argv[3]);
   mw.add_frame(frame, numberLocalMapPoints);
   std::fprintf(stderr, "%s\n", dsh_last_error(ctx));

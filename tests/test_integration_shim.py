@@ -308,3 +308,69 @@ def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow
     dev_lines = open(tmp_path / "out_dev.txt").read().split("\n")
     assert dev_lines[0].split() == [str(nrec), "0"]                # as many records on the device as the host map held; none on the host
     assert dev_lines[1:] == host_lines[1 + nrec:]                  # bookkeeping, normals written into the surfaces, covariances, pending flags
+
+
+def _parse_shim_out(path, n_nodes, N, n_mp):
+    it = iter(open(path).read().split())
+    head = dict(inliers=int(next(it)), rep=float(next(it)), pose_sets=int(next(it)), locks=int(next(it)), held=int(next(it)), moved_under_lock=int(next(it)))
+    head["Tcw"] = np.array([float(next(it)) for _ in range(16)], np.float32).reshape(4, 4)
+    head["nodes"] = np.array([[float(next(it)) for _ in range(7)] for _ in range(n_nodes)])
+    head["outl"] = np.array([int(next(it)) for _ in range(N)], bool)
+    head["mp"] = np.array([[float(next(it)) for _ in range(4)] for _ in range(n_mp)])
+    return head
+
+
+@pytest.mark.gpu
+def test_switch_frame_two_calls_through_the_shim_follow_the_oracle(oracle_mod, tmp_path):
+    """The frame right behind a template switch is solved twice (DefTracking.cc:109-123, then TrackLocalMap :244-247): RegTemp = 0 first,
+    then the regular call on the SAME frame object -- from the pose and the nodes the first call wrote, without the key points it flagged
+    (DefOptimizer.cc:295).  The compiled shim executable makes both calls; each is checked against the oracle on the inputs it saw."""
+    from defslam_amd import synth
+    exe = _build()
+    tmpl, fr = synth.make_problem("smoke", 5)
+    M = fr.obs_nodes.shape[0]
+    facets_sorted = np.sort(tmpl.facets, axis=1)
+    N = M
+    levels = (1.2 ** (-2.0 * np.arange(8))).astype(np.float32)
+    octave = np.round(-np.log(fr.obs_invsig2) / (2 * np.log(1.2))).astype(int)
+    with open(tmp_path / "in.txt", "w") as f:
+        f.write(f"{tmpl.n} {facets_sorted.shape[0]}\n")
+        for row in tmpl.xyz0:
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+        for row in fr.xyz:
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+        for row in facets_sorted:
+            f.write(" ".join(str(int(v)) for v in row) + "\n")
+        f.write(" ".join(repr(float(v)) for v in fr.K) + "\n")
+        f.write(" ".join(repr(float(v)) for v in fr.Tcw.ravel()) + "\n")
+        f.write(f"{N} 41\n{levels.size}\n" + " ".join(repr(float(v)) for v in levels) + "\n")
+        for m in range(M):
+            f.write(f"{float(fr.obs_uv[m, 0])!r} {float(fr.obs_uv[m, 1])!r} {octave[m]} 1 {fr.obs_facet[m]} " + " ".join(repr(float(v)) for v in fr.obs_bary[m]) + "\n")
+        f.write(f"{synth.REG_LAP!r} {synth.REG_INEX!r} {synth.REG_TEMP!r} 1\n640\n")
+    r = subprocess.run([exe, str(tmp_path / "in.txt"), str(tmp_path / "out.txt"), str(tmp_path / "Matches.txt"), "0", "switch"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    first = _parse_shim_out(str(tmp_path / "out.txt") + ".first", tmpl.n, N, M)
+    second = _parse_shim_out(tmp_path / "out.txt", tmpl.n, N, M)
+    obs_nodes = facets_sorted[fr.obs_facet].astype(np.int32)
+    isig = levels[octave].astype(np.float64)
+    tc = oracle_mod.template_build(tmpl.xyz0, facets_sorted)
+    # ---- first call: every match, RegTemp = 0
+    r1 = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, N, obs_nodes, fr.obs_bary, fr.obs_uv, isig, fr.xyz, synth.REG_LAP, synth.REG_INEX, 0.0)
+    assert first["inliers"] == r1.ret and first["pose_sets"] == 1 and first["locks"] == 1
+    np.testing.assert_allclose(first["nodes"][:, :3], r1.xyz, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(first["Tcw"], r1.Tcw, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(first["outl"], r1.outlier.astype(bool))
+    assert first["outl"].any(), "the case must flag something, otherwise the second call proves nothing"
+    # ---- second call: the regular regulariser, the first call's state (float32 pose round trip like Frame::mTcw), its inliers only
+    keep = ~first["outl"]
+    r2 = oracle_mod.sft_solve(tc, first["Tcw"], fr.K, N, obs_nodes[keep], fr.obs_bary[keep], fr.obs_uv[keep], isig[keep], first["nodes"][:, :3].copy(),
+                              synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    assert second["inliers"] == r2.ret and second["pose_sets"] == 2 and second["locks"] == 2 and second["held"] == 0
+    np.testing.assert_allclose(second["nodes"][:, :3], r2.xyz, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(second["Tcw"], r2.Tcw, rtol=0, atol=2e-6)
+    # flags: what the first call flagged stays flagged (those key points never entered the second graph), the rest is the second call's verdict
+    assert second["outl"][~keep].all()
+    np.testing.assert_array_equal(second["outl"][keep], r2.outlier.astype(bool))
+    # Matches.txt counts the final flags
+    mI, mO = int((~second["outl"]).sum()), int(second["outl"].sum())
+    assert open(tmp_path / "Matches.txt").read() == f"00041 {mI} {mO} 640\n"

@@ -19,7 +19,7 @@ class OracleHooks:
     def __init__(self, oracle, seq):
         self.o, self.seq = oracle, seq
         self.tc = None
-        self.counts = dict(template=0, tracking=0, tracking_switch=0, warp_init=0, search=0, schwarp=0, normals=0, sfn=0, registration=0)
+        self.counts = dict(template=0, tracking=0, tracking_switch=0, tracking_switch_second=0, warp_init=0, search=0, schwarp=0, normals=0, sfn=0, registration=0)
 
     def template(self, nodes, facets, pts_w, fid, enodes, bary, k):
         self.tc = self.o.template_build(nodes, facets)
@@ -44,7 +44,10 @@ class OracleHooks:
         assert np.abs(f.pose7 - r.pose7).max() <= 1e-8
         np.testing.assert_array_equal(f.mvbOutlier, r.outlier.astype(bool))
         self.counts["tracking"] += 1
-        self.counts["tracking_switch"] += int(switch)
+        self.counts["tracking_switch"] += int(bool(switch))
+        self.counts["tracking_switch_second"] += int(switch == 2)
+        if switch == 2:   # the second solve of a switch frame starts where the first one ended and sees only its inliers
+            assert regs[2] == seq_reg_temp()
 
     def warp_init(self, k, kp1, kp2, lam, ok, x0):
         oko, x0o = self.o.warp_initialize(self.seq["bbs2"], kp1, kp2, lam)
@@ -97,6 +100,11 @@ class OracleHooks:
         self.counts["registration"] += 1
 
 
+def seq_reg_temp():
+    from defslam_amd import synth
+    return synth.REG_TEMP
+
+
 def test_tracking_and_mapping_interleaved_in_one_sequence_against_the_oracles(gpu_ctx, oracle_mod):
     from defslam_amd import seqmap, synth
     seq = synth.make_interleaved_sequence(**synth.SEQMAP)
@@ -110,6 +118,8 @@ def test_tracking_and_mapping_interleaved_in_one_sequence_against_the_oracles(gp
     c = hooks.counts
     assert c["template"] == 1 + n_kf and c["normals"] == c["sfn"] == c["registration"] == n_kf
     assert c["warp_init"] == c["search"] == c["schwarp"] == n_kf + 1
-    assert c["tracking_switch"] == len(st["switch_frames"]) and c["tracking"] >= 2 * n_kf
+    # a switch frame is solved twice (DefTracking.cc:109-123 then :244-247): both solves went through the oracle
+    assert st["switch_solves"] == 2 * len(st["switch_frames"])
+    assert c["tracking_switch"] == 2 * len(st["switch_frames"]) and c["tracking_switch_second"] == len(st["switch_frames"]) and c["tracking"] >= 2 * n_kf
     assert min(st["inliers"]) > 0.9                                         # tracking holds through every template switch
     assert st["iters"] / st["frames"] < 12
