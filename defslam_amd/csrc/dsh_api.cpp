@@ -141,12 +141,18 @@ struct dsh_ctx : dsh_ctx_base {
   int* d_counters = nullptr;
   size_t lds_configured_b[2] = {0, 0};
   int rounds_hint = 24;                // rounds the previous run of this context needed
+  // The batch runs as up to kMaxSub sub-batches on streams of their own: the launches of a round are enqueued sub-batch by sub-batch, so
+  // the tail of one sub-batch's FACTOR launch (waves that have run out of work) overlaps with the next launches of the others.
+  static constexpr int kMaxSub = 4;
+  hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr, nullptr, nullptr};   // [0] = stream
+  hipEvent_t sub_event[kMaxSub] = {nullptr, nullptr, nullptr, nullptr};
+  int n_sub = 1;
   std::vector<hipEvent_t>* phase_events = nullptr;   // lab builds (dsh_lab_sft_rounds_timed): an event in front of and behind every phase launch
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -294,33 +300,45 @@ int pack_problem(dsh_ctx* c, const dsh_sft_frame& f, bool wide_off, Packed& P, s
 // finish the typical frame; the done flags are read back behind them and further rounds are launched only while needed.
 int run_rounds(dsh_ctx* c) {
   // Throughput shape: every problem of the batch advances by one damping trial per round (LIN for those that start an iteration, FACTOR,
-  // TRIAL).  As many rounds as the previous run needed are enqueued in one go, then the done counter is read back and rounds are added
+  // TRIAL).  As many rounds as the previous run needed are enqueued in one go, then the done counters are read back and rounds are added
   // in pairs while a problem still runs (a finished problem's workgroups leave at their first instruction).
-  const int B = c->B;
-  auto launch = [&](int phase) {
-    if (c->phase_events) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
-    const hipError_t r = sftb_launch(c->d_probs, c->d_runs, c->d_counters, B, phase, c->jl_doubles, c->lds_configured_b, c->num_cus, c->stream);
-    if (c->phase_events) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
+  const int B = c->B, S = c->n_sub;
+  int b0[dsh_ctx::kMaxSub + 1];
+  for (int s = 0; s <= S; s++) b0[s] = (int)((long long)B * s / S);
+  auto launch = [&](int s, int phase) {
+    const bool ev = c->phase_events && S == 1;
+    if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
+    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, b0[s + 1] - b0[s], phase, c->jl_doubles, c->lds_configured_b,
+                                     c->num_cus, c->sub_stream[s]);
+    if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
     return r;
   };
-  HIPCHK(c, launch(SFTB_PH_INIT));
+  // the other streams start behind whatever the context's stream has enqueued (the upload)
+  if (S > 1) {
+    HIPCHK(c, hipEventRecord(c->sub_event[0], c->stream));
+    for (int s = 1; s < S; s++) HIPCHK(c, hipStreamWaitEvent(c->sub_stream[s], c->sub_event[0], 0));
+  }
+  for (int s = 0; s < S; s++) HIPCHK(c, launch(s, SFTB_PH_INIT));
   const int worst = std::max(1, c->max_iters_batch) * 10 + 1;
   int rounds = 0, group = std::max(1, std::min(worst, c->rounds_hint));
-  HIPCHK(c, c->spec_done.ensure(64, true));
+  HIPCHK(c, c->spec_done.ensure(64 * dsh_ctx::kMaxSub, true));
+  int rc = DSH_OK;
   while (true) {
-    for (int i = 0; i < group && rounds < worst; i++, rounds++) {
-      HIPCHK(c, launch(SFTB_PH_LIN));
-      HIPCHK(c, launch(SFTB_PH_FACTOR));
-      HIPCHK(c, launch(SFTB_PH_TRIAL));
-    }
-    HIPCHK(c, hipMemcpyAsync(c->spec_done.p, c->d_counters, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int done = *reinterpret_cast<const int*>(c->spec_done.p);
+    for (int i = 0; i < group && rounds < worst; i++, rounds++)
+      for (int s = 0; s < S; s++) {
+        HIPCHK(c, launch(s, SFTB_PH_LIN));
+        HIPCHK(c, launch(s, SFTB_PH_FACTOR));
+        HIPCHK(c, launch(s, SFTB_PH_TRIAL));
+      }
+    for (int s = 0; s < S; s++) HIPCHK(c, hipMemcpyAsync(c->spec_done.p + 64 * s, c->d_counters + 16 * s, sizeof(int), hipMemcpyDeviceToHost, c->sub_stream[s]));
+    for (int s = 0; s < S; s++) HIPCHK(c, hipStreamSynchronize(c->sub_stream[s]));
+    int done = 0;
+    for (int s = 0; s < S; s++) done += *reinterpret_cast<const int*>(c->spec_done.p + 64 * s);
     if (done >= B) { c->rounds_hint = rounds; break; }
-    if (rounds >= worst) return fail(c, DSH_ERR_STATE, "batched rounds: a problem did not terminate within its trial budget");
+    if (rounds >= worst) { rc = fail(c, DSH_ERR_STATE, "batched rounds: a problem did not terminate within its trial budget"); break; }
     group = 2;
   }
-  return DSH_OK;
+  return rc;   // (every stream is idle here: what the caller enqueues on the context's stream is ordered behind all of them)
 }
 
 int run_once(dsh_ctx* c) {
@@ -394,6 +412,12 @@ int dsh_create(dsh_ctx** out, int device) {
   }
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+  // streams of the sub-batches of the throughput shape ([0] is the context's stream) and the events that order them behind it
+  c->sub_stream[0] = c->stream;
+  for (int i = 0; i < dsh_ctx::kMaxSub; i++) {
+    if (i > 0 && hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) != hipSuccess) c->sub_stream[i] = nullptr;
+    if (hipEventCreateWithFlags(&c->sub_event[i], hipEventDisableTiming) != hipSuccess) c->sub_event[i] = nullptr;
+  }
   *out = c;
   return DSH_OK;
 }
@@ -404,6 +428,8 @@ int dsh_destroy(dsh_ctx* c) {
   if (c->host_only) { c->stage.release(); c->results.release(); delete c; return DSH_OK; }
   (void)hipSetDevice(c->device);
   drop_graphs(c);
+  for (int i = 1; i < dsh_ctx::kMaxSub; i++) if (c->sub_stream[i]) { (void)hipStreamSynchronize(c->sub_stream[i]); (void)hipStreamDestroy(c->sub_stream[i]); }
+  for (int i = 0; i < dsh_ctx::kMaxSub; i++) if (c->sub_event[i]) (void)hipEventDestroy(c->sub_event[i]);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
   c->stage.release();
@@ -543,6 +569,16 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     if (c->force_waves == 8) nw = 8;
     // From two problems per CU upwards the batch runs as rounds of phase kernels with one wavefront per factorisation (sft_batch.h)
     c->rounds_mode = all_tiles && nw == 4 && c->opt.waves == 0 && c->opt.rounds != 0 && !c->host_only;
+    // sub-batches: each must still fill the device with factor waves (one per SIMD) several times over
+    c->n_sub = 1;
+    if (c->rounds_mode) {
+      // (measured on MI355X, tools/streams_ab.py, 16384 C2 problems: 416 / 428 / 424 / 423 ms per step for 1 / 2 / 3 / 4 sub-batches -- what the
+      // overlapped tails win, the additional launches and last-problem back substitutions lose again: one sub-batch unless asked otherwise)
+      const int want = c->opt.streams > 0 ? c->opt.streams : 1;
+      while (c->n_sub < want && c->n_sub < dsh_ctx::kMaxSub && B / (c->n_sub + 1) >= 16 * c->num_cus) c->n_sub++;
+      if (c->opt.streams > 0) c->n_sub = std::min(std::min(c->opt.streams, (int)dsh_ctx::kMaxSub), std::max(1, B / 64));
+      for (int i = 0; i < c->n_sub; i++) if (!c->sub_stream[i] || !c->sub_event[0]) c->n_sub = 1;
+    }
   }
   // Latency mode: while CUs would idle anyway, every problem gets K of them and tries K dampings per iteration at once.
   int K = 1;
@@ -635,7 +671,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
-  const size_t o_runs = a.take(c->rounds_mode ? sizeof(SftRun) * (size_t)B + 256 : 0);
+  const size_t o_runs = a.take(c->rounds_mode ? sizeof(SftRun) * (size_t)B + 64 * dsh_ctx::kMaxSub : 0);
   for (int e = 0; e < B * K; e++) {
     const int b = e % B, lane = e / B;
     const SftDev& h = c->packed[b].h;
@@ -1218,6 +1254,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "dataflow") c->opt.dataflow = value != 0;
   else if (k == "wide_off") c->opt.wide_off = value != 0;
   else if (k == "rounds") c->opt.rounds = value != 0;
+  else if (k == "streams") { if (value < 0 || value > dsh_ctx::kMaxSub) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: streams is 0 (automatic) or 1..4 sub-batches"); c->opt.streams = value; }
   else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);

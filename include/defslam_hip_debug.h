@@ -23,6 +23,8 @@ extern "C" {
  *   "waves"    0 = automatic (default), 4 or 8 wavefronts per problem of the persistent kernel
  *   "rounds"   1 (default) = from two problems per CU upwards the batch runs as rounds of LIN / FACTOR / TRIAL launches with one wavefront per
  *              factorisation (sft_batch.h, sft_wave.h); 0 = the persistent four-wavefront kernel for such batches as well
+ *   "streams"  0 (default) = one, 1..4 = that many sub-batches of the throughput shape, each on a stream of its own (the tail of one
+ *              sub-batch's FACTOR launch overlaps with the next launches of the others)
  *   "dataflow" 1 = barrier-free factor steps (default), 0 = the barrier version (only compiled into the lab library)
  *   "wide_off" 1 = half-bandwidths 128 < kd <= 256 use the row-major band solver instead of the wide tile solver
  *   "speculate"  0 = automatic, 1 = off (the one-workgroup persistent kernel), 2..4 = that many workgroups per problem try
