@@ -12,6 +12,12 @@
 #pragma once
 
 #define SFTB_NW 4   // wavefronts of a LIN / TRIAL workgroup
+#ifndef SFTB_LIN_WAVES
+#define SFTB_LIN_WAVES 2   // waves per SIMD the LIN kernel is compiled for (A/B: tools/ab_build.sh NAME "-DSFTB_LIN_WAVES=3")
+#endif
+#ifndef SFTB_TRIAL_WAVES
+#define SFTB_TRIAL_WAVES 2
+#endif
 
 __device__ __forceinline__ void sftb_ctl_lds(char* smem, Ctl*& ctl, double*& red, double*& out, double*& panel) {
   ctl = reinterpret_cast<Ctl*>(smem);
@@ -33,7 +39,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev
 }
 
 // LIN: a problem that starts an outer iteration is linearised; the first iteration also fixes the initial damping (tau = 1e-5).
-__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_lin_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs) {
+__global__ __launch_bounds__(64 * SFTB_NW, SFTB_LIN_WAVES) void sftb_lin_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs) {
   constexpr int NW = SFTB_NW, NT = 64 * NW;
   SftRun& R = runs[blockIdx.x];
   if (R.state != SFTB_LIN) return;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
 
 // TRIAL: push, x applied, scale, chi2 at the trial state, the controller's verdict; pop on rejection; at the end of an iteration the stop
 // rules; at the end of the problem the classification.
-__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters) {
+__global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters) {
   constexpr int NW = SFTB_NW, NT = 64 * NW;
   SftRun& R = runs[blockIdx.x];
   const int st = R.state;

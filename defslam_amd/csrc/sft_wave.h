@@ -56,6 +56,9 @@ constexpr int WV_L_XRING = 2400;                  // back substitution of the PR
 constexpr int WV_L_LAND = 2528;                   // ... and the landing buffer of one block column of its L: [Yb | Y_1 .. Y_8 | W], 10 x 256
 constexpr int WV_LDS_DOUBLES = WV_L_LAND + 10 * 256;   // 5088 doubles = 40704 bytes
 typedef double v2d_w __attribute__((ext_vector_type(2)));
+#ifndef WV_DMA_AUX
+#define WV_DMA_AUX 0     // cache policy bits of the LDS-DMA requests of the deferred back substitution (2 = non-temporal)
+#endif
 using lds_v2d = __attribute__((address_space(3))) v2d_w;
 
 // MFMA result -> any reader other than the next MFMA that accumulates into it: 16 passes + write-back (the compiler pads nothing
@@ -311,10 +314,10 @@ __device__ __forceinline__ void wv_bs_request(const WvPrev& Q, int J, lds_double
   typedef __attribute__((address_space(3))) void lds_void;
   const SFT_G char* col = reinterpret_cast<const SFT_G char*>(Q.Lg + ((size_t)J * (BT + 1)) * 256) + 16 * lane;
 #pragma unroll
-  for (int i = 0; i < 18; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(col + 1024 * i), (lds_void*)(land + 128 * i), 16, 0, 0);
+  for (int i = 0; i < 18; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(col + 1024 * i), (lds_void*)(land + 128 * i), 16, 0, WV_DMA_AUX);
   const SFT_G char* w = reinterpret_cast<const SFT_G char*>(Q.Linv + (size_t)J * 256) + 16 * lane;
 #pragma unroll
-  for (int i = 0; i < 2; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(w + 1024 * i), (lds_void*)(land + 128 * (18 + i)), 16, 0, 0);
+  for (int i = 0; i < 2; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(w + 1024 * i), (lds_void*)(land + 128 * (18 + i)), 16, 0, WV_DMA_AUX);
 }
 // Column J from the landing buffer: S_q = sum_d Y_d[q] x_{J+d}[c] + Yb[q] xb[c], summed over the 16 lanes of a row, is (L^T x)_tail + the
 // camera term - y at index g + 4q; x_J[c] = sum_r W[r][c] (-S[r]).  The border tile is a ninth tile whose "x" is (x_cam, -1, 0, ...).
@@ -474,7 +477,11 @@ __device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int
         constexpr int n = wv_tile_index(I, J);
         if constexpr (n < 18) {   // half (n & 1) of tile n / 2: lanes' registers 2 (n & 1), 2 (n & 1) + 1
           const v4d& y = S.Y[n >> 1];
+#ifdef WV_NT_STORE
+          __builtin_nontemporal_store((v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]}, reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)));
+#else
           *reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+#endif
         }
         // ... and two of the 28 gathers of the row that enters the window (the tiles of ring row PH are free since the TRSM): like the
         // stores, one burst of them holds up the instruction stream (each scattered 8-byte load keeps the address unit busy ~100 cycles)

@@ -13,6 +13,27 @@ from bench import kernel_source_hash  # noqa: E402
 
 out_dir, commit = sys.argv[1], sys.argv[2]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16384   # problems per launch of both passes (bench.py's C2 default)
+runs = int(sys.argv[4]) if len(sys.argv) > 4 else 0         # > 0: throughput shape (rounds of phase kernels): steps + warm-ups of a PMC pass; bytes are per STEP
+
+
+def per_step(sub, counter, kernel):
+    tot = 0.0
+    n = 0
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"])
+                n += 1
+    return (tot / runs, n) if n and runs else (None, 0)
+
+
+def total_ms(sub, kernel, steps):
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Name"]:
+                return float(r["TotalDurationNs"]) * 1e-6 / steps, int(r["Calls"])
+    return None, 0
+
 
 
 def per_launch(sub, counter, kernel):
@@ -36,6 +57,16 @@ def avg_ms(sub, kernel):
 res = {"_comment": "HBM traffic per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, --kernel-trace only; "
                    "FETCH_SIZE x2, both KiB); bench.py drops these numbers when its device code hash differs",
        "kernel_source_hash": kernel_source_hash(), "commit": commit}
+if runs:
+    for key, kernel in ((f"C2_B{batch}_factor", "sftb_factor_kernel"), (f"C2_B{batch}_lin", "sftb_lin_kernel"), (f"C2_B{batch}_trial", "sftb_trial_kernel")):
+        f, nf = per_step("pmc_fetch", "FETCH_SIZE", kernel)
+        w, nw = per_step("pmc_write", "WRITE_SIZE", kernel)
+        ms, calls = total_ms("stats", kernel, 6)      # the stats pass runs 5 steps + 1 warm-up
+        if f is None or w is None:
+            continue
+        res[key] = {"fetch_kib": f, "write_kib": w, "bytes_per_step": int((2 * f + w) * 1024), "counter_rows_in_pass": [nf, nw], "kernel_ms_per_step_rocprof": ms, "calls": calls}
+    print(json.dumps(res, indent=1))
+    sys.exit(0)
 for key, kernel, fs, ws, st in ((f"C2_B{batch}", "sft_lm_kernel", "pmc_fetch", "pmc_write", "stats"),
                                 (f"C2_B{batch}_assembly", "sft_assembly_kernel", "asm_fetch", "asm_write", "asm_stats")):
     f, nf = per_launch(fs, "FETCH_SIZE", kernel)
