@@ -38,7 +38,7 @@ def kernel_source_hash() -> str:
     """Identifies the device code a PMC traffic figure was measured on (profiles/<round>/traffic.json stores it)."""
     import re
     h = hashlib.sha256()
-    for name in ("sft_kernels.hip", "sft_wide.h", "tile_chol.h", "sft_problem.h"):
+    for name in ("sft_kernels.hip", "sft_wide.h", "sft_wave.h", "sft_batch.h", "tile_chol.h", "sft_problem.h"):
         with open(os.path.join(ROOT, "defslam_amd", "csrc", name), "r", encoding="utf-8") as f:
             src = f.read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # comments and layout do not change the device code
@@ -471,6 +471,7 @@ def main():
         # HBM traffic per launch: rocprofv3 PMC passes of exactly this configuration, carried with their provenance and dropped when the
         # device code has changed since (profiles/<round>/traffic.json; tools/profile_bench.sh regenerates it)
         traffic = traffic_asm = None
+        traffic_phase = {}
         traffic_source = "none: no PMC pass recorded for this configuration"
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))
@@ -483,6 +484,8 @@ def main():
                     traffic = tj[key]["bytes_per_launch"]
                 if key + "_assembly" in tj:
                     traffic_asm = tj[key + "_assembly"]["bytes_per_launch"]
+                # throughput shape: bytes per STEP of each phase kernel (all of its launches of a step summed)
+                traffic_phase = {ph: tj[f"{key}_{ph}"]["bytes_per_step"] for ph in ("factor", "lin", "trial") if f"{key}_{ph}" in tj}
                 traffic_source = f"profiles/{PROFILE_ROUND}/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes; device code {src_hash}, commit {tj.get('commit')})"
         except Exception as e:  # noqa: BLE001
             traffic_source = f"none: {type(e).__name__}"
@@ -570,6 +573,8 @@ def main():
                 rf = out["roofline"]
                 tf = flops_per_launch / (ph["factor"] * 1e-3) / 1e12
                 rf.update({"kernel": "sftb_factor_kernel", "kernel_ms": ph["factor"], "achieved": tf, "frac": tf / FP64_PEAK_TFLOPS,
+                           "traffic": traffic_phase.get("factor"), "traffic_GBps": (traffic_phase["factor"] / (ph["factor"] * 1e-3) / 1e9) if "factor" in traffic_phase else None,
+                           "traffic_what": "HBM bytes of the kernel's launches of one step (PMC)",
                            "timing": "HIP events in front of and behind every launch of one step (dsh_lab_sft_rounds_timed, libdefslam_hip_lab.so: the device code of "
                                      "the timed product run); kernel_ms = the sum over the step's sftb_factor_kernel launches",
                            "phases_ms": ph, "rounds_per_step": n_rounds, "phases_sum_over_step": sum(ph.values()) / ms_per_step,
@@ -579,6 +584,7 @@ def main():
                 lin_gbs = bytes_per_launch / (ph["lin"] * 1e-3) / 1e9
                 rf["hbm_assembly"] = {"kernel": "sftb_lin_kernel", "kernel_ms": ph["lin"], "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
+                                      "traffic": traffic_phase.get("lin"), "traffic_over_algorithmic": (traffic_phase["lin"] / bytes_per_launch) if "lin" in traffic_phase else None,
                                       "what": "every linearisation of a step (residuals + records + normal equations of the problems that start an iteration), "
                                               "algorithmic bytes over the kernel's own time"}
                 fs = (stream_bytes) / (ph["factor"] * 1e-3) / 1e9
