@@ -529,7 +529,7 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
-template <int NW, int CLS>
+template <int NW, int CLS, int PARTS = 3>
 __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* out, const AsmRec<CLS>& ar, int part = 0, int nparts = 1) {
   // The pointers and scalars the gathers use, read once: wave-uniform values stay in scalar registers instead of being re-read
   // from the problem record (a scalar load + a wait that also drains the LDS counter) inside the loops.
@@ -607,7 +607,8 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
   // workgroups of a problem, which all write into the same H (sft_spec_kernel); 0, 1 = everything
   const int I0 = wave + NW * part, dI = NW * nparts;
   Hdr nxt = load_hdr(I0);
-  DL nl = load_dlists(nxt);
+  DL nl{};
+  if constexpr (PARTS & 1) nl = load_dlists(nxt);
 
 #pragma unroll 1
   for (int I = I0; I < ngroups; I += dI) {
@@ -636,10 +637,11 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
     // first chunk of the lists of the lane's (first) off-diagonal block: issued here, with the diagonal lists below, used after the
     // diagonal section -- one memory round trip less per round
     constexpr int OCH = 4, SCH = 6;
-    int om0[OCH];
-    double oc0[OCH];
-    uint32_t orc0[SCH];
-    double occ0[SCH];
+    int om0[OCH] = {0, 0, 0, 0};
+    double oc0[OCH] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t orc0[SCH] = {0, 0, 0, 0, 0, 0};
+    double occ0[SCH] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (PARTS & 2) {
 #pragma unroll
     for (int i = 0; i < OCH; i++) {
       const bool in = cur.ob0 + i < cur.ob1;
@@ -652,9 +654,10 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       orc0[i] = in ? P.sh_rec[cur.sh0 + i] : 0xFFFFFFFFu;
       occ0[i] = in ? P.sh_cf[2 * (cur.sh0 + i)] : 0.0;
     }
+    }
     // ---- diagonal blocks: 8 lanes per node, contributions dealt round-robin, partial sums combined by a fixed xor butterfly.
     // Every level of the gather (list entries -> records) is issued for up to DCH contributions at once.
-    {
+    if constexpr (PARTS & 1) {
       const int sub = lane & 7, a = a_lo + (lane >> 3);
       const bool on = (lane >> 3) < GN && a <= a_hi;
       double sii = 0.0, G0[5], G1[5], g0 = 0.0, g1 = 0.0, Hs[6], bn[3];
@@ -759,8 +762,9 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       }
     }
     AS_ADD(34);
-    nl = load_dlists(nxt);   // the next round's list entries travel while this round's off-diagonal blocks are summed
+    if constexpr (PARTS & 1) nl = load_dlists(nxt);   // the next round's list entries travel while this round's off-diagonal blocks are summed
     // ---- off-diagonal blocks of the block rows a_lo .. a_hi: one lane per block; the headers of the first 64 came a group ahead
+    if constexpr (PARTS & 2)
     for (int q = cur.q; q < cur.qe; q += 64) {
       Hdr h = cur;
       if (q != cur.q) {   // more than 64 off-diagonal blocks in the group (rare): headers on demand

@@ -155,6 +155,40 @@ def test_connected_mesh_cut_across_two_ranks_equals_the_oracle_solve_of_the_whol
             c.close()
 
 
+def test_connected_mesh_c5_full_size_against_the_golden_fixture():
+    """BASELINE.json configs[4], the mesh the connected mode exists for: the 2000-node template (half-bandwidth 248) cut across two ranks
+    against the oracle's solve of the whole connected mesh (tests/golden/sft_C5_p0.npz: 15 minutes of CPU, done once in the build
+    container -- the inputs are regenerated from the seed and their digest is checked)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden_c5 import input_digest
+    from defslam_amd import sft, synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sft_C5_p0.npz"))
+    tmpl, fr = synth.make_problem("C5", int(g["problem_id"]))
+    assert input_digest(tmpl, fr) == str(g["input_sha256"])
+    regs = tuple(g["regs"])
+    ctxs = [sft.Context(0), sft.Context(0)]
+    try:
+        for c in ctxs:
+            c.template_build(tmpl.xyz0, tmpl.facets)
+        frames = [sft.frame_from_synth(fr), sft.frame_from_synth(fr)]
+        inl = sft.ConnectedPoseOptimizationGroup(ctxs[0], ctxs[1], frames, *regs)
+        _, counts = ctxs[0].problem_info(0)
+        assert int(counts[5]) == 6006 and 128 < int(counts[6]) <= 256
+        for f, i in zip(frames, inl):
+            assert f.status == 0 and i == int(g["out_inliers"]) and f.iters == int(g["out_iters"]) and f.trials == int(g["out_trials"])
+            np.testing.assert_array_equal(f.trace[:, [2, 6]], g["out_trace"][:, [2, 6]])
+            assert np.abs(f.nodes_xyz - g["out_xyz"]).max() <= 1e-7 * np.abs(g["out_xyz"]).max()
+            assert np.abs(f.pose7 - g["out_pose7"]).max() <= 1e-8
+            np.testing.assert_array_equal(f.mvbOutlier, np.asarray(g["out_outlier"], bool))
+        np.testing.assert_array_equal(frames[0].nodes_xyz, frames[1].nodes_xyz)
+        np.testing.assert_array_equal(frames[0].pose7, frames[1].pose7)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_connected_mode_refuses_what_it_cannot_cut_on_every_rank():
     """A band too short for two parts next to a separator, and a half-bandwidth beyond 256: both contexts get the same error code and
     nobody is left waiting inside a collective."""
