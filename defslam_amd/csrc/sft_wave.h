@@ -314,7 +314,9 @@ __device__ __forceinline__ void wv_bs_request(const WvPrev& Q, int J, lds_double
   typedef __attribute__((address_space(3))) void lds_void;
   const SFT_G char* col = reinterpret_cast<const SFT_G char*>(Q.Lg + ((size_t)J * (BT + 1)) * 256) + 16 * lane;
 #pragma unroll
-  for (int i = 0; i < 18; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(col + 1024 * i), (lds_void*)(land + 128 * i), 16, 0, WV_DMA_AUX);
+  for (int i = 0; i < 18; i++)
+    if (i != 1)   // (the second KB of slot 0 is not used: the border tile is stored as its 32 lanes c < 8)
+      __builtin_amdgcn_global_load_lds((const SFT_G void*)(col + 1024 * i), (lds_void*)(land + 128 * i), 16, 0, WV_DMA_AUX);
   const SFT_G char* w = reinterpret_cast<const SFT_G char*>(Q.Linv + (size_t)J * 256) + 16 * lane;
 #pragma unroll
   for (int i = 0; i < 2; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(w + 1024 * i), (lds_void*)(land + 128 * (18 + i)), 16, 0, WV_DMA_AUX);
@@ -326,7 +328,8 @@ __device__ __forceinline__ void wv_bs_column(const WvPrev& Q, int J, const lds_d
   const lds_v2d* t2 = reinterpret_cast<const lds_v2d*>(land) + 2 * lane;   // the lane's 32 bytes of tile 0; tile i: + 128 * i
   double s[4];
   {
-    const v2d_w a = t2[0], b = t2[1];
+    const lds_v2d* tb = reinterpret_cast<const lds_v2d*>(land) + 2 * ((lane >> 4) * 8 + (lane & 7));   // Yb: 32 kept lanes, the others mirror c - 8
+    const v2d_w a = tb[0], b = tb[1];
     s[0] = a.x * Q.xb; s[1] = a.y * Q.xb; s[2] = b.x * Q.xb; s[3] = b.y * Q.xb;
   }
 #pragma unroll
@@ -372,7 +375,8 @@ __device__ __forceinline__ void wv_backsub_now(const WvPrev& Q, int lane) {
     if (J >= 0) {
       const SFT_G double* col = Q.Lg + ((size_t)J * (BT + 1)) * 256 + 4 * lane;
 #pragma unroll
-      for (int i = 0; i <= 8; i++) C.t[i] = (i == 0 || J + i < Q.nT) ? *reinterpret_cast<const SFT_G v4d*>(col + 256 * i) : (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int i = 1; i <= 8; i++) C.t[i] = (J + i < Q.nT) ? *reinterpret_cast<const SFT_G v4d*>(col + 256 * i) : (v4d){0.0, 0.0, 0.0, 0.0};
+      C.t[0] = *reinterpret_cast<const SFT_G v4d*>(col - 4 * lane + 4 * ((lane >> 4) * 8 + (lane & 7)));   // Yb: stored as its 32 lanes c < 8
       C.t[9] = *reinterpret_cast<const SFT_G v4d*>(Q.Linv + (size_t)J * 256 + 4 * lane);
     } else {
 #pragma unroll
@@ -477,11 +481,12 @@ __device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int
         constexpr int n = wv_tile_index(I, J);
         if constexpr (n < 18) {   // half (n & 1) of tile n / 2: lanes' registers 2 (n & 1), 2 (n & 1) + 1
           const v4d& y = S.Y[n >> 1];
-#ifdef WV_NT_STORE
-          __builtin_nontemporal_store((v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]}, reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)));
-#else
-          *reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
-#endif
+          if constexpr (n < 2) {   // the border tile Yb: only its 32 lanes c < 8 carry data (the others mirror them) -- 1 KB instead of 2
+            const int ln = threadIdx.x & 63;
+            if ((ln & 15) < 8) *reinterpret_cast<SFT_G v2d_w*>(col - 4 * ln + 4 * ((ln >> 4) * 8 + (ln & 7)) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+          } else {
+            *reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+          }
         }
         // ... and two of the 28 gathers of the row that enters the window (the tiles of ring row PH are free since the TRSM): like the
         // stores, one burst of them holds up the instruction stream (each scattered 8-byte load keeps the address unit busy ~100 cycles)
@@ -630,7 +635,7 @@ __device__ __forceinline__ void wv_prologue_row(const WvProb& W, lds_double* lds
 
 // ---- the factorisation of one problem by one wavefront (+ the deferred back substitution of the wave's previous problem) ----------------------
 // lds: WV_LDS_DOUBLES doubles of this wave.  Returns the "all pivots positive" flag and, per lane c < 6, the camera solution x_cam[c];
-// L = block columns [Yb | Y_1 .. Y_8] in P.Lb + W tiles in P.Linv.  When it returns, Q's back substitution is complete (Q.x written).
+// L = block columns [Yb (1 KB: the lanes c < 8) | Y_1 .. Y_8 (slots of 2 KB)] in P.Lb + W tiles in P.Linv.  When it returns, Q's back substitution is complete (Q.x written).
 __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double lam_corner, lds_double* lds, const WvPrev& Q, double& xcam_out) {
   asm volatile("" ::: "a0", "a255");   // the accumulator file is ours (the kernel descriptor allocates all of it)
   const int lane = threadIdx.x & 63;
