@@ -142,6 +142,68 @@ def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
         assert frames[p].trials == r.trials
 
 
+@pytest.mark.parametrize("shape,m", [((3, 3), 60), ((5, 6), 200), ((7, 7), 300), ((10, 10), 300), ((9, 14), 420)])
+def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mod, shape, m):
+    """The throughput shape (LIN / FACTOR / TRIAL rounds, one wavefront per factorisation) away from the benched size: block-row counts
+    below, at and just above the 8-tile window (2, 6, 10, 19, 24 block rows), active blocks that are not a multiple of the tile size, and
+    -- every third problem sees only part of the template -- different dimensions inside one batch.  512 problems per batch (the smallest
+    batch that takes this shape on a 256-CU device), 56 of them against the oracle."""
+    from defslam_amd import sft, synth
+    B = 512
+    rows, cols = shape
+    tmpl = synth.make_grid_template(rows, cols)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = []
+    for p in range(B):
+        fr = synth.make_frame(tmpl, m, p)
+        if p % 3 == 1 and cols > 3:
+            keep = [c + cols * r for r in range(rows) for c in range(cols - 1 - (p % 2))]
+            sel = np.all(np.isin(fr.obs_nodes, keep), axis=1)
+            for k in ["obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+                setattr(fr, k, getattr(fr, k)[sel])
+        syn.append(fr)
+    frames = [sft.frame_from_synth(fr) for fr in syn]
+    gpu_ctx.batch_upload(frames, *regs, 1, 50)
+    _, counts = gpu_ctx.problem_info(0)
+    assert int(counts[7]) == 1, "512 narrow-band problems must run as rounds of phase kernels"
+    gpu_ctx.batch_run()
+    inl = gpu_ctx.batch_download()
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    dims = set()
+    relaxed = []
+    for p in list(range(0, 48)) + [255, 256, 257, 300, 301, 509, 510, 511]:
+        fr = syn[p]
+        r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+        f = frames[p]
+        # Terminal stagnation: once an iteration needs >= 8 dampings in a row (lambda grown by > 2^28 within it) the trial steps are below
+        # one ulp of the state, the gain ratio is rounding noise and accept / reject -- and with it "ten rejections: stop" against "one more
+        # iteration" -- is a coin toss.  Measured on the 512 3x3 problems (tools/diag/rounds_small_mesh.py): 29 differ from the oracle there
+        # and nowhere else, the eight-wavefront latency kernel differs from the oracle just as often (on other problems), the one-wavefront
+        # and four-wavefront solutions of the same system agree to 1.4e-11 (damping 1e-5) ... 2e-16 (damping 1e18), final states to 1.2e-12.
+        # So: strict up to the first such iteration of either side; the final state, outliers and inliers always.
+        heavy = [int(np.argmax(t[:, 2] >= 8)) if (t[:, 2] >= 8).any() else len(t) for t in (r.trace, f.trace)]
+        k = min(heavy)
+        if k >= len(r.trace) and k >= len(f.trace):
+            _compare(f, int(inl[p]), r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+        else:
+            relaxed.append(p)
+            assert f.status == 0 and abs(f.iters - r.trace.shape[0]) <= 1 and f.iters > k
+            np.testing.assert_array_equal(f.trace[:k, [2, 6]], r.trace[:k, [2, 6]])
+            np.testing.assert_allclose(f.trace[:k, [0, 1, 3, 4]], r.trace[:k, [0, 1, 3, 4]], rtol=1e-8)
+            np.testing.assert_allclose(f.trace[k, [0, 1]], r.trace[k, [0, 1]], rtol=1e-8)   # chi2 and damping at the start of that iteration
+            assert np.abs(f.nodes_xyz - r.xyz).max() <= VERT_TOL * np.abs(r.xyz).max() and np.abs(f.pose7 - r.pose7).max() <= POSE_TOL
+            np.testing.assert_array_equal(f.mvbOutlier, np.asarray(r.outlier, bool))
+            assert int(inl[p]) == r.ret and f.rep_error_f64 == pytest.approx(r.rep_error, rel=1e-9)
+        assert f.dim == r.dims[0]
+        dims.add(f.dim)
+    if cols > 3:
+        assert len(dims) >= 2
+        assert not relaxed, relaxed          # only the 3x3 mesh (27 unknowns, 60 matches) runs into the stagnation phase
+    else:
+        assert len(relaxed) <= 12, relaxed
+
+
 @pytest.mark.parametrize("cfg,pid", [("smoke", 0), ("smoke", 7), ("C2", 0), ("W12", 1), ("W16", 2), ("B272", 3)])
 def test_hip_matches_oracle_seeded(gpu_ctx, oracle_mod, cfg, pid):
     from defslam_amd import synth
