@@ -601,7 +601,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     // (4.09 against 4.49 ms for one, 5.97 against 6.15 for twelve) and loses from 16 on (6.31 against 6.18; 48 problems: 11.0 against 7.4) --
     // a wide band gains at every size (C5: 33 against 62 ms for one problem, 89 against 116 for 64).
     if ((c->force_split && hh.tile_mode == 1) ||
-        (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && 20 * B <= c->num_cus && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS))) {
+        (K > 1 && hh.tile_mode == 1 && c->opt.split >= 2 && 20 * B <= c->num_cus && hh.kd > kTS && hh.Dn >= 8 * kTS * ((hh.kd + kTS - 1) / kTS))) {
+      // (kd > kTS: a band of one tile has no separator of two tile columns -- it would run the wide-tile code on one workgroup for nothing)
       hh.tile_mode = 2;
       hh.wbt = (hh.kd + kTS - 1) / kTS;
       hh.tpr = hh.wbt + 1;

@@ -109,11 +109,24 @@ int dsh_sft_solve(dsh_ctx* ctx, const dsh_sft_frame* frame, dsh_sft_result* resu
  *   dsh_sft_batch_upload  packs B frames on the host and starts ONE asynchronous copy to HBM on dsh_stream
  *                         (the frame buffers may be reused as soon as it returns),
  *   dsh_sft_batch_run     launches the solve on dsh_stream; may be called repeatedly -- every run restarts from the uploaded
- *                         initial state.  From 129 problems upwards it is one persistent kernel and returns at once.  Smaller
- *                         batches (a tracked frame) run in latency mode: several workgroups per problem try consecutive
- *                         dampings of a Levenberg-Marquardt iteration side by side, one launch per round, and the call
- *                         returns when the problems have terminated (it reads their done flags between groups of launches);
- *                         the results are bit-identical in both modes,
+ *                         initial state.  The launch shape is chosen at upload from the batch and the device:
+ *                           - at least two problems per compute unit, every half-bandwidth <= 128: rounds of three phase
+ *                             kernels (linearise / factor + solve, one wavefront per problem / trial + controller) over the
+ *                             whole batch; the call enqueues rounds and returns when every problem has terminated;
+ *                           - more than num_cus/2 problems otherwise: one persistent kernel, one workgroup per problem;
+ *                             the call returns at once;
+ *                           - smaller batches (a tracked frame) run in latency mode: several workgroups per problem try
+ *                             consecutive dampings of a Levenberg-Marquardt iteration side by side, one launch per round,
+ *                             and the call returns when the problems have terminated; while the launch holds at most
+ *                             num_cus/20 problems, a band of more than one tile that is long enough is cut in two parts
+ *                             factored by two workgroups.
+ *                         All shapes run the same Levenberg-Marquardt controller on the same normal equations; they differ
+ *                         in the elimination order of the Cholesky factorisation, so the SAME frame solved in batches of
+ *                         different size, or on devices with a different number of compute units, agrees to rounding
+ *                         (vertices to ~1e-12 relative on the test templates), not bit for bit.  A fixed (batch, device)
+ *                         reproduces itself bit for bit.  Problems that end in terminal stagnation (an iteration of >= 8
+ *                         rejected dampings in a row: the steps are below one ulp of the state) may differ between shapes
+ *                         in the number of rejected trials of that last iteration; the state returned agrees as above,
  *   dsh_sft_batch_download brings every result of the batch back with ONE copy (outlier classification, inlier count,
  *                         repError and the float32 map points are computed by the kernel) and waits for it.
  * To time the device work, record your own HIP events on dsh_stream() around dsh_sft_batch_run.
@@ -126,7 +139,8 @@ int dsh_sft_batch_download(dsh_ctx* ctx, int B, dsh_sft_result* results);
 int dsh_sft_batch_counts(dsh_ctx* ctx, int64_t* iters, int64_t* trials);
 /* Algorithmic bytes of one assembly pass of problem b (SURVEY 8d convention) and its edge counts
  * counts[9] = M, n_active, curvature edges (reference count), stretch edges, viewed nodes, dim,
- * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload,
+ * half-bandwidth of the node block (scalars), wavefronts per problem of the launch shape chosen at upload (8, 4; 1 = rounds of
+ * phase kernels with one wavefront per factorisation),
  * off-diagonal 3x3 blocks of H (lower triangle). */
 int dsh_sft_batch_problem_info(dsh_ctx* ctx, int b, int64_t* assembly_bytes, int32_t* counts);
 

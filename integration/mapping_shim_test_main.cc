@@ -76,9 +76,21 @@ int main(int argc, char** argv) {
     for (int i = 0; i < kfs[k]->N; i++) out << " " << (kfs[k]->mvpMapPoints[i] ? kfs[k]->mvpMapPoints[i]->id : -1);
     out << "\n";
   }
-  const int solved = devrec ? defslam_hip::ObtainK1K2DeviceHIP<DB, KeyFrame, KeyFrame, MapPointM>(ctx, &db)
+  // argv[5] = n: the first n map points that have records are re-anchored in another keyframe that observes them before the normals are solved
+  // (what MapPoint::EraseObservation does when the reference keyframe loses the point)
+  int reanchor = argc > 5 ? std::atoi(argv[5]) : 0, reanchored = 0;
+  for (int p = 0; p < P && reanchored < reanchor; p++) {
+    MapPointM* mp = mps[p].get();
+    auto flag = db.getToProccess().find(mp);
+    if (flag == db.getToProccess().end() || !flag->second) continue;   // (only points that received a record)
+    for (int k = 0; k < nKF; k++)
+      if (kfs[k].get() != mp->refKF && mp->GetIndexInKeyFrame(kfs[k].get()) >= 0) { mp->refKF = kfs[k].get(); reanchored++; break; }
+  }
+  int skipped = 0;
+  const int solved = devrec ? defslam_hip::ObtainK1K2DeviceHIP<DB, KeyFrame, KeyFrame, MapPointM>(ctx, &db, &skipped)
                             : defslam_hip::ObtainK1K2HIP<DB, KeyFrame, KeyFrame, MapPointM>(ctx, &db);
   out << solved << "\n";
+  if (reanchor) std::fprintf(stderr, "reanchored %d skipped %d\n", reanchored, skipped);
   for (int k = 0; k < nKF; k++) {
     out << kfs[k]->surface->writes << "\n";
     for (int i = 0; i < kfs[k]->N; i++) {

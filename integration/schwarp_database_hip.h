@@ -66,7 +66,7 @@ class SchwarpDatabaseHIP : public Base {
   void erase(KeyFrameT* kf) override { mpkeyframes.erase(kf); }
   void clear() override {
     mpkeyframes.clear();
-    if (devdb_) { dsh_diffdb_clear(devdb_); point_id_.clear(); points_.clear(); tag_kf_.clear(); }
+    if (devdb_) { dsh_diffdb_clear(devdb_); point_id_.clear(); points_.clear(); anchor_kf_.clear(); tag_kf_.clear(); }
   }
   int last_status() const { return status_; }
   ~SchwarpDatabaseHIP() { if (devdb_) dsh_diffdb_destroy(devdb_); }
@@ -77,6 +77,9 @@ class SchwarpDatabaseHIP : public Base {
   const std::vector<MapPointT*>& device_points() const { return points_; }       // map point of a point id
   const std::vector<KeyFrameT*>& device_tags() const { return tag_kf_; }         // second keyframe of a record tag
   int32_t device_point_id(MapPointT* mp) const { auto it = point_id_.find(mp); return it == point_id_.end() ? -1 : it->second; }
+  // the keyframe the point's records are anchored in: its reference keyframe at the time its id was created (every record of the id is stored
+  // under `GetReferenceKeyFrame() == KFi`, so a point that is re-anchored later simply stops receiving records under the old anchor)
+  KeyFrameT* device_point_anchor(int32_t id) const { return anchor_kf_[id]; }
 
  protected:
   static dsh_bbs bbs_of(DefKeyFrameT* KF, int valdim) { return dsh_bbs{KF->umin, KF->umax, KF->NCu, KF->vmin, KF->vmax, KF->NCv, valdim}; }
@@ -195,7 +198,8 @@ class SchwarpDatabaseHIP : public Base {
         MapPointT* mapPoint2 = KF2->GetMapPoint(vMatchedIndices[ikp].second);
         if (!mapPoint || !mapPoint2 || mapPoint->isBad() || mapPoint2->isBad() || mapPoint->GetReferenceKeyFrame() != KFi) continue;
         auto it = point_id_.find(mapPoint);
-        if (it == point_id_.end()) { it = point_id_.emplace(mapPoint, (int32_t)points_.size()).first; points_.push_back(mapPoint); }
+        if (it == point_id_.end()) { it = point_id_.emplace(mapPoint, (int32_t)points_.size()).first; points_.push_back(mapPoint); anchor_kf_.push_back(KFi); }
+        else if (anchor_kf_[it->second] != KFi) continue;   // re-anchored since its first record: its old records belong to another keyframe
         pid[ikp] = it->second;
       }
       dsh_schwarp_problem q{};
@@ -249,6 +253,7 @@ class SchwarpDatabaseHIP : public Base {
   dsh_diffdb* devdb_ = nullptr;
   std::unordered_map<MapPointT*, int32_t> point_id_;
   std::vector<MapPointT*> points_;
+  std::vector<KeyFrameT*> anchor_kf_;   // per point id
   std::vector<KeyFrameT*> tag_kf_;
 };
 
@@ -320,10 +325,13 @@ int ObtainK1K2HIP(dsh_ctx* ctx, WarpDBT* warpDB) {
 }
 
 // The same over the device-resident records (SchwarpDatabaseHIP::enable_device_records): key points in, normals out.  Every stored record
-// is anchored in its point's reference keyframe (the fit stores no other), so there are no first-keyframe normals to look up; a point whose
-// reference keyframe changed after its records were stored is outside this mode.
+// is anchored in the keyframe that was its point's reference keyframe when the point got its id (the fit stores no other), so there are no
+// first-keyframe normals to look up.  A point whose reference keyframe changed since (MapPoint::EraseObservation can reassign mpRefKF) is
+// SKIPPED: the reference would treat its records as non-reference ones (NormalEstimator.cc:80) and that needs the host route's first-keyframe
+// normals; *skipped_reanchored counts them (they stay unsolved, their flag is cleared like the reference clears it).
 template <class WarpDBT, class KeyFrameT, class DefKeyFrameT, class MapPointT>
-int ObtainK1K2DeviceHIP(dsh_ctx* ctx, WarpDBT* warpDB) {
+int ObtainK1K2DeviceHIP(dsh_ctx* ctx, WarpDBT* warpDB, int* skipped_reanchored = nullptr) {
+  if (skipped_reanchored) *skipped_reanchored = 0;
   auto& toProcess = warpDB->getToProccess();
   std::vector<int32_t> ids;
   std::vector<uint8_t> has_x0;
@@ -337,6 +345,7 @@ int ObtainK1K2DeviceHIP(dsh_ctx* ctx, WarpDBT* warpDB) {
     const int32_t id = warpDB->device_point_id(mp);
     if (id < 0) continue;
     KeyFrameT* refKF = mp->GetReferenceKeyFrame();
+    if (refKF != warpDB->device_point_anchor(id)) { if (skipped_reanchored) ++*skipped_reanchored; continue; }
     const size_t idx = mp->GetIndexInKeyFrame(refKF);
     float Ni[3] = {0, 0, 0};
     const bool h = static_cast<DefKeyFrameT*>(refKF)->surface->getNormalSurfacePoint(idx, Ni);

@@ -308,6 +308,25 @@ def test_schwarp_database_hip_and_normal_estimator_hip_follow_the_reference_flow
     dev_lines = open(tmp_path / "out_dev.txt").read().split("\n")
     assert dev_lines[0].split() == [str(nrec), "0"]                # as many records on the device as the host map held; none on the host
     assert dev_lines[1:] == host_lines[1 + nrec:]                  # bookkeeping, normals written into the surfaces, covariances, pending flags
+    # ---- a point whose reference keyframe changed after its records were stored (MapPoint::EraseObservation can reassign mpRefKF): the stored
+    # records are anchored in the OLD keyframe, the device mode has no first-keyframe normals for them -> it must skip the point (and say so),
+    # not solve it against the new keyframe's key point.  The first 3 points with records are re-anchored before the normals are solved.
+    r3 = subprocess.run([exe, str(tmp_path / "in.txt"), str(tmp_path / "out_dev3.txt"), "0", "devrec", "3"], capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stderr
+    assert "reanchored 3 skipped 3" in r3.stderr
+    l3 = open(tmp_path / "out_dev3.txt").read().split("\n")
+    nkf = len(kfs)
+    i_solved = 1 + nkf
+    assert l3[:i_solved] == dev_lines[:i_solved]                   # storing is untouched
+    first3 = pts[:3]
+    lost = int(sum(ng.status[q] == 0 for q in range(3)))
+    assert int(l3[i_solved]) == solved - lost
+    i_cov = i_solved + 1 + sum(1 + int(k["N"]) for k in kfs)
+    for p in range(len(cov)):
+        if p in first3:
+            assert [float(v) for v in l3[i_cov + p].split()] == [0.0, 0.0, 0.0, 0.0]        # never solved: covNorm untouched
+        else:
+            assert l3[i_cov + p] == dev_lines[i_cov + p]
 
 
 def _parse_shim_out(path, n_nodes, N, n_mp):
