@@ -490,6 +490,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             traffic_source = f"none: {type(e).__name__}"
         ms_per_step = 1e3 * wall / args.steps
+        num_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         value = g_iters * args.steps / wall
         kern_ms = kernel_ms / args.steps            # avg duration of the persistent kernel (rank 0)
         # The one persistent kernel is ~70% banded-arrowhead Cholesky (FP64 MFMA) and ~15% assembly (HBM-bound in principle,
@@ -524,7 +525,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("all launches of a step (sftb_lin / sftb_factor / sftb_trial kernels)" if int(counts[7]) == 1 else
-                                    ("sft_lm_kernel<4>" if int(counts[7]) == 4 else "sft_lm_kernel<8> / sft_spec_kernel<8>")), "kernel_ms": kern_ms,
+                                    ("sft_lm_kernel<4>" if int(counts[7]) == 4 else
+                                     # eight wavefronts per problem: the persistent kernel above half a problem per CU, the latency mode below
+                                     ("sft_spec_kernel<8> (latency mode: every launch of the step)" if 2 * args.batch <= num_cus else "sft_lm_kernel<8>"))), "kernel_ms": kern_ms,
                          "timing": "HIP events recorded by bench.py on dsh_stream() around the K steps of the product library",
                          "algorithmic_flops_per_launch": flops_per_launch, "flops_per_lm_trial": flops_trial, "dim": Dn + 6, "half_bandwidth": kd,
                          "hbm_assembly": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
