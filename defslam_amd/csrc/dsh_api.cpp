@@ -25,7 +25,7 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
@@ -139,6 +139,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool rounds_mode = false;
   SftRun* d_runs = nullptr;            // B controller states + the done counter behind them, inside d_batch
   int* d_counters = nullptr;
+  int* d_linlist = nullptr;            // B ints behind the counters: the problems the next LIN launch linearises (sft_batch.h)
   size_t lds_configured_b[2] = {0, 0};
   int rounds_hint = 24;                // rounds the previous run of this context needed
   // The batch runs as up to kMaxSub sub-batches on streams of their own: the launches of a round are enqueued sub-batch by sub-batch, so
@@ -308,7 +309,7 @@ int run_rounds(dsh_ctx* c) {
   auto launch = [&](int s, int phase) {
     const bool ev = c->phase_events && S == 1;
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
-    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, b0[s + 1] - b0[s], phase, c->jl_doubles, c->lds_configured_b,
+    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->lds_configured_b,
                                      c->num_cus, c->sub_stream[s]);
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
     return r;
@@ -591,7 +592,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   // (4 wavefronts: two problems share a CU's 160 KB)
   size_t jl_doubles = 0;
   int max_kd = 0;
-  const size_t lds_budget = (((nw == 4 || SFT_WAVES_PER_EU >= 4) ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
+  // (rounds of phase kernels: the LIN kernel is the only one that stages records, eight wavefronts and one workgroup per CU -- sft_batch.h)
+  const size_t lds_budget = ((((nw == 4 && !c->rounds_mode) || SFT_WAVES_PER_EU >= 4) ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
   for (int b = 0; b < B; b++) {
     SftDev& hh = c->packed[b].h;
     // A narrow band (kd <= 128) that is long enough for two parts also takes the two-sided factorisation in latency mode: it runs on the
@@ -672,7 +674,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
-  const size_t o_runs = a.take(c->rounds_mode ? sizeof(SftRun) * (size_t)B + 64 * dsh_ctx::kMaxSub : 0);
+  const size_t o_runs = a.take(c->rounds_mode ? sizeof(SftRun) * (size_t)B + 64 * dsh_ctx::kMaxSub + sizeof(int) * (size_t)B : 0);
   for (int e = 0; e < B * K; e++) {
     const int b = e % B, lane = e / B;
     const SftDev& h = c->packed[b].h;
@@ -796,6 +798,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->d_spec = (SftSpec*)(base + o_spec);
   c->d_runs = (SftRun*)(base + o_runs);
   c->d_counters = (int*)(base + o_runs + sizeof(SftRun) * (size_t)B);
+  c->d_linlist = c->d_counters + 16 * dsh_ctx::kMaxSub;
   c->spec_bytes = sizeof(SftSpec) * (size_t)B * K;
   c->spec_k = K;
   c->any_split = false;
@@ -1295,7 +1298,7 @@ int dsh_lab_sft_assemble_timed(dsh_ctx* c, int launches, double* total_ms) {
   EventPair ev;
   HIPCHK(c, ev.create());
   HIPCHK(c, hipEventRecord(ev.e0, c->stream));
-  for (int i = 0; i < launches; i++) HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));
+  for (int i = 0; i < launches; i++) HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->rounds_mode ? 8 : c->nw, c->stream));
   HIPCHK(c, hipEventRecord(ev.e1, c->stream));
   HIPCHK(c, hipEventSynchronize(ev.e1));
   float ms = 0.f;
@@ -1312,7 +1315,7 @@ int dsh_lab_sft_wave_check(dsh_ctx* c, double rel, int launches, int only, doubl
   for (int b = 0; b < c->B; b++)
     if (c->h_probs[b].tile_mode != 1) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_wave_check: register-window problems (half-bandwidth <= 128) only");
   (void)hipSetDevice(c->device);
-  HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->stream));   // H of the initial state
+  HIPCHK(c, sft_assembly_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->rounds_mode ? 8 : c->nw, c->stream));   // H of the initial state
   EventPair ev;
   HIPCHK(c, ev.create());
   for (int which = 0; which < 2; which++) {

@@ -1,5 +1,5 @@
 // The throughput shape of the batched solver: the Levenberg-Marquardt loop of B independent problems as ROUNDS of phase kernels,
-//   LIN     residuals + Jacobian records + normal equations        (problems that start an iteration;   256 threads)
+//   LIN     residuals + Jacobian records + normal equations        (problems that start an iteration;   512 threads)
 //   FACTOR  (H + lambda I) x = b, one wavefront per problem         (every problem that is still running;  64 threads, sft_wave.h)
 //   TRIAL   state update, chi2 of the trial, LM controller          (the same problems;                   256 threads)
 // instead of one persistent kernel per problem (sft_lm_kernel).  Why: the factorisation wants a wave that owns a whole SIMD (512
@@ -11,7 +11,13 @@
 // (optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:403-475, DefOptimizer.cc:513).
 #pragma once
 
-#define SFTB_NW 4   // wavefronts of a LIN / TRIAL workgroup
+#define SFTB_NW 4   // wavefronts of a TRIAL workgroup
+#ifndef SFTB_LIN_NW
+// Wavefronts of a LIN workgroup: 8 = one workgroup per CU with the CU's whole LDS, so every record class the assembly gathers (node matrices and
+// stretching records too: placement class 2, sft_kernels.hip AsmRec) is an LDS read.  Measured on 16384 C2 problems (tools/diag/assembly_shapes.py):
+// 7.22 ms per pass against 8.13-8.18 with 4 wavefronts and two workgroups per CU (class 1).
+#define SFTB_LIN_NW 8
+#endif
 #ifndef SFTB_LIN_WAVES
 #define SFTB_LIN_WAVES 2   // waves per SIMD the LIN kernel is compiled for (A/B: tools/ab_build.sh NAME "-DSFTB_LIN_WAVES=3")
 #endif
@@ -26,7 +32,7 @@ __device__ __forceinline__ void sftb_ctl_lds(char* smem, Ctl*& ctl, double*& red
   panel = out + 32;
 }
 
-__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters) {
+__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list) {
   const SftDev& P = probs[blockIdx.x];
   init_state<64 * SFTB_NW>(P);
   if (threadIdx.x == 0) {
@@ -34,33 +40,47 @@ __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev
     R.lambda = -1.0; R.ni = 2.0; R.chi_cur = 0.0; R.chi_ini = 0.0; R.rho = 0.0; R.lambda_start = 0.0;
     R.it = 0; R.qmax = 0; R.nbad = 0; R.accepted = 0; R.all_ok = 1; R.iters = 0; R.trials = 0; R.fact_ok = 1;
     R.state = P.max_iters > 0 ? SFTB_LIN : SFTB_FINISH;
-    if (blockIdx.x == 0) { counters[0] = 0; counters[1] = 0; }
+    if (P.max_iters > 0) lin_list[atomicAdd(&counters[2], 1)] = blockIdx.x;   // (the host zeroes the counters in front of this launch)
   }
 }
 
 // LIN: a problem that starts an outer iteration is linearised; the first iteration also fixes the initial damping (tau = 1e-5).
-__global__ __launch_bounds__(64 * SFTB_NW, SFTB_LIN_WAVES) void sftb_lin_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs) {
-  constexpr int NW = SFTB_NW, NT = 64 * NW;
-  SftRun& R = runs[blockIdx.x];
-  if (R.state != SFTB_LIN) return;
+// Persistent workgroups pull the problems from the list the previous TRIAL (or INIT) launch appended them to (counters[2] entries, work counter
+// counters[3]; FACTOR resets both): a launch over all B problems spent 0.1-0.2 ms per round on workgroups that found nothing to do -- each of
+// them holds a CU's LDS while it finds out.  The order of the list varies from run to run; the problems are independent, the results do not.
+__global__ __launch_bounds__(64 * SFTB_LIN_NW, SFTB_LIN_WAVES) void sftb_lin_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters,
+                                                                                  const int* __restrict__ lin_list) {
+  constexpr int NW = SFTB_LIN_NW, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const SftDev& P = probs[blockIdx.x];
+  __shared__ int next_b;
   Ctl* ctl; double *red, *out, *panel;
   sftb_ctl_lds(smem, ctl, red, out, panel);
   const int tid = threadIdx.x;
-  const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
-  double lambda = R.lambda;
-  if (R.it == 0) {
-    double mx = 0.0;
-    for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
-    if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
-    mx = block_max(mx, red);
-    lambda = 1e-5 * mx;
-  }
-  if (tid == 0) {
-    if (R.it == 0) { R.lambda = lambda; R.ni = 2.0; R.nbad = 0; }
-    R.chi_cur = chi0; R.chi_ini = chi0; R.qmax = 0; R.rho = 0.0; R.accepted = 0; R.all_ok = 1; R.lambda_start = lambda;
-    R.state = SFTB_TRIAL;
+  while (true) {
+    __syncthreads();   // (the previous problem is done with the LDS)
+    if (tid == 0) {
+      const int i = atomicAdd(&counters[3], 1);
+      next_b = i < counters[2] ? lin_list[i] : -1;
+    }
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(next_b);
+    if (b < 0) break;
+    SftRun& R = runs[b];
+    const SftDev& P = probs[b];
+    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+    double lambda = R.lambda;
+    if (R.it == 0) {
+      double mx = 0.0;
+      for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+      if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+      mx = block_max(mx, red);
+      lambda = 1e-5 * mx;
+    }
+    if (tid == 0) {
+      if (R.it == 0) { R.lambda = lambda; R.ni = 2.0; R.nbad = 0; }
+      R.chi_cur = chi0; R.chi_ini = chi0; R.qmax = 0; R.rho = 0.0; R.accepted = 0; R.all_ok = 1; R.lambda_start = lambda;
+      R.state = SFTB_TRIAL;
+    }
   }
 }
 
@@ -71,6 +91,7 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
   lds_double* lds = to_lds(reinterpret_cast<double*>(smem));
   const int lane = threadIdx.x;
   for (int i = lane; i < WV_LDS_DOUBLES; i += 64) lds[i] = 0.0;   // (the landing buffer is multiplied by ring zeros before its first fill)
+  if (blockIdx.x == 0 && lane == 0) { counters[2] = 0; counters[3] = 0; }   // the LIN list of this round is consumed; TRIAL appends the next one
   WvPrev Q;
   Q.Lg = nullptr; Q.Linv = nullptr; Q.x = nullptr; Q.nT = 0; Q.active = 0; Q.xb = 0.0;
   while (true) {
@@ -91,7 +112,7 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
 
 // TRIAL: push, x applied, scale, chi2 at the trial state, the controller's verdict; pop on rejection; at the end of an iteration the stop
 // rules; at the end of the problem the classification.
-__global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters) {
+__global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list) {
   constexpr int NW = SFTB_NW, NT = 64 * NW;
   SftRun& R = runs[blockIdx.x];
   const int st = R.state;
@@ -180,6 +201,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
     ctl->it = R.iters;
     ctl->accepted = R.trials;
     R.state = term ? SFTB_DONE : SFTB_LIN;
+    if (!term) lin_list[atomicAdd(&counters[2], 1)] = blockIdx.x;
   }
   __syncthreads();
   if (ctl->nbad) {

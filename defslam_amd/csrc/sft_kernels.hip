@@ -3266,7 +3266,8 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 #ifdef DSH_LAB
 extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int which, double rel, int max_kd, size_t jl_doubles, hipStream_t stream) {
   if (which == 0) {
-    const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+    (void)jl_doubles;   // (the solver workspace only: this kernel does not assemble)
+    const size_t lds = sft_lm_kernel_lds_bytes(max_kd, 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_ref_solve_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sft_ref_solve_kernel<4>, dim3(B), dim3(256), lds, stream, d_probs, rel);
@@ -3279,10 +3280,12 @@ extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int whic
 
 // Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the calling context): the dynamic LDS sizes the
 // LIN and TRIAL kernels were last enabled for on that device.
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream) {
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream) {
   const size_t head = 512 + (16 * 27 + 5 + 32) * sizeof(double) + 64;
   if (phase == SFTB_PH_INIT) {
-    hipLaunchKernelGGL(sftb_init_kernel, dim3(B), dim3(64 * SFTB_NW), 0, stream, d_probs, d_runs, d_counters);
+    hipError_t e = hipMemsetAsync(d_counters, 0, 16 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sftb_init_kernel, dim3(B), dim3(64 * SFTB_NW), 0, stream, d_probs, d_runs, d_counters, d_list);
   } else if (phase == SFTB_PH_LIN) {
     const size_t lds = head + jl_doubles * sizeof(double);
     if (lds > configured[0]) {
@@ -3290,7 +3293,8 @@ extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_
       if (e != hipSuccess) return e;
       configured[0] = lds;
     }
-    hipLaunchKernelGGL(sftb_lin_kernel, dim3(B), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs);
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;   // persistent workgroups: as many as are resident at once
+    hipLaunchKernelGGL(sftb_lin_kernel, dim3(std::min(B, per_cu * num_cus)), dim3(64 * SFTB_LIN_NW), lds, stream, d_probs, d_runs, d_counters, d_list);
   } else if (phase == SFTB_PH_FACTOR) {
     hipLaunchKernelGGL(sftb_factor_kernel, dim3(std::min(B, 4 * num_cus)), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs, d_runs, d_counters, B);   // one wave per SIMD
   } else {
@@ -3300,7 +3304,7 @@ extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_
       if (e != hipSuccess) return e;
       configured[1] = lds;
     }
-    hipLaunchKernelGGL(sftb_trial_kernel, dim3(B), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs, d_counters);
+    hipLaunchKernelGGL(sftb_trial_kernel, dim3(B), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs, d_counters, d_list);
   }
   return hipGetLastError();
 }

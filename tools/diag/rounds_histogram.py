@@ -19,8 +19,15 @@ active = np.array([(T >= r).sum() for r in range(1, R + 1)])
 waves = 1024
 sets = np.ceil(active / waves)
 print("rounds", R, "factor wave-sets", int(sets.sum()), "ideal", T.sum() / waves)
+lin = np.zeros(R + 1, int)
+for f in frames:
+    r = 1
+    for q in f.trace[:f.iters, 2].astype(int):
+        lin[r - 1] += 1
+        r += q
+print("round: problems in FACTOR / TRIAL, factor wave-sets, problems linearised")
 for r in range(R):
-    print(r + 1, active[r], int(sets[r]))
+    print(r + 1, active[r], int(sets[r]), lin[r])
 # speculation: per problem the trial sequence per iteration (trace[:, 2]); in rounds where K * active <= waves a rejection run of n trials takes ceil(n / K) rounds
 def rounds_with_spec(Kmax):
     # simulate: every problem advances through its list of runs; global rounds; K chosen per round from the active count
