@@ -669,6 +669,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   wv_prologue_row<4>(W, lds, lane); wv_prologue_row<5>(W, lds, lane); wv_prologue_row<6>(W, lds, lane); wv_prologue_row<7>(W, lds, lane);
   wv_list(W, 8, 8, lane, S.al);
   wv_wait_vm();
+  asm volatile("" : "+v"(S.al[0]), "+v"(S.al[1]), "+v"(S.al[2]), "+v"(S.al[3]));   // (consumed here as far as the compiler is concerned: see the step head)
 #ifdef DSH_LAB
   const long long wv_t1 = clock64();
 #endif
@@ -680,9 +681,12 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
     // Requests of this step, issued in front of the tile Cholesky (2 us of vector-ALU work: they arrive behind it) and consumed behind the
     // TRSM -- nothing of them is alive during the trailing update, where the 9 Y tiles and the pipelined LDS tiles need the registers.
     S.araw = wv_gather_vgpr(W, S.al);            // tile (k+8, k)^T through the list that came a step ahead
+    // The next list right behind it, in FRONT of the other requests: the wait that consumes them (behind the TRSM) covers it as well, so the
+    // compiler's wait in front of the gather above is s_waitcnt vmcnt(14) instead of vmcnt(0) (the list was the youngest load crossing the back
+    // edge).  Measured: no change of the head section (1.32 k cycles either way) -- what is in flight there has long landed.
+    wv_list(W, k + 9, 8, lane, S.al);
     wv_row_list(W, k + 8, lane, S.rl);
     S.bnext = wv_border_fresh(W, k + 8, lane);
-    wv_list(W, k + 9, 8, lane, S.al);
     v4d d;
     switch (ph) {
       case 0: d = wv_step_diag<0>(W, k, lane); break;
