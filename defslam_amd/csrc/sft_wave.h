@@ -182,6 +182,18 @@ __device__ __forceinline__ void wv_bord_store(lds_double* tile, int lane, const 
 }
 
 // ---- 16 x 16 Cholesky + inverse, every MFMA as asm on VGPR tiles (tile_chol.h: chol_inv_blocked is the compiler-scheduled original) --
+// 1/sqrt(d): the v_rsq_f64 seed (2^-26) and ONE step that carries the second-order term, y (1 + e/2 + 3 e^2/8) with e = 1 - d y^2 exact through
+// the fused multiply-add: 5 instructions behind the seed where rsqrt_sqrt (tile_chol.h) issues 9 -- 64 fewer vector instructions per factor
+// step, each of which would occupy the FP64 pipe.  Accuracy: tools/probes/rsqrt_probe.hip (both within an ulp of the correctly rounded value).
+__device__ __forceinline__ double wv_rsqrt(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double t = d * y;
+  const double e = fma(-t, y, 1.0);
+  const double p = fma(0.375, e, 0.5);
+  const double q = y * e;
+  return fma(q, p, y);
+}
+
 __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
@@ -194,17 +206,16 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
     const double d00 = bcast_lane(aJ, b0), d10 = bcast_lane(aJ, 16 + b0), d11 = bcast_lane(aJ, 16 + b0 + 1);
     const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
     const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
-    double i0, i1, i2, i3, sq;
-    rsqrt_sqrt(d00, i0, sq);
+    const double i0 = wv_rsqrt(d00);
     const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
     const double p1 = fma(-l10, l10, d11);
-    rsqrt_sqrt(p1, i1, sq);
+    const double i1 = wv_rsqrt(p1);
     const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
     const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
-    rsqrt_sqrt(p2, i2, sq);
+    const double i2 = wv_rsqrt(p2);
     const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
     const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-    rsqrt_sqrt(p3, i3, sq);
+    const double i3 = wv_rsqrt(p3);
     plast = p3;
     const double m10 = -(l10 * i0) * i1;
     const double m21 = -(l21 * i1) * i2;
@@ -622,15 +633,42 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
   WV_T(8);
 }
 
-// prologue: tile rows 0..7 of H into the window
+// prologue: tile rows 0..7 of H into the window.  The compiler does not see the accumulator gathers (asm), so any wait it inserts for a load
+// it does see also waits for gathers issued in between -- a round trip of everything in flight.  The rows used to be fetched one after the
+// other, lists, gathers, border and the LDS-resident d = 4 tile each (20 such drains: 33-48 k cycles per factorisation with the MFMA pipe idle).
+// Now: the gather lists of all 36 tiles first (144 registers; the window is not live yet), ONE wait, every gather back to back, the border
+// loads, and what goes to LDS is stored behind the last request.
+struct WvTriList { unsigned o[36][4]; };   // tile (R, d), d <= R, at R (R + 1) / 2 + d
+template <int R, int D>
+__device__ __forceinline__ void wv_prologue_lists(const WvProb& W, int lane, WvTriList& T) {
+  if constexpr (R < 8) {
+    wv_list(W, R, D, lane, T.o[R * (R + 1) / 2 + D]);
+    if constexpr (D < R) wv_prologue_lists<R, D + 1>(W, lane, T);
+    else wv_prologue_lists<R + 1, 0>(W, lane, T);
+  }
+}
+template <int R, int D>
+__device__ __forceinline__ void wv_prologue_gathers(const WvProb& W, WvTriList& T, v4d (&f4)[8]) {
+  if constexpr (R < 8) {
+    unsigned (&o)[4] = T.o[R * (R + 1) / 2 + D];
+    if constexpr (R == 0 && D == 0) {   // the lists have arrived -- said once, in front of the first gather
+#pragma unroll
+      for (int t = 0; t < 36; t++) asm volatile("" : "+v"(T.o[t][0]), "+v"(T.o[t][1]), "+v"(T.o[t][2]), "+v"(T.o[t][3]));
+    }
+    if constexpr (D == 4) f4[R] = wv_gather_vgpr(W, o);
+    else wv_gather_agpr<wv_phys(R, D)>(W.Hc, o[0], o[1], o[2], o[3]);
+    if constexpr (D < R) wv_prologue_gathers<R, D + 1>(W, T, f4);
+    else wv_prologue_gathers<R + 1, 0>(W, T, f4);
+  }
+}
 template <int PH>
-__device__ __forceinline__ void wv_prologue_row(const WvProb& W, lds_double* lds, int lane) {
-  WvRowList L;
-  wv_row_list(W, PH, lane, L);
-  v4d fresh4 = {0.0, 0.0, 0.0, 0.0};
-  wv_row_fetch_d<PH, 0>(W, L, PH, fresh4);
-  if constexpr (PH >= 4) wv_lds_store(lds + WV_L_WIN + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, fresh4);
-  wv_bord_store(lds + WV_L_BORD + 128 * PH, lane, wv_border_fresh(W, PH, lane));
+__device__ __forceinline__ void wv_prologue_store(lds_double* lds, int lane, v4d& f4, v4d& bd) {
+  if constexpr (PH >= 4) {
+    asm volatile("" : "+v"(f4));   // (VGPR operands where they are consumed: see S.bnext in wv_step_rest)
+    wv_lds_store(lds + WV_L_WIN + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, f4);
+  }
+  asm volatile("" : "+v"(bd));
+  wv_bord_store(lds + WV_L_BORD + 128 * PH, lane, bd);
 }
 
 // ---- the factorisation of one problem by one wavefront (+ the deferred back substitution of the wave's previous problem) ----------------------
@@ -665,9 +703,18 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
     if (r < SFT_BORDER && c < SFT_BORDER && c <= r) S.corner[q] = P.Hcorner[r * 7 + c] + ((r == c && r < 6) ? lam_corner : 0.0);
   }
   S.ok = 1;
-  wv_prologue_row<0>(W, lds, lane); wv_prologue_row<1>(W, lds, lane); wv_prologue_row<2>(W, lds, lane); wv_prologue_row<3>(W, lds, lane);
-  wv_prologue_row<4>(W, lds, lane); wv_prologue_row<5>(W, lds, lane); wv_prologue_row<6>(W, lds, lane); wv_prologue_row<7>(W, lds, lane);
-  wv_list(W, 8, 8, lane, S.al);
+  {
+    WvTriList T;
+    v4d f4[8], bd[8];
+    wv_prologue_lists<0, 0>(W, lane, T);
+    wv_prologue_gathers<0, 0>(W, T, f4);
+#pragma unroll
+    for (int r = 0; r < 8; r++) bd[r] = wv_border_fresh(W, r, lane);
+    wv_list(W, 8, 8, lane, S.al);
+    wv_prologue_store<0>(lds, lane, f4[0], bd[0]); wv_prologue_store<1>(lds, lane, f4[1], bd[1]); wv_prologue_store<2>(lds, lane, f4[2], bd[2]);
+    wv_prologue_store<3>(lds, lane, f4[3], bd[3]); wv_prologue_store<4>(lds, lane, f4[4], bd[4]); wv_prologue_store<5>(lds, lane, f4[5], bd[5]);
+    wv_prologue_store<6>(lds, lane, f4[6], bd[6]); wv_prologue_store<7>(lds, lane, f4[7], bd[7]);
+  }
   wv_wait_vm();
   asm volatile("" : "+v"(S.al[0]), "+v"(S.al[1]), "+v"(S.al[2]), "+v"(S.al[3]));   // (consumed here as far as the compiler is concerned: see the step head)
 #ifdef DSH_LAB
