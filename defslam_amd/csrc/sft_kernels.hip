@@ -518,8 +518,10 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
 // 16-lane row; no LDS crossbar, no wait): only the lanes that feed lane 0 of a group matter, and they read inside the group.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  // (mov_dpp: the destination of a lane whose source is outside its row stays undefined instead of 0 -- update_dpp(0, ...) costs a v_mov of
+  // the zero in front of every move; the lanes that read outside never feed lane 0 of a group, see group8_sum)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double group8_sum(double v) {

@@ -182,6 +182,16 @@ __device__ __forceinline__ void wv_bord_store(lds_double* tile, int lane, const 
 }
 
 // ---- 16 x 16 Cholesky + inverse, every MFMA as asm on VGPR tiles (tile_chol.h: chol_inv_blocked is the compiler-scheduled original) --
+// A lane's value moved along its 16-lane row.  row_ror reads a valid lane for every lane, so the destination's previous content never shows --
+// __builtin_amdgcn_mov_dpp leaves it undefined, where update_dpp(0, ...) (dpp_mov in sft_kernels.hip) makes the compiler write a zero into
+// the destination in front of every move: 32 v_mov_b32 per factor step in the deferred back substitution's all-reduce.
+template <int CTRL>
+__device__ __forceinline__ double wv_dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 // 1/sqrt(d): the v_rsq_f64 seed (2^-26) and ONE step that carries the second-order term, y (1 + e/2 + 3 e^2/8) with e = 1 - d y^2 exact through
 // the fused multiply-add: 5 instructions behind the seed where rsqrt_sqrt (tile_chol.h) issues 9 -- 64 fewer vector instructions per factor
 // step, each of which would occupy the FP64 pipe.  Accuracy: tools/probes/rsqrt_probe.hip (both within an ulp of the correctly rounded value).
@@ -351,10 +361,10 @@ __device__ __forceinline__ void wv_bs_column(const WvPrev& Q, int J, const lds_d
   }
 #pragma unroll
   for (int q = 0; q < 4; q++) {   // all-reduce over the 16 lanes of a row (fixed butterfly: row_ror 8, 4, 2, 1)
-    s[q] += dpp_mov<0x128>(s[q]);
-    s[q] += dpp_mov<0x124>(s[q]);
-    s[q] += dpp_mov<0x122>(s[q]);
-    s[q] += dpp_mov<0x121>(s[q]);
+    s[q] += wv_dpp_mov<0x128>(s[q]);
+    s[q] += wv_dpp_mov<0x124>(s[q]);
+    s[q] += wv_dpp_mov<0x122>(s[q]);
+    s[q] += wv_dpp_mov<0x121>(s[q]);
   }
   const v2d_w wa = t2[128 * 9], wb = t2[128 * 9 + 1];
   double p = wa.x * -s[0];
@@ -406,10 +416,10 @@ __device__ __forceinline__ void wv_backsub_now(const WvPrev& Q, int lane) {
       for (int q = 0; q < 4; q++) s[q] = fma(C.t[dd][q], xr[(ph + dd) & 7], s[q]);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      s[q] += dpp_mov<0x128>(s[q]);
-      s[q] += dpp_mov<0x124>(s[q]);
-      s[q] += dpp_mov<0x122>(s[q]);
-      s[q] += dpp_mov<0x121>(s[q]);
+      s[q] += wv_dpp_mov<0x128>(s[q]);
+      s[q] += wv_dpp_mov<0x124>(s[q]);
+      s[q] += wv_dpp_mov<0x122>(s[q]);
+      s[q] += wv_dpp_mov<0x121>(s[q]);
     }
     double p = C.t[9][0] * -s[0];
 #pragma unroll
