@@ -451,6 +451,7 @@ struct WvState {
   v4d bnext;         // raw border tile of column k+8 (enters the ring this step): requested at the head of the step
   WvRowList rl;      // gather lists of the row that enters the window this step (row k+8): requested at the head of the step
   unsigned al[4];    // gather list of tile (k+9, k+1), the next step's araw -- the only request that is carried across the update
+  unsigned off_lane, off_bord;   // byte offsets of the lane inside a 2 KB tile slot of L (32 l) and inside the compact border tile
   int ok;
 };
 
@@ -502,11 +503,15 @@ __device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int
         constexpr int n = wv_tile_index(I, J);
         if constexpr (n < 18) {   // half (n & 1) of tile n / 2: lanes' registers 2 (n & 1), 2 (n & 1) + 1
           const v4d& y = S.Y[n >> 1];
+          // scalar base (the slot of the tile, wave-uniform: SALU) + the lane's 32-bit offset + immediate: as a pointer expression every
+          // store cost one or two 64-bit vector adds for its address (35 vector instructions per step on the one FP64 pipe)
+          const v2d_w half = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+          const SFT_G double* slot = col + 256 * (n >> 1);
           if constexpr (n < 2) {   // the border tile Yb: only its 32 lanes c < 8 carry data (the others mirror them) -- 1 KB instead of 2
             const int ln = threadIdx.x & 63;
-            if ((ln & 15) < 8) *reinterpret_cast<SFT_G v2d_w*>(col - 4 * ln + 4 * ((ln >> 4) * 8 + (ln & 7)) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+            if ((ln & 15) < 8) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3" :: "v"(S.off_bord), "v"(half), "s"(slot), "n"(16 * (n & 1)) : "memory");
           } else {
-            *reinterpret_cast<SFT_G v2d_w*>(col + 256 * (n >> 1) + 2 * (n & 1)) = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3" :: "v"(S.off_lane), "v"(half), "s"(slot), "n"(16 * (n & 1)) : "memory");
           }
         }
         // ... and two of the 28 gathers of the row that enters the window (the tiles of ring row PH are free since the TRSM): like the
@@ -606,7 +611,7 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
   // L leaves from the registers it was computed in: block column k = [Yb | Y_1 .. Y_8] at slots (k, 0..8), 2 KB each (lane l: 32 bytes at
   // 32 l) -- stored half by half between the MFMAs of the update below (wv_update_tiles); tiles behind the matrix are stored as the
   // zeros they are
-  SFT_G double* col = W.Lg + ((size_t)k * (BT + 1)) * 256 + 4 * lane;
+  SFT_G double* col = W.Lg + ((size_t)k * (BT + 1)) * 256;   // (wave-uniform; the lanes' offsets are S.off_lane / S.off_bord)
   // ---- the ring row / border slot of column k are free: row k+8 enters (its lists came a step ahead), the lists of row k+9 are requested
   v4d fresh4 = wv_gather_vgpr(W, S.rl.o[4]);   // (the accumulator-file tiles of the row: wv_update_tiles)
   // A value that is only loaded and stored may be allocated to the accumulator file by the compiler (memory instructions address it) --
@@ -737,6 +742,11 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
     const int ph = k & 7;
     // Requests of this step, issued in front of the tile Cholesky (2 us of vector-ALU work: they arrive behind it) and consumed behind the
     // TRSM -- nothing of them is alive during the trailing update, where the 9 Y tiles and the pipelined LDS tiles need the registers.
+    // the lanes' byte offsets inside a 2 KB tile slot of L / inside the compact border tile: computed every step by statements the compiler
+    // cannot hoist -- as loop invariants such registers were parked in the accumulator file, on a window tile (tools/wave_audit.py)
+    asm volatile("v_lshlrev_b32 %0, 5, %1" : "=v"(S.off_lane) : "v"(lane));
+    // 32 ((l >> 4) 8 + (l & 7)) = ((32 l >> 1) & 0x300) | (32 l & 0xe0)
+    asm volatile("v_lshrrev_b32 %0, 1, %1\n\tv_and_b32 %0, 0x300, %0\n\tv_bfi_b32 %0, %2, %1, %0" : "=&v"(S.off_bord) : "v"(S.off_lane), "s"(0xe0));
     S.araw = wv_gather_vgpr(W, S.al);            // tile (k+8, k)^T through the list that came a step ahead
     // The next list right behind it, in FRONT of the other requests: the wait that consumes them (behind the TRSM) covers it as well, so the
     // compiler's wait in front of the gather above is s_waitcnt vmcnt(14) instead of vmcnt(0) (the list was the youngest load crossing the back
@@ -764,7 +774,11 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
       S.ok = 0;
     }
     WV_T(1);
-    *reinterpret_cast<SFT_G v4d*>(W.Linv + (size_t)k * 256 + 4 * lane) = w;
+    {   // W of column k leaves like the tiles of L: scalar base + the lane's 32-bit offset
+      const SFT_G double* slot = W.Linv + (size_t)k * 256;
+      const v2d_w w01 = (v2d_w){w[0], w[1]}, w23 = (v2d_w){w[2], w[3]};
+      asm volatile("global_store_dwordx4 %0, %1, %3\n\tglobal_store_dwordx4 %0, %2, %3 offset:16" :: "v"(S.off_lane), "v"(w01), "v"(w23), "s"(slot) : "memory");
+    }
     // W^T in accumulator order: through LDS (element [row][col] at row * 17 + col)
     v4d Wt;
     {
