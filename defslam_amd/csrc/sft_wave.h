@@ -227,17 +227,14 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
     const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
     const double i3 = wv_rsqrt(p3);
     plast = p3;
-    const double m10 = -(l10 * i0) * i1;
-    const double m21 = -(l21 * i1) * i2;
-    const double m32 = -(l32 * i2) * i3;
-    const double m20 = -fma(l21, m10, l20 * i0) * i2;
-    const double m31 = -fma(l32, m21, l31 * i1) * i3;
-    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * i0)) * i3;
-    double sel = 0.0;
-    sel = (c == 0 && g == 0) ? i0 : sel;
-    sel = (c == 1) ? (g == 0 ? m10 : (g == 1 ? i1 : 0.0)) : sel;
-    sel = (c == 2) ? (g == 0 ? m20 : (g == 1 ? m21 : (g == 2 ? i2 : 0.0))) : sel;
-    sel = (c == 3) ? (g == 0 ? m30 : (g == 1 ? m31 : (g == 2 ? m32 : i3))) : sel;
+    // M = Ld^-1, lane (g, c) needs M[c][g] (c < 4): every lane solves Ld x = e_g -- its own column of the inverse -- by the same four
+    // steps of forward substitution (10 instructions) and keeps x_c; the explicit formulas of the six off-diagonal entries followed by a
+    // ten-way select (chol_inv_blocked in tile_chol.h) take 41 where this takes 22.
+    const double x0 = ((g == 0) ? 1.0 : 0.0) * i0;
+    const double x1 = fma(-l10, x0, (g == 1) ? 1.0 : 0.0) * i1;
+    const double x2 = fma(-l21, x1, fma(-l20, x0, (g == 2) ? 1.0 : 0.0)) * i2;
+    const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, (g == 3) ? 1.0 : 0.0))) * i3;
+    const double sel = (c == 0) ? x0 : (c == 1) ? x1 : (c == 2) ? x2 : (c == 3) ? x3 : 0.0;
     const double wJ = w[J];
     v4d zw, z;
     if (J < 3) {
