@@ -234,7 +234,11 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
     const double x1 = fma(-l10, x0, (g == 1) ? 1.0 : 0.0) * i1;
     const double x2 = fma(-l21, x1, fma(-l20, x0, (g == 2) ? 1.0 : 0.0)) * i2;
     const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, (g == 3) ? 1.0 : 0.0))) * i3;
-    const double sel = (c == 0) ? x0 : (c == 1) ? x1 : (c == 2) ? x2 : (c == 3) ? x3 : 0.0;
+    // (x3 is the last value of the chain: it enters the last select, the others are chosen while it is still being computed)
+    double sel = (c == 0) ? x0 : 0.0;
+    sel = (c == 1) ? x1 : sel;
+    sel = (c == 2) ? x2 : sel;
+    sel = (c == 3) ? x3 : sel;
     const double wJ = w[J];
     v4d zw, z;
     if (J < 3) {
