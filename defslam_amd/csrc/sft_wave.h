@@ -493,12 +493,13 @@ __device__ __forceinline__ void wv_fetch_slot(const WvProb& W, const WvRowList& 
     wv_gather1_agpr<wv_phys(PH, d), q>(W.Hc, L.o[d][q]);
   }
 }
-template <int PH, int I, int J>
+template <int PH, bool TAIL, int I, int J>
 __device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int k, int nT, int q8, SFT_G double* col) {
   if constexpr (I <= 8) {
     constexpr int d = I - J, r = (PH + I) & 7;
     if constexpr (d != 4) {
-      if (k + I < nT) wv_upd_agpr<wv_phys(r, d)>(S.Y[J], S.Y[I], (I == 8) ? q8 : 0);
+      // (TAIL: the last eight steps of a factorisation, where rows of the window lie behind the matrix -- the others carry no branch)
+      if (!TAIL || k + I < nT) wv_upd_agpr<wv_phys(r, d)>(S.Y[J], S.Y[I], (I == 8) ? q8 : 0);
       if constexpr (I <= 7) {
         constexpr int n = wv_tile_index(I, J);
         if constexpr (n < 18) {   // half (n & 1) of tile n / 2: lanes' registers 2 (n & 1), 2 (n & 1) + 1
@@ -520,14 +521,14 @@ __device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int
         wv_fetch_slot<PH, 2 * n + 1>(W, S.rl);
       }
     }
-    if constexpr (J < I) wv_update_tiles<PH, I, J + 1>(W, S, k, nT, q8, col);
+    if constexpr (J < I) wv_update_tiles<PH, TAIL, I, J + 1>(W, S, k, nT, q8, col);
   }
 }
-template <int PH, int I0, int I1>
+template <int PH, bool TAIL, int I0, int I1>
 __device__ __forceinline__ void wv_update_rows(const WvProb& W, WvState& S, int k, int nT, int q8, SFT_G double* col) {
   if constexpr (I0 <= I1) {
-    wv_update_tiles<PH, I0, 1>(W, S, k, nT, q8, col);
-    wv_update_rows<PH, I0 + 1, I1>(W, S, k, nT, q8, col);
+    wv_update_tiles<PH, TAIL, I0, 1>(W, S, k, nT, q8, col);
+    wv_update_rows<PH, TAIL, I0 + 1, I1>(W, S, k, nT, q8, col);
   }
 }
 // The LDS-resident tiles of a step as a list of tasks: T = 0..6 border tiles Bd(k+T+1)^T, T = 7, 8, 9 the d = 4 window tiles of rows 5, 6, 7
@@ -593,7 +594,7 @@ __device__ __forceinline__ v4d wv_step_diag(const WvProb& W, int k, int lane) {
 }
 
 // Part B (behind the tile Cholesky): TRSM of block column k, the row that enters the window, the trailing update.
-template <int PH>
+template <int PH, bool TAIL>
 __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& Wt, int k, lds_double* lds, int lane, const WvPrev& Q WV_T_ARG) {
   lds_double* ldsw = lds + WV_L_WIN;
   lds_double* ldsb = lds + WV_L_BORD;
@@ -621,14 +622,14 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
   // ---- trailing update: corner, rows 1..7, the LDS tiles of the first half; then (everything requested has landed) the deferred back
   // substitution's column, row 8 and the LDS tiles of the second half
   wv_upd_vgpr(S.corner, S.Y[0], S.Y[0]);
-  wv_update_rows<PH, 1, 7>(W, S, k, nT, W.q8, col);
+  wv_update_rows<PH, TAIL, 1, 7>(W, S, k, nT, W.q8, col);
   wv_lds_pipe<PH, 0, 9>(S, W.q8, lds, lane);
   WV_T(5);
   wv_wait_vm();
   WV_T(6);
   {   // second half: border tile Bd(k+8)^T and window tile (k+8, k+4) -- the latter straight from the registers it was fetched into
     v4d C10 = wv_task_load<PH, 10>(lds, lane);
-    wv_update_rows<PH, 8, 8>(W, S, k, nT, W.q8, col);
+    wv_update_rows<PH, TAIL, 8, 8>(W, S, k, nT, W.q8, col);
     wv_task_mfma<10>(C10, S, W.q8);
     wv_task_mfma<11>(fresh4, S, W.q8);
     wv_task_store<PH, 10>(lds, lane, C10);
@@ -791,15 +792,23 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
       for (int q = 0; q < 4; q++) Wt[q] = wscr[c * 17 + g + 4 * q];
     }
     WV_T(2);
-    switch (ph) {
-      case 0: wv_step_rest<0>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 1: wv_step_rest<1>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 2: wv_step_rest<2>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 3: wv_step_rest<3>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 4: wv_step_rest<4>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 5: wv_step_rest<5>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 6: wv_step_rest<6>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      default: wv_step_rest<7>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+    switch (ph + ((k + 8 >= W.nT) ? 8 : 0)) {
+      case 0: wv_step_rest<0, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 1: wv_step_rest<1, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 2: wv_step_rest<2, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 3: wv_step_rest<3, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 4: wv_step_rest<4, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 5: wv_step_rest<5, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 6: wv_step_rest<6, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 7: wv_step_rest<7, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 8: wv_step_rest<0, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 9: wv_step_rest<1, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 10: wv_step_rest<2, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 11: wv_step_rest<3, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 12: wv_step_rest<4, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 13: wv_step_rest<5, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 14: wv_step_rest<6, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      default: wv_step_rest<7, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
     }
   }
   WV_T_DUMP(P);
