@@ -192,18 +192,6 @@ __device__ __forceinline__ double wv_dpp_mov(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d): the v_rsq_f64 seed (2^-26) and ONE step that carries the second-order term, y (1 + e/2 + 3 e^2/8) with e = 1 - d y^2 exact through
-// the fused multiply-add: 5 instructions behind the seed where rsqrt_sqrt (tile_chol.h) issues 9 -- 64 fewer vector instructions per factor
-// step, each of which would occupy the FP64 pipe.  Accuracy: tools/probes/rsqrt_probe.hip (both within an ulp of the correctly rounded value).
-__device__ __forceinline__ double wv_rsqrt(double d) {
-  const double y = __builtin_amdgcn_rsq(d);
-  const double t = d * y;
-  const double e = fma(-t, y, 1.0);
-  const double p = fma(0.375, e, 0.5);
-  const double q = y * e;
-  return fma(q, p, y);
-}
-
 __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
@@ -212,33 +200,7 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
 #pragma unroll
   for (int J = 0; J < 4; J++) {
     const double aJ = a[J];
-    const int b0 = 4 * J;
-    const double d00 = bcast_lane(aJ, b0), d10 = bcast_lane(aJ, 16 + b0), d11 = bcast_lane(aJ, 16 + b0 + 1);
-    const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
-    const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
-    const double i0 = wv_rsqrt(d00);
-    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-    const double p1 = fma(-l10, l10, d11);
-    const double i1 = wv_rsqrt(p1);
-    const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
-    const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
-    const double i2 = wv_rsqrt(p2);
-    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
-    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-    const double i3 = wv_rsqrt(p3);
-    plast = p3;
-    // M = Ld^-1, lane (g, c) needs M[c][g] (c < 4): every lane solves Ld x = e_g -- its own column of the inverse -- by the same four
-    // steps of forward substitution (10 instructions) and keeps x_c; the explicit formulas of the six off-diagonal entries followed by a
-    // ten-way select (chol_inv_blocked in tile_chol.h) take 41 where this takes 22.
-    const double x0 = ((g == 0) ? 1.0 : 0.0) * i0;
-    const double x1 = fma(-l10, x0, (g == 1) ? 1.0 : 0.0) * i1;
-    const double x2 = fma(-l21, x1, fma(-l20, x0, (g == 2) ? 1.0 : 0.0)) * i2;
-    const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, (g == 3) ? 1.0 : 0.0))) * i3;
-    // (x3 is the last value of the chain: it enters the last select, the others are chosen while it is still being computed)
-    double sel = (c == 0) ? x0 : 0.0;
-    sel = (c == 1) ? x1 : sel;
-    sel = (c == 2) ? x2 : sel;
-    sel = (c == 3) ? x3 : sel;
+    const double sel = chol4_inverse_operand(aJ, J, g, c, plast);   // (tile_chol.h: the chain of dependent operations of a block step)
     const double wJ = w[J];
     v4d zw, z;
     if (J < 3) {

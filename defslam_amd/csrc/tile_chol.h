@@ -42,6 +42,54 @@ __device__ __forceinline__ void rsqrt_sqrt(double d, double& inv, double& s) {
   inv = fma(fma(-h, g, 0.5), h + h, h + h);   // one more correction of 1/sqrt without lengthening the sqrt chain
 }
 
+// 1/sqrt(d) alone: the v_rsq_f64 seed (2^-24) and ONE step that carries the second-order term, y (1 + e/2 + 3 e^2/8) with e = 1 - d y^2
+// exact through the fused multiply-add -- 5 dependent-ish instructions behind the seed, within 0.99 ulp of the correctly rounded value
+// (rsqrt_sqrt above: 9 instructions, 1.61 ulp; tools/probes/rsqrt_probe.hip).
+__device__ __forceinline__ double rsqrt_only(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double t = d * y;
+  const double e = fma(-t, y, 1.0);
+  const double p = fma(0.375, e, 0.5);
+  const double q = y * e;
+  return fma(q, p, y);
+}
+
+// Block step J of the 16 x 16 factorisation, the part every lane computes on broadcast scalars: Cholesky Ld Ld^T of the 4 x 4 diagonal block
+// of `aJ` (register J of the tile) and the A operand of the products with M = Ld^-1 -- lane (g, c) needs M[c][g] for c < 4.  This is a CHAIN of
+// dependent FP64 operations (four pivots: 1/sqrt, scale, update), the pipe mostly waits for its own results, so what counts is the length of
+// the critical path, not the instruction count:
+//   * every lane solves Ld x = e_g -- its own column of the inverse -- by four steps of forward substitution and keeps x_c (22 instructions;
+//     the explicit formulas of the six off-diagonal entries + a ten-way select took 41);
+//   * x3, the last value of the chain, enters the LAST select (r04: the tile Cholesky of the one-wavefront solver 3.09 k -> 2.32 k cycles).
+// `plast`: the last pivot -- a pivot that is not positive (or not a number) turns its 1/sqrt into NaN or infinity and from there every later
+// pivot of the tile into NaN (through l = d * inv and through the rank-4 update), so the LAST pivot tells whether all sixteen were positive.
+__device__ __forceinline__ double chol4_inverse_operand(double aJ, int J, int g, int c, double& plast) {
+  const int b0 = 4 * J;
+  const double d00 = bcast_lane(aJ, b0), d10 = bcast_lane(aJ, 16 + b0), d11 = bcast_lane(aJ, 16 + b0 + 1);
+  const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
+  const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
+  const double i0 = rsqrt_only(d00);
+  const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+  const double p1 = fma(-l10, l10, d11);
+  const double i1 = rsqrt_only(p1);
+  const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
+  const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
+  const double i2 = rsqrt_only(p2);
+  const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
+  const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+  const double i3 = rsqrt_only(p3);
+  plast = p3;
+  const double x0 = ((g == 0) ? 1.0 : 0.0) * i0;
+  const double x1 = fma(-l10, x0, (g == 1) ? 1.0 : 0.0) * i1;
+  const double x2 = fma(-l21, x1, fma(-l20, x0, (g == 2) ? 1.0 : 0.0)) * i2;
+  const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, (g == 3) ? 1.0 : 0.0))) * i3;
+  double sel = (c == 0) ? x0 : 0.0;
+  sel = (c == 1) ? x1 : sel;
+  sel = (c == 2) ? x2 : sel;
+  sel = (c == 3) ? x3 : sel;
+  return sel;
+}
+
 // Cholesky A = L L^T of a symmetric 16x16 tile and W = L^-1, blocked by 4 (13 MFMAs, 4 dependent block steps), one wavefront.
 // Block step J (rows/columns 4J..4J+3 live in register J of lane groups g = 0..3):
 //   1. the 10 entries of the symmetric 4x4 diagonal block are broadcast to every lane; every lane factors it and inverts
@@ -60,37 +108,7 @@ __device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
 #pragma unroll
   for (int J = 0; J < 4; J++) {
     const double aJ = a[J];
-    const int b0 = 4 * J;
-    const double d00 = bcast_lane(aJ, b0), d10 = bcast_lane(aJ, 16 + b0), d11 = bcast_lane(aJ, 16 + b0 + 1);
-    const double d20 = bcast_lane(aJ, 32 + b0), d21 = bcast_lane(aJ, 32 + b0 + 1), d22 = bcast_lane(aJ, 32 + b0 + 2);
-    const double d30 = bcast_lane(aJ, 48 + b0), d31 = bcast_lane(aJ, 48 + b0 + 1), d32 = bcast_lane(aJ, 48 + b0 + 2), d33 = bcast_lane(aJ, 48 + b0 + 3);
-    double i0, i1, i2, i3, sq;
-    rsqrt_sqrt(d00, i0, sq);
-    const double l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-    const double p1 = fma(-l10, l10, d11);
-    rsqrt_sqrt(p1, i1, sq);
-    const double l21 = fma(-l20, l10, d21) * i1, l31 = fma(-l30, l10, d31) * i1;
-    const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
-    rsqrt_sqrt(p2, i2, sq);
-    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * i2;
-    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
-    rsqrt_sqrt(p3, i3, sq);
-    // A pivot that is not positive (or not a number) turns its 1/sqrt into NaN or infinity, and from there every later pivot of the
-    // tile into NaN (through l = d * inv and through the rank-4 update): the LAST pivot tells whether all sixteen were positive.
-    plast = p3;
-    // M = Ld^-1 (lower triangular)
-    const double m10 = -(l10 * i0) * i1;
-    const double m21 = -(l21 * i1) * i2;
-    const double m32 = -(l32 * i2) * i3;
-    const double m20 = -fma(l21, m10, l20 * i0) * i2;
-    const double m31 = -fma(l32, m21, l31 * i1) * i3;
-    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * i0)) * i3;
-    // A operand of Z = Mpad * rows: lane (i = c, k = g) holds M[i][k] for i < 4, k <= i
-    double sel = 0.0;
-    sel = (c == 0 && g == 0) ? i0 : sel;
-    sel = (c == 1) ? (g == 0 ? m10 : (g == 1 ? i1 : 0.0)) : sel;
-    sel = (c == 2) ? (g == 0 ? m20 : (g == 1 ? m21 : (g == 2 ? i2 : 0.0))) : sel;
-    sel = (c == 3) ? (g == 0 ? m30 : (g == 1 ? m31 : (g == 2 ? m32 : i3))) : sel;
+    const double sel = chol4_inverse_operand(aJ, J, g, c, plast);
     const v4d zw = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, w[J], zero, 0, 0, 0);
     if (J < 3) {
       const v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, aJ, zero, 0, 0, 0);

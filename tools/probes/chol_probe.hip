@@ -3,13 +3,8 @@
 #include <cstdio>
 #include <cmath>
 #define TS 16
-typedef double v4d __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double bcast_lane(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void rsqrt_sqrt(double d, double& inv, double& s) {
+#include "../../defslam_amd/csrc/tile_chol.h"   // the product's chol_inv_blocked (r04: shortened chain); the copy below is the r03 code
+__device__ __forceinline__ void rsqrt_sqrt_first(double d, double& inv, double& s) {
   double y = __builtin_amdgcn_rsq(d);
   double g = d * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
@@ -32,7 +27,7 @@ __device__ __forceinline__ bool chol_inv_mfma(v4d& a, v4d& w) {
     const int gj = j & 3, qj = j >> 2;
     if (!(pd > 0.0)) bad = true;
     double inv, sq;
-    rsqrt_sqrt(pd, inv, sq);
+    rsqrt_sqrt_first(pd, inv, sq);
     const double m = (g == gj) ? inv : 0.0;
     const double la = a[qj] * m;
     if (j + 1 < TS) {
@@ -59,7 +54,7 @@ __device__ __forceinline__ void rsqrt_sqrt_k(double d, double& inv, double& s) {
   s = fma(res, h, g);
   inv = fma(fma(-h, g, 0.5), h + h, h + h);   // one more correction of 1/sqrt without lengthening the sqrt chain
 }
-__device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
+__device__ __forceinline__ bool chol_inv_blocked_r03(v4d& a, v4d& w) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
   w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
@@ -115,6 +110,7 @@ __device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
 }
 
 
+template <int NEW>
 __global__ void kb(const double* A, double* out, int n, long long* t, double* Wout) {
   const int l = threadIdx.x;
   v4d a0;
@@ -124,13 +120,13 @@ __global__ void kb(const double* A, double* out, int n, long long* t, double* Wo
   for (int i = 0; i < n; i++) {
     v4d a = a0;
     a[0] += 1e-9 * i;
-    chol_inv_blocked(a, w);
+    if (NEW) chol_inv_blocked(a, w); else chol_inv_blocked_r03(a, w);
     acc += w + a;
   }
   long long t1 = clock64();
   for (int q = 0; q < 4; q++) out[l * 4 + q] = acc[q];
-  { v4d a = a0; chol_inv_blocked(a, w); for (int q = 0; q < 4; q++) Wout[((l >> 4) + 4 * q) * 16 + (l & 15)] = w[q]; }
-  if (l == 0) t[3] = (t1 - t0) / n;
+  { v4d a = a0; if (NEW) chol_inv_blocked(a, w); else chol_inv_blocked_r03(a, w); for (int q = 0; q < 4; q++) Wout[((l >> 4) + 4 * q) * 16 + (l & 15)] = w[q]; }
+  if (l == 0) t[3 + NEW] = (t1 - t0) / n;
 }
 template <int VARIANT>
 __global__ void k(const double* A, double* out, int n, long long* t) {
@@ -152,22 +148,30 @@ __global__ void k(const double* A, double* out, int n, long long* t) {
 int main() {
   double hA[256];
   for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) hA[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + i + j);
-  double *dA, *out; long long* t; long long h[4]; double* dW; double hW[256];
+  double *dA, *out; long long* t; long long h[5]; double* dW; double hW[256];
   hipMalloc(&dA, 2048); hipMalloc(&out, 4096); hipMalloc(&t, 64); hipMalloc(&dW, 2048);
   hipMemcpy(dA, hA, 2048, hipMemcpyHostToDevice);
   k<0><<<1, 64>>>(dA, out, 2000, t); k<1><<<1, 64>>>(dA, out, 2000, t); k<2><<<1, 64>>>(dA, out, 2000, t);
-  kb<<<1, 64>>>(dA, out, 2000, t, dW);
+  auto check = [&]() {
+    hipMemcpy(hW, dW, 2048, hipMemcpyDeviceToHost);
+    double err = 0;
+    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
+      double s = 0;
+      for (int p = 0; p < 16; p++) for (int q = 0; q < 16; q++) s += hW[i * 16 + p] * hA[p * 16 + q] * hW[j * 16 + q];
+      const double e = s - (i == j ? 1.0 : 0.0);
+      if (e * e > err) err = e * e;
+    }
+    return sqrt(err);
+  };
+  kb<0><<<1, 64>>>(dA, out, 2000, t, dW);
   hipDeviceSynchronize();
-  hipMemcpy(h, t, 32, hipMemcpyDeviceToHost); hipMemcpy(hW, dW, 2048, hipMemcpyDeviceToHost);
+  const double e_old = check();
+  kb<1><<<1, 64>>>(dA, out, 2000, t, dW);
+  hipDeviceSynchronize();
+  const double e_new = check();
+  hipMemcpy(h, t, 40, hipMemcpyDeviceToHost);
   printf("chol+inv (2 MFMA/step): %lld cycles per tile; chol only (1 MFMA/step): %lld; no MFMA (chain only): %lld\n", h[0], h[1], h[2]);
-  // check W A W^T = I for the blocked variant
-  double err = 0;
-  for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
-    double s = 0;
-    for (int p = 0; p < 16; p++) for (int q = 0; q < 16; q++) s += hW[i * 16 + p] * hA[p * 16 + q] * hW[j * 16 + q];
-    const double e = s - (i == j ? 1.0 : 0.0);
-    if (e * e > err) err = e * e;
-  }
-  printf("blocked chol+inv: %lld cycles per tile, max |W A W^T - I| = %.3e\n", h[3], sqrt(err));
+  printf("blocked chol+inv, r03 code:            %lld cycles per tile, max |W A W^T - I| = %.3e\n", h[3], e_old);
+  printf("blocked chol+inv, product (tile_chol.h): %lld cycles per tile, max |W A W^T - I| = %.3e\n", h[4], e_new);
   return 0;
 }
