@@ -123,9 +123,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
   Ctl* ctl; double *red, *out, *panel;
   sftb_ctl_lds(smem, ctl, red, out, panel);
   const int tid = threadIdx.x;
-  if (st == SFTB_FINISH) {   // max_iters == 0: nothing but the classification of the initial state (the errors of a first evaluation)
-    (void)eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
-    __syncthreads();
+  if (st == SFTB_FINISH) {   // max_iters == 0: nothing but the classification of the initial state; no error was ever computed (chi2 = 0, like the oracle)
     classify<NT>(P, ctl, panel, 0, 0);
     if (tid == 0) { R.state = SFTB_DONE; atomicAdd(&counters[0], 1); }
     return;

@@ -2401,6 +2401,8 @@ __device__ __forceinline__ void init_state(const SftDev& P) {
   }
   for (size_t i = tid; i < (size_t)(SFT_BORDER + 1) * Dnp + SFT_H_PAD_BORDER; i += NT) P.Hbord[i] = 0.0;   // 8th row + padding stay zero
   for (int i = tid; i < Dnp + 6; i += NT) P.x[i] = 0.0;
+  // (max_iters = 0: no evaluation ever writes them, and the classification reads them -- like the oracle's edges that never computed an error)
+  for (int m = tid; m < P.M; m += NT) P.chi2_obs[m] = 0.0;
   if (tid == 0) {
     P.res->iters = 0; P.res->trials = 0; P.res->status = 0; P.res->inliers = 0;
     for (int i = 0; i < 96; i++) P.dbg[i] = 0.0;

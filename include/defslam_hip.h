@@ -82,7 +82,9 @@ typedef struct dsh_sft_frame {
   const double* xyz;           /* n*3 current node positions */
   double reg_lap, reg_inex, reg_temp;
   int32_t neighbour_layers;    /* >=1: viewed nodes + 1-ring (the reference quirk, DefOptimizer.cc:388-406); 0: viewed only */
-  int32_t max_iters;           /* 50 in the reference (DefOptimizer.cc:513) */
+  int32_t max_iters;           /* 50 in the reference (DefOptimizer.cc:513); 0 = no iteration (the reference never does this): no edge error is
+                                * ever computed, every observation counts as an inlier, repError is the mean reprojection error of the
+                                * initial state -- what the oracle's restatement of g2o's freshly allocated edges gives */
 } dsh_sft_frame;
 
 typedef struct dsh_sft_result {
