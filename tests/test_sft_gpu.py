@@ -204,6 +204,44 @@ def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mo
         assert len(relaxed) <= 12, relaxed
 
 
+def test_rounds_of_phase_kernels_with_failing_factorisations(gpu_ctx, oracle_mod):
+    """Problems whose normal equations are not positive definite (observations with NEGATIVE information: H = sum w J^T J is indefinite) among
+    healthy ones in one batch of the throughput shape: the one-wavefront Cholesky reports the non-positive pivot, the trial counts as failed
+    (g2o: `_solver->solve` returns false, the step is rejected, optimization_algorithm_levenberg.cpp:103-113), the state is restored, status
+    bit 0 is set -- and the neighbours of such a problem in the batch (same factor wave before and after it) are solved as if it were not there."""
+    from defslam_amd import sft, synth
+    B = 512
+    tmpl = synth.make_grid_template(10, 10)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = [synth.make_frame(tmpl, 300, p) for p in range(B)]
+    poisoned = (3, 77, 300, 511)
+    for p in poisoned:
+        syn[p].obs_invsig2 = -50.0 * np.abs(syn[p].obs_invsig2)
+    frames = [sft.frame_from_synth(fr) for fr in syn]
+    gpu_ctx.batch_upload(frames, *regs, 1, 50)
+    assert int(gpu_ctx.problem_info(0)[1][7]) == 1
+    gpu_ctx.batch_run()
+    inl = gpu_ctx.batch_download()
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    for p in list(poisoned) + [2, 4, 76, 78, 299, 301, 510, 0, 1]:
+        fr = syn[p]
+        r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+        f = frames[p]
+        if p in poisoned:
+            # An indefinite problem has no trajectory to compare: whether H + lambda I passes the Cholesky at a given damping hangs on the last
+            # bits of a pivot, and from the first such difference on the two runs are different problems.  What is defined: the first
+            # linearisation (chi2, the damping it starts from), that its first factorisation fails in both, that the failure is reported, and
+            # that the solve terminates with finite numbers.
+            assert f.status & 1, "a failed factorisation must be reported"
+            assert 1 <= f.iters <= 50 and f.trials >= f.iters
+            np.testing.assert_allclose(f.trace[0, [0, 1]], r.trace[0, [0, 1]], rtol=1e-8)
+            assert f.trace[0, 7] == 0 and r.trace[0, 7] == 0
+            assert np.isfinite(f.nodes_xyz).all() and np.isfinite(f.pose7).all()
+        else:
+            _compare(f, int(inl[p]), r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+
+
 @pytest.mark.parametrize("max_iters", [0, 1, 3])
 def test_rounds_of_phase_kernels_with_an_iteration_budget(gpu_ctx, oracle_mod, max_iters):
     """The throughput shape when the caller's iteration budget ends the solve: 0 (classification of the initial state only -- the batch never
