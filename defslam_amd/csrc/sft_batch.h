@@ -11,7 +11,10 @@
 // (optimization_algorithm_levenberg.cpp:61-164, sparse_optimizer.cpp:403-475, DefOptimizer.cc:513).
 #pragma once
 
-#define SFTB_NW 4   // wavefronts of a TRIAL workgroup
+// Wavefronts of a TRIAL workgroup -- the same as LIN's: the block-wide chi2 sums associate per thread and wavefront, and chi2 of the state LIN
+// linearised at and chi2 of a trial that did not move must be the SAME number (gain ratio exactly 0, the step rejected, as in the reference);
+// measured neutral against 4 (19.44 / 19.48 ms per step).
+#define SFTB_NW 8
 #ifndef SFTB_LIN_NW
 // Wavefronts of a LIN workgroup: 8 = one workgroup per CU with the CU's whole LDS, so every record class the assembly gathers (node matrices and
 // stretching records too: placement class 2, sft_kernels.hip AsmRec) is an LDS read.  Measured on 16384 C2 problems (tools/diag/assembly_shapes.py):
