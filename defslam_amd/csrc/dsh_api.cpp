@@ -631,8 +631,9 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     size_t used = 0;
     // placement class of the records (sft_kernels.hip: AsmRec): 1 = node positions + observation weights + curvature records, 2 = + node matrices + stretch records
     const size_t need1 = ((3 * (size_t)hh.n + 1) & ~(size_t)1) + (((size_t)hh.M + 1) & ~(size_t)1) + 4 * (size_t)hh.S, need2 = need1 + 6 * (size_t)hh.nA + 4 * (size_t)hh.Es;
-    hh.lds_class = (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
-    used += hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
+    const size_t need3 = need2 + 5 * (size_t)hh.M;   // + the camera records as five doubles (only the LIN kernel of the phase rounds has the code)
+    hh.lds_class = (c->rounds_mode && used + need3 <= lds_budget) ? 3 : (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
+    used += hh.lds_class == 3 ? need3 : hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
     jl_doubles = std::max(jl_doubles, used);
     max_kd = std::max(max_kd, hh.tile_mode == 2 ? std::max(hh.kd, kTS * kBT + 1) : hh.kd);   // (LDS of the wide-tile solver whenever a problem runs on it)
   }

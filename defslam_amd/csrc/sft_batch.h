@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64 * SFTB_LIN_NW, SFTB_LIN_WAVES) void sftb_lin_ker
     if (b < 0) break;
     SftRun& R = runs[b];
     const SftDev& P = probs[b];
-    const double chi0 = linearise<NW>(P, ctl, red, out, panel, [] {});
+    auto nothing = [] {};
+    const double chi0 = linearise<NW, decltype(nothing), true>(P, ctl, red, out, panel, nothing);
     double lambda = R.lambda;
     if (R.it == 0) {
       double mx = 0.0;

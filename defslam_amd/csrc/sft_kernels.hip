@@ -305,10 +305,12 @@ __device__ __forceinline__ void stretch_record(double d0, double d1, double d2, 
 //   0: everything in the workspace (global memory)
 //   1: node positions (every residual gathers three to seven of them), observation weights and curvature records in LDS
 //   2: also the node matrices and the stretching records
+//   3: also the camera records, as five doubles per observation (x/z, y/z, 1/z, e0, e1) from which cam_jac rebuilds the ten Jacobian entries --
+//      the 128-byte record in the workspace is the last thing the diagonal blocks gathered from memory (rounds of phase kernels: sft_batch.h)
 template <int CLS>
 struct AsmRec {
-  static constexpr bool XYZ_L = CLS >= 1, WT_L = CLS >= 1, STAR_L = CLS >= 1, A_L = CLS >= 2, STR_L = CLS >= 2;
-  lds_double *xyz_l, *wt_l, *A_l, *star_l, *str_l;
+  static constexpr bool XYZ_L = CLS >= 1, WT_L = CLS >= 1, STAR_L = CLS >= 1, A_L = CLS >= 2, STR_L = CLS >= 2, CAM_L = CLS >= 3;
+  lds_double *xyz_l, *wt_l, *A_l, *star_l, *str_l, *cam_l;
   gdouble *xyz_g, *wt_g, *A_g, *star_g, *str_g;
   __device__ __forceinline__ double xyz(size_t i) const { if constexpr (XYZ_L) return xyz_l[i]; else return xyz_g[i]; }
   __device__ __forceinline__ double wt(int m) const { if constexpr (WT_L) return wt_l[m]; else return wt_g[m]; }
@@ -347,8 +349,18 @@ __device__ __forceinline__ AsmRec<CLS> asm_records(const SftDev& P, double* lds)
   r.star_l = base + off; if (AsmRec<CLS>::STAR_L) off += 4 * (size_t)P.S;
   r.A_l = base + off; if (AsmRec<CLS>::A_L) off += 6 * (size_t)P.nA;
   r.str_l = base + off; if (AsmRec<CLS>::STR_L) off += 4 * (size_t)P.Es;
+  r.cam_l = base + off; if (AsmRec<CLS>::CAM_L) off += 5 * (size_t)P.M;
   r.xyz_g = P.xyz; r.wt_g = P.wtv; r.A_g = P.Anode; r.star_g = P.Jstar; r.str_g = P.Jstr;
   return r;
+}
+
+// The ten non-zero entries of the camera Jacobian of an observation (sft_types.h:162-174, columns [omega, upsilon]; row 0: columns 0, 1, 2,
+// 3, 5, row 1: columns 0, 1, 2, 4, 5) from xz = x/z, yz = y/z, iz = 1/z -- placement class 3 keeps these three per observation in LDS and both
+// the residual pass (camera corner) and the assembly (camera x node blocks) call this ONE function, so they work with the same bits.
+__device__ __forceinline__ void cam_jac(double xz, double yz, double iz, double fx, double fy, double* j0, double* j1) {
+  const double xy = xz * yz;
+  j0[0] = xy * fx; j0[1] = -(1.0 + xz * xz) * fx; j0[2] = yz * fx; j0[3] = -iz * fx; j0[4] = (xz * iz) * fx;
+  j1[0] = (1.0 + yz * yz) * fy; j1[1] = -xy * fy; j1[2] = -xz * fy; j1[3] = -iz * fy; j1[4] = (yz * iz) * fy;
 }
 
 // (force-inlined like assemble: inside the kernel `P` is a kernel-argument-derived reference whose fields are scalar loads; as a
@@ -410,12 +422,23 @@ __device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* 
         const double z2 = z * z, fx = P.fx, fy = P.fy;
         const double wt = rho1 * w;
         // row 0: columns 0, 1, 2, 3, 5 (column 4 is zero); row 1: columns 0, 1, 2, 4, 5 (column 3 is zero)
-        const double j0[6] = {x * y / z2 * fx, -(1 + (x * x / z2)) * fx, y / z * fx, -1. / z * fx, 0.0, x / z2 * fx};
-        const double j1[6] = {(1 + y * y / z2) * fy, -x * y / z2 * fy, -x / z * fy, 0.0, -1. / z * fy, y / z2 * fy};
-        // the record is one 128-byte line (SFT_CAM_STRIDE = 16): eight 16-byte stores here, one line per gather in the assembly
-        const auto rec = reinterpret_cast<SFT_G v2d*>(P.camrec + (size_t)m * SFT_CAM_STRIDE);
-        rec[0] = (v2d){wt, e0}; rec[1] = (v2d){e1, j0[0]}; rec[2] = (v2d){j0[1], j0[2]}; rec[3] = (v2d){j0[3], j0[5]};
-        rec[4] = (v2d){j1[0], j1[1]}; rec[5] = (v2d){j1[2], j1[4]}; rec[6] = (v2d){j1[5], c2}; rec[7] = (v2d){0.0, 0.0};
+        double j0[6], j1[6];
+        if constexpr (AsmRec<CLS>::CAM_L) {
+          const double iz = 1.0 / z, xz = x * iz, yz = y * iz;
+          double a0[5], a1[5];
+          cam_jac(xz, yz, iz, fx, fy, a0, a1);
+          j0[0] = a0[0]; j0[1] = a0[1]; j0[2] = a0[2]; j0[3] = a0[3]; j0[4] = 0.0; j0[5] = a0[4];
+          j1[0] = a1[0]; j1[1] = a1[1]; j1[2] = a1[2]; j1[3] = 0.0; j1[4] = a1[3]; j1[5] = a1[4];
+          lds_double* cr = ar.cam_l + 5 * (size_t)m;
+          cr[0] = xz; cr[1] = yz; cr[2] = iz; cr[3] = e0; cr[4] = e1;
+        } else {
+          j0[0] = x * y / z2 * fx; j0[1] = -(1 + (x * x / z2)) * fx; j0[2] = y / z * fx; j0[3] = -1. / z * fx; j0[4] = 0.0; j0[5] = x / z2 * fx;
+          j1[0] = (1 + y * y / z2) * fy; j1[1] = -x * y / z2 * fy; j1[2] = -x / z * fy; j1[3] = 0.0; j1[4] = -1. / z * fy; j1[5] = y / z2 * fy;
+          // the record is one 128-byte line (SFT_CAM_STRIDE = 16): eight 16-byte stores here, one line per gather in the assembly
+          const auto rec = reinterpret_cast<SFT_G v2d*>(P.camrec + (size_t)m * SFT_CAM_STRIDE);
+          rec[0] = (v2d){wt, e0}; rec[1] = (v2d){e1, j0[0]}; rec[2] = (v2d){j0[1], j0[2]}; rec[3] = (v2d){j0[3], j0[5]};
+          rec[4] = (v2d){j1[0], j1[1]}; rec[5] = (v2d){j1[2], j1[4]}; rec[6] = (v2d){j1[5], c2}; rec[7] = (v2d){0.0, 0.0};
+        }
         ar.set_wt(m, wt);
         if constexpr (WANT_J) {
           int q = 0;
@@ -537,10 +560,10 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
   // from the problem record (a scalar load + a wait that also drains the LDS counter) inside the loops.
   struct {
     int Dn, nA, M, tile_mode, tpr, kd, ldh;
-    double w_ref, w_curv, w_str;
+    double w_ref, w_curv, w_str, fx, fy;
     decltype(P_.camrec) camrec; decltype(P_.ob_ptr) ob_ptr, sh_ptr, ob_m, off_ptr, off_rc, tmask, actnode; decltype(P_.ob_c) ob_c, sh_cf, xyz0;
     decltype(P_.sh_rec) sh_rec; decltype(P_.viewed) viewed; decltype(P_.Hb) Hb, Hc, Hbord, Hcorner, xyz, dbg;
-  } P{P_.Dn, P_.nA, P_.M, P_.tile_mode, P_.tpr, P_.kd, P_.ldh, P_.w_ref, P_.w_curv, P_.w_str, P_.camrec, P_.ob_ptr, P_.sh_ptr, P_.ob_m, P_.off_ptr,
+  } P{P_.Dn, P_.nA, P_.M, P_.tile_mode, P_.tpr, P_.kd, P_.ldh, P_.w_ref, P_.w_curv, P_.w_str, P_.fx, P_.fy, P_.camrec, P_.ob_ptr, P_.sh_ptr, P_.ob_m, P_.off_ptr,
       P_.off_rc, P_.tmask, P_.actnode, P_.ob_c, P_.sh_cf, P_.xyz0, P_.sh_rec, P_.viewed, P_.Hb, P_.Hc, P_.Hbord, P_.Hcorner, P_.xyz, P_.dbg};
   const int Dnp = ((P.Dn + NB - 1) / NB) * NB;
   const int lane = threadIdx.x & 63;
@@ -681,6 +704,21 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
       }
       if (on) {
         const int ob0 = cur.dob0, ob1 = cur.dob1, sh0 = cur.dsh0, sh1 = cur.dsh1;
+        // camera record of observation m as [wt, e0, e1, j0 (5), j1 (5), -]: one 128-byte line of the workspace (seven 16-byte loads), or -- placement
+        // class 3 -- five doubles from LDS and the Jacobian rebuilt from them
+        auto cam_record = [&](int m, double (&rr)[14]) {
+          if constexpr (AsmRec<CLS>::CAM_L) {
+            const lds_double* cr = ar.cam_l + 5 * (size_t)m;
+            const double xz = cr[0], yz = cr[1], iz = cr[2];
+            rr[0] = ar.wt(m); rr[1] = cr[3]; rr[2] = cr[4];
+            cam_jac(xz, yz, iz, P.fx, P.fy, &rr[3], &rr[8]);
+            rr[13] = 0.0;
+          } else {
+            const auto rec = reinterpret_cast<const SFT_G v2d*>(P.camrec + (size_t)m * SFT_CAM_STRIDE);
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const v2d v = rec[k]; rr[2 * k] = v.x; rr[2 * k + 1] = v.y; }
+          }
+        };
         auto add_obs = [&](const double (&rr)[14], double b) {
           const double om = rr[0] * b;
           sii += om * b;
@@ -702,11 +740,7 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
         {
           double rr[DCH][14], r[HCH][4];
 #pragma unroll
-          for (int i = 0; i < DCH; i++) {   // the record is one 128-byte line: seven 16-byte loads
-            const auto rec = reinterpret_cast<const SFT_G v2d*>(P.camrec + (size_t)mm[i] * SFT_CAM_STRIDE);
-#pragma unroll
-            for (int k = 0; k < 7; k++) { const v2d v = rec[k]; rr[i][2 * k] = v.x; rr[i][2 * k + 1] = v.y; }
-          }
+          for (int i = 0; i < DCH; i++) cam_record(mm[i], rr[i]);
 #pragma unroll
           for (int i = 0; i < HCH; i++) ar.rec4((rc[i] >> 30) == SFT_KIND_STAR, rc[i] & 0x3FFFFFu, rc[i] != 0xFFFFFFFFu, r[i]);
 #pragma unroll
@@ -717,10 +751,8 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
             if (rc[i] != 0xFFFFFFFFu) add_sh(rc[i], c0[i], c1[i], r[i]);
         }
         for (int p = ob0 + sub + 8 * DCH; p < ob1; p += 8) {   // nodes seen by more than 16 observations
-          const auto rec = reinterpret_cast<const SFT_G v2d*>(P.camrec + (size_t)P.ob_m[p] * SFT_CAM_STRIDE);
           double rr[14];
-#pragma unroll
-          for (int k = 0; k < 7; k++) { const v2d v = rec[k]; rr[2 * k] = v.x; rr[2 * k + 1] = v.y; }
+          cam_record(P.ob_m[p], rr);
           add_obs(rr, P.ob_c[p]);
         }
         for (int p = sh0 + sub + 8 * HCH; p < sh1; p += 8) {   // more than 24 curvature / stretch contributions
@@ -2411,9 +2443,15 @@ __device__ __forceinline__ void init_state(const SftDev& P) {
 
 // One linearisation: residuals + assembly records, then the normal equations.  The records alias the solver workspace in LDS (dead
 // once H is assembled); their placement class is a template parameter (AsmRec).  (part, nparts): see assemble.
-template <int NW, class F>
+template <int NW, class F, bool WITH_CLASS3 = false>
 __device__ __forceinline__ double linearise(const SftDev& P, Ctl* ctl, double* red, double* out, double* panel, F ph_residuals, int part = 0, int nparts = 1) {
   double chi = 0.0;
+  if constexpr (WITH_CLASS3) {   // (only the LIN kernel of the phase rounds is compiled with it: the host sets class 3 for that launch shape alone)
+    if (P.lds_class == 3) {
+      const auto jp = asm_records<NW, 3>(P, panel); chi = eval_edges<true, 3>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 3>(P, red, out, jp, part, nparts);
+      return chi;
+    }
+  }
   switch (P.lds_class) {
     case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 2>(P, red, out, jp, part, nparts); break; }
     case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); ph_residuals(); assemble<NW, 1>(P, red, out, jp, part, nparts); break; }
@@ -3120,6 +3158,7 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_assembly_kernel
   __syncthreads();
   double chi = 0.0;
   switch (P.lds_class) {
+    case 3: { const auto jp = asm_records<NW, 3>(P, panel); chi = eval_edges<true, 3>(P, ctl, red, out, jp); assemble<NW, 3>(P, red, out, jp); break; }
     case 2: { const auto jp = asm_records<NW, 2>(P, panel); chi = eval_edges<true, 2>(P, ctl, red, out, jp); assemble<NW, 2>(P, red, out, jp); break; }
     case 1: { const auto jp = asm_records<NW, 1>(P, panel); chi = eval_edges<true, 1>(P, ctl, red, out, jp); assemble<NW, 1>(P, red, out, jp); break; }
     default: { const auto jp = asm_records<NW, 0>(P, panel); chi = eval_edges<true, 0>(P, ctl, red, out, jp); assemble<NW, 0>(P, red, out, jp); break; }

@@ -127,7 +127,7 @@ struct SftDev {
   int32_t tile_mode;          // 1: 16x16-tile band storage + register-window MFMA factorisation (kd <= 128); 2: wide tile band, left-looking
                               // MFMA factorisation (kd <= 256, sft_wide.h); 0: row-major band (general)
   int32_t pad1;
-  int32_t lds_class;          // assembly records kept in LDS instead of the workspace: 0 none, 1 observation weights + curvature records, 2 also node matrices + stretch records
+  int32_t lds_class;          // assembly records kept in LDS instead of the workspace: 0 none, 1 observation weights + curvature records, 2 also node matrices + stretch records, 3 also the camera records (phase rounds only)
   int32_t tpr, wbt;           // tile modes: pitch of a tile row of the band storage in tiles (wbt + 1), sub-diagonal tiles per block
                               // column (mode 1: 8; mode 2: ceil(kd/16); an even pitch, i.e. an odd tile distance between (I,K) and
                               // (I,K+1), was tried against L2 channel aliasing: no effect)
