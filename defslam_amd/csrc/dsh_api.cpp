@@ -25,7 +25,7 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
@@ -120,6 +120,7 @@ struct dsh_ctx : dsh_ctx_base {
   std::vector<ResOffs> res_offs;
   int max_kd = 0;
   size_t jl_doubles = 0;
+  size_t xyz_doubles = 0;   // LDS copy of the node positions in the TRIAL kernel of the phase rounds (largest problem of the batch)
   int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
   size_t lds_configured[2] = {0, 0};   // dynamic LDS size the two launch shapes were last enabled for on THIS device
   size_t lds_configured_sc = 0;        // the same for the phase kernel of the shared-camera mode
@@ -309,7 +310,7 @@ int run_rounds(dsh_ctx* c) {
   auto launch = [&](int s, int phase) {
     const bool ev = c->phase_events && S == 1;
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
-    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->lds_configured_b,
+    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->xyz_doubles, c->lds_configured_b,
                                      c->num_cus, c->sub_stream[s]);
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
     return r;
@@ -590,7 +591,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   }
   // LDS of the assembly (it aliases the solver workspace): the records a gather touches most often, as far as the budget goes
   // (4 wavefronts: two problems share a CU's 160 KB)
-  size_t jl_doubles = 0;
+  size_t jl_doubles = 0, xyz_doubles = 0;
   int max_kd = 0;
   // (rounds of phase kernels: the LIN kernel is the only one that stages records, eight wavefronts and one workgroup per CU -- sft_batch.h)
   const size_t lds_budget = ((((nw == 4 && !c->rounds_mode) || SFT_WAVES_PER_EU >= 4) ? 75 : 155) * 1024) / 8;   // doubles, next to ~4.3 KB of control block and reduction scratch
@@ -635,6 +636,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     hh.lds_class = (c->rounds_mode && used + need3 <= lds_budget) ? 3 : (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
     used += hh.lds_class == 3 ? need3 : hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
     jl_doubles = std::max(jl_doubles, used);
+    xyz_doubles = std::max(xyz_doubles, ((3 * (size_t)hh.n + 1) & ~(size_t)1));
     max_kd = std::max(max_kd, hh.tile_mode == 2 ? std::max(hh.kd, kTS * kBT + 1) : hh.kd);   // (LDS of the wide-tile solver whenever a problem runs on it)
   }
   if (c->host_only) {  // packed on the host only; dsh_sft_batch_problem_info works, running does not
@@ -808,6 +810,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->B = B;
   c->max_kd = max_kd;
   c->jl_doubles = jl_doubles;
+  c->xyz_doubles = xyz_doubles;
   c->nw = nw;
   return DSH_OK;   // asynchronous: the launch of dsh_sft_batch_run is ordered behind the copy on the same stream
 }

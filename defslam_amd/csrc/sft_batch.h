@@ -153,7 +153,10 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
   block_sum<1>(&sc, red, out);
   const double scale = out[0];
   __syncthreads();
-  const double chi_new = eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+  // (the positions every residual gathers three to seven of: staged in LDS where the problem's placement class says they fit -- the launch
+  // sizes the LDS for them; only the position array of class 1 is touched by a pass without Jacobians)
+  const double chi_new = P.lds_class >= 1 ? eval_edges<false, 1>(P, ctl, red, out, asm_records<NW, 1>(P, panel))
+                                          : eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
   if (tid == 0) {
     const double tempChi = ok ? chi_new : DBL_MAX;
     double rho = (R.chi_cur - tempChi);

@@ -3323,7 +3323,7 @@ extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int whic
 
 // Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the calling context): the dynamic LDS sizes the
 // LIN and TRIAL kernels were last enabled for on that device.
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream) {
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream) {
   const size_t head = 512 + (16 * 27 + 5 + 32) * sizeof(double) + 64;
   if (phase == SFTB_PH_INIT) {
     hipError_t e = hipMemsetAsync(d_counters, 0, 16 * sizeof(int), stream);
@@ -3341,7 +3341,7 @@ extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_
   } else if (phase == SFTB_PH_FACTOR) {
     hipLaunchKernelGGL(sftb_factor_kernel, dim3(std::min(B, 4 * num_cus)), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs, d_runs, d_counters, B);   // one wave per SIMD
   } else {
-    const size_t lds = head + 2048 * sizeof(double);   // classify: the error norms of 2048 observations per pass
+    const size_t lds = head + std::max<size_t>(2048, xyz_doubles) * sizeof(double);   // classify: the error norms of 2048 observations per pass; the trial's residual pass: the node positions
     if (lds > configured[1]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sftb_trial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
