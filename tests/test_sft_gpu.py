@@ -204,6 +204,29 @@ def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mo
         assert len(relaxed) <= 12, relaxed
 
 
+def test_rounds_of_phase_kernels_when_the_camera_records_do_not_fit_lds(gpu_ctx, oracle_mod):
+    """The benched template with four times the observations (4000 matches): the camera records of placement class 3 (five doubles per
+    observation) no longer fit the LDS budget of the LIN kernel next to the other record classes, the upload falls back to class 2 (128-byte
+    records in the workspace) -- same throughput shape, same results."""
+    from defslam_amd import sft, synth
+    B = 512
+    rows, cols, _ = synth.CONFIGS["C2"]
+    tmpl = synth.make_grid_template(rows, cols)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = [synth.make_frame(tmpl, 4000, p) for p in range(B)]
+    frames = [sft.frame_from_synth(fr) for fr in syn]
+    gpu_ctx.batch_upload(frames, *regs, 1, 50)
+    assert int(gpu_ctx.problem_info(0)[1][7]) == 1
+    gpu_ctx.batch_run()
+    inl = gpu_ctx.batch_download()
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    for p in (0, 255, 511):
+        fr = syn[p]
+        r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+        _compare(frames[p], int(inl[p]), r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+
+
 def test_rounds_of_phase_kernels_with_failing_factorisations(gpu_ctx, oracle_mod):
     """Problems whose normal equations are not positive definite (observations with NEGATIVE information: H = sum w J^T J is indefinite) among
     healthy ones in one batch of the throughput shape: the one-wavefront Cholesky reports the non-positive pivot, the trial counts as failed
