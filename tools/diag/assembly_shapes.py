@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from defslam_amd import sft, synth
 B = 16384; reps = 5
 rows, cols, m = synth.CONFIGS["C2"]

@@ -2,7 +2,8 @@
 a speculative FACTOR (K dampings of a rejection run side by side once K * active <= waves) would save.  GPU: python tools/diag/rounds_histogram.py [B]"""
 import sys
 import numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from defslam_amd import sft, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 rows, cols, m = synth.CONFIGS["C2"]

@@ -1,5 +1,7 @@
 import sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import oracle; oracle.build()
 from defslam_amd import sft, synth
 B = 512; rows, cols, m = 3, 3, 60
