@@ -137,13 +137,18 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
   const int ok = R.fact_ok;
   const double lam = R.lambda;
-  // push + update (sparse_optimizer.cpp:477-491); like g2o, x keeps its previous content when the factorisation failed
-  for (int i = tid; i < 3 * P.n; i += NT) {
-    const double v = P.xyz[i];
-    P.xyz_bak[i] = v;
-    const int a = P.act[i / 3];
-    if (a >= 0) P.xyz[i] = v + P.x[3 * a + (i % 3)];
-  }
+  // push + update (sparse_optimizer.cpp:477-491); like g2o, x keeps its previous content when the factorisation failed.  Where the node
+  // positions are staged in LDS for the residual pass (placement class >= 1) the trial state of the nodes exists THERE only: the staging adds
+  // the step, an accepted trial writes the LDS copy back, a rejected one leaves memory as it was -- no backup, no restore (3 x 12 KB of
+  // traffic per trial at C2); same additions, same bits.
+  const bool in_lds = P.lds_class >= 1;
+  if (!in_lds)
+    for (int i = tid; i < 3 * P.n; i += NT) {
+      const double v = P.xyz[i];
+      P.xyz_bak[i] = v;
+      const int a = P.act[i / 3];
+      if (a >= 0) P.xyz[i] = v + P.x[3 * a + (i % 3)];
+    }
   if (tid < 7) R.pose_bak[tid] = P.pose[tid];
   __syncthreads();
   if (tid == 0) pose_oplus(P.pose, P.x + Dnp);
@@ -156,8 +161,9 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
   __syncthreads();
   // (the positions every residual gathers three to seven of: staged in LDS where the problem's placement class says they fit -- the launch
   // sizes the LDS for them; only the position array of class 1 is touched by a pass without Jacobians)
-  const double chi_new = P.lds_class >= 1 ? eval_edges<false, 1>(P, ctl, red, out, asm_records<NW, 1>(P, panel))
-                                          : eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
+  const auto staged = asm_records<NW, 1>(P, panel);
+  const double chi_new = in_lds ? eval_edges<false, 1>(P, ctl, red, out, staged, P.x)
+                                : eval_edges<false, 0>(P, ctl, red, out, asm_records<NW, 0>(P, panel));
   if (tid == 0) {
     const double tempChi = ok ? chi_new : DBL_MAX;
     double rho = (R.chi_cur - tempChi);
@@ -180,8 +186,11 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
   }
   __syncthreads();
   if (ctl->stop) {  // pop
-    for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
+    if (!in_lds)
+      for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = P.xyz_bak[i];
     if (tid < 7) P.pose[tid] = R.pose_bak[tid];
+  } else if (in_lds) {   // accepted: the trial state becomes the state
+    for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = staged.xyz_l[i];
   }
   const bool again = (ctl->rho < 0) && (ctl->qmax < 10);
   if (again) return;   // the next round factors the same H with the new damping

@@ -366,14 +366,22 @@ __device__ __forceinline__ void cam_jac(double xz, double yz, double iz, double 
 // (force-inlined like assemble: inside the kernel `P` is a kernel-argument-derived reference whose fields are scalar loads; as a
 // separate function it would arrive as a generic pointer in vector registers and every P.field would be a flat vector load)
 template <bool WANT_J, int CLS>
-__device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, const AsmRec<CLS>& ar) {
+__device__ __forceinline__ double eval_edges(const SftDev& P, Ctl* ctl, double* red, double* out, const AsmRec<CLS>& ar, const SFT_G double* step = nullptr) {
   if (threadIdx.x == 0) {
     quat_to_R(P.pose + 3, ctl->R);
     ctl->t[0] = P.pose[0]; ctl->t[1] = P.pose[1]; ctl->t[2] = P.pose[2];
   }
   if constexpr (AsmRec<CLS>::XYZ_L) {   // the node positions once, coalesced; every gather below is an LDS read
     const auto src = P.xyz;
-    for (int i = threadIdx.x; i < 3 * P.n; i += blockDim.x) ar.xyz_l[i] = src[i];
+    if (step) {   // a damping trial of the phase rounds: the trial state xyz + x exists in LDS only (sftb_trial_kernel writes it back if accepted)
+      for (int i = threadIdx.x; i < 3 * P.n; i += blockDim.x) {
+        const double v = src[i];
+        const int a = P.act[i / 3];
+        ar.xyz_l[i] = a >= 0 ? v + step[3 * a + (i % 3)] : v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < 3 * P.n; i += blockDim.x) ar.xyz_l[i] = src[i];
+    }
   }
   __syncthreads();
   double R[9], t[3];
