@@ -14,7 +14,7 @@
 // Wavefronts of a TRIAL workgroup -- the same as LIN's: the block-wide chi2 sums associate per thread and wavefront, and chi2 of the state LIN
 // linearised at and chi2 of a trial that did not move must be the SAME number (gain ratio exactly 0, the step rejected, as in the reference);
 // costs 2.4 ms per step of 16384 problems against 4 (21.7 / 19.3 ms, A/B interleaved on one box) -- paid for the property above, and
-// won back by the LDS copy of the node positions in the trial's residual pass (19.5 ms).
+// won back by the LDS copy of the node positions in the trial's residual pass (19.5 ms; 17.2 with the trial state in LDS only).
 #define SFTB_NW 8
 #ifndef SFTB_LIN_NW
 // Wavefronts of a LIN workgroup: 8 = one workgroup per CU with the CU's whole LDS, so every record class the assembly gathers (node matrices and
