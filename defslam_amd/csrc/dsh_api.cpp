@@ -26,7 +26,7 @@
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream);
-extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
 extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
@@ -127,6 +127,9 @@ struct dsh_ctx : dsh_ctx_base {
   size_t lds_configured_spec = 0;      // and for the speculative-trial kernel
   // latency mode: K workgroups per problem run the next K damping trials of an iteration side by side (sft_kernels.hip: sft_spec_kernel)
   int spec_k = 1;
+  int spec_nh = 0;                     // helper workgroups per part of a two-sided factorisation (FACTOR launches of the latency mode, sft_wide.h)
+  char* d_sync = nullptr;              // their progress words and column flags (inside the batch arena), cleared at the start of every run
+  size_t sync_bytes = 0;
   int spec_hint = 12;                  // launches the previous speculative run needed (first group of the next one)
   int max_iters_batch = 0;
   SftSpec* d_spec = nullptr;           // K*B controller states, inside d_batch
@@ -154,7 +157,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -357,7 +360,8 @@ int run_once(dsh_ctx* c) {
   // launch.  First group: as many rounds as the previous run of this context needed (tracking is coherent from frame to frame:
   // usually exact), then the done flags are read back and rounds of two are added while a problem still runs.  Launches behind the
   // end of a problem cost a few microseconds each (it leaves at the first instruction); a read-back costs a stream synchronisation.
-  auto launch = [&](int phase) { return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream); };
+  auto launch = [&](int phase) { return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->spec_nh, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream); };
+  if (c->spec_nh > 0) HIPCHK(c, hipMemsetAsync(c->d_sync, 0, c->sync_bytes, c->stream));   // progress words and column flags of the helper workgroups: epochs count from here
   HIPCHK(c, launch(SFT_SPEC_INIT));
   int rounds = 0, group = std::max(2, std::min(worst, c->spec_hint));
   HIPCHK(c, c->spec_done.ensure(sizeof(SftSpec) * (size_t)B, true));
@@ -672,12 +676,34 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     r.mp = a.take(4 * 3 * (size_t)h.M) - c->res_off; r.outl = a.take((size_t)h.M) - c->res_off;
   }
   c->res_bytes = a.size - c->res_off;
-  struct POffs { size_t Hb, Lb, Lt, LbT, Lbord, Linv, x, xchg; };
+  struct POffs { size_t Hb, Lb, Lt, LbT, Lbord, Linv, x, xchg, Pf, PfB, sync; };
   struct WOffs { size_t bak, camrec, wtv, Anode, Jstar, Jstr, Hc, Hb, Hbord, Hcn, Lb, Lbord, Lc, Linv, Lt, LbT, x, dbg, sx0, sx1, shadow_xyz, shadow_chi2, shadow_hdr; POffs part[4]; };
   std::vector<WOffs> wo((size_t)B * K);
   const size_t ws_off = a.size;
   const size_t o_spec = a.take(sizeof(SftSpec) * (size_t)B * K);
   const size_t o_runs = a.take(c->rounds_mode ? sizeof(SftRun) * (size_t)B + 64 * dsh_ctx::kMaxSub + sizeof(int) * (size_t)B : 0);
+  // Helper workgroups of the two-sided factorisation: while CUs idle anyway, every part gets nh more of them for the far products of its block
+  // columns (sft_wide.h).  Everything has to be resident at once for that to pay, so nh is what the device holds: B * K * 2 * (1 + nh) <= CUs.
+  int nh = 0;
+  {
+    // (only where the far products are most of a block column: bands of at least 12 tiles; a narrow band through this path gains nothing --
+    // C2, 8 tiles: 4.4 against 4.0 ms per frame with helpers)
+    bool any = false;
+    for (int b = 0; b < B; b++) any = any || (c->packed[b].h.split != 0 && c->packed[b].h.wbt >= 12);
+    if (any && K > 1 && !c->force_split) {
+      while (nh < 3 && (long long)B * K * 2 * (2 + nh) <= c->num_cus) nh++;
+      if (c->opt.helpers >= 0) nh = c->opt.helpers;   // lab builds only
+    }
+  }
+  // (one block: a run clears it with one memset)
+  size_t sync_total = 0;
+  if (nh > 0)
+    for (int e = 0; e < B * K; e++) {
+      const SftDev& h = c->packed[e % B].h;
+      if (h.split) for (int g = 0; g < 2; g++) sync_total += ((size_t)4 * (16 + h.part[g].nT) + 255) & ~(size_t)255;
+    }
+  const size_t o_sync = a.take(sync_total);
+  size_t sync_used = 0;
   for (int e = 0; e < B * K; e++) {
     const int b = e % B, lane = e / B;
     const SftDev& h = c->packed[b].h;
@@ -708,6 +734,10 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
         po.Hb = a.take(g < 2 && lane == 0 ? tiles : 0);
         po.Lb = a.take(tiles); po.Lt = a.take(tiles); po.LbT = a.take(col); po.Linv = a.take(col);
         po.Lbord = a.take(8 * 8 * (size_t)kTS * q.nT); po.x = a.take(8 * ((size_t)kTS * q.nT + 8)); po.xchg = a.take(8 * (size_t)h.sp_xl);
+        const bool helped = nh > 0 && g < 2;
+        po.Pf = a.take(helped ? tiles : 0); po.PfB = a.take(helped ? col : 0);
+        po.sync = o_sync + sync_used;
+        if (helped) sync_used += ((size_t)4 * (16 + q.nT) + 255) & ~(size_t)255;
       }
   }
   if (sft_lm_kernel_lds_bytes(max_kd, jl_doubles) > 160 * 1024 || max_kd + kNB + SFT_BORDER > SFT_NT)
@@ -775,6 +805,9 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
         q.Hb = g < 2 ? (double*)(base + (lane ? wo[b].part[g].Hb : po.Hb)) : (double*)(base + po.xchg);   // reduced problem: H = the summed exchange buffer
         q.Lb = (double*)(base + po.Lb); q.Lt = (double*)(base + po.Lt); q.LbT = (double*)(base + po.LbT); q.Linv = (double*)(base + po.Linv);
         q.Lbord = (double*)(base + po.Lbord); q.x = (double*)(base + po.x); q.xchg = (double*)(base + po.xchg);
+        const bool helped = nh > 0 && g < 2;
+        q.Pf = helped ? (double*)(base + po.Pf) : nullptr; q.PfB = helped ? (double*)(base + po.PfB) : nullptr;
+        q.sync = helped ? (int32_t*)(base + po.sync) : nullptr;
       }
     if (lane) {
       h.xyz = (double*)(base + w.shadow_xyz); h.chi2_obs = (double*)(base + w.shadow_chi2);
@@ -804,6 +837,9 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->d_linlist = c->d_counters + 16 * dsh_ctx::kMaxSub;
   c->spec_bytes = sizeof(SftSpec) * (size_t)B * K;
   c->spec_k = K;
+  c->spec_nh = nh;
+  c->d_sync = base + o_sync;
+  c->sync_bytes = sync_total;
   c->any_split = false;
   for (int b = 0; b < B; b++) c->any_split = c->any_split || c->packed[b].h.split != 0;
   c->max_iters_batch = max_iters;
@@ -1264,6 +1300,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "rounds") c->opt.rounds = value != 0;
   else if (k == "streams") { if (value < 0 || value > dsh_ctx::kMaxSub) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: streams is 0 (automatic) or 1..4 sub-batches"); c->opt.streams = value; }
   else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
+  else if (k == "helpers") { if (value < -1 || value > 3) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers is -1 (automatic) or 0..3 workgroups per part"); c->opt.helpers = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;
@@ -1374,7 +1411,9 @@ int dsh_lab_sft_dump(dsh_ctx* c, int b, int what, int64_t n, double* out) {
   if (!c || !out || b < 0 || b >= c->B || n <= 0) return fail(c, DSH_ERR_ARG, "dsh_lab_sft_dump: bad argument");
   if (c->host_only) return fail(c, DSH_ERR_NO_DEVICE, "dsh_lab_sft_dump: host-only context");
   const SftDev& h = c->h_probs[b];
-  const double* src = what == 0 ? h.Lb : what == 1 ? h.Linv : what == 2 ? h.Lbord : what == 3 ? h.Hc : what == 4 ? h.Hbord : what == 5 ? h.x : what == 6 ? h.Hcorner : h.dbg;
+  const double* src = what == 0 ? h.Lb : what == 1 ? h.Linv : what == 2 ? h.Lbord : what == 3 ? h.Hc : what == 4 ? h.Hbord : what == 5 ? h.x : what == 6 ? h.Hcorner :
+                      (what == 8 || what == 9) ? (const double*)h.part[what - 8].sync : h.dbg;   // 8, 9: the helper statistics of part 0 / 1 (int32 words)
+  if (!src) return fail(c, DSH_ERR_STATE, "dsh_lab_sft_dump: the problem has no such buffer");
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out, src, 8 * (size_t)n, hipMemcpyDeviceToHost));

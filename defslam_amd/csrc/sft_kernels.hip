@@ -2632,13 +2632,17 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_lm_kernel(const
 // (no device-scope fences, no flags); results, state and decisions are bit-identical to sft_lm_kernel.
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K, int phase) {
+__global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K, int phase, int nh) {
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // SFT_SPEC_FACTOR / SFT_SPEC_SOLVE run two workgroups per (problem, lane): one per part of the two-sided factorisation
-  const int wgs = (phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) ? 2 : 1, fpart = blockIdx.x % wgs;
-  const int bx = blockIdx.x / wgs;
-  const int B = gridDim.x / (K * wgs), b = bx / K, j = bx % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
+  // SFT_SPEC_FACTOR / SFT_SPEC_SOLVE run two workgroups per (problem, lane): one per part of the two-sided factorisation; a FACTOR launch
+  // carries nh helper workgroups per part behind them (role 1 .. nh, role-major: an owner and its helpers are a multiple of 8 workgroups
+  // apart -- the same XCD under the round-robin dispatch, though nothing depends on it)
+  const int roles = phase == SFT_SPEC_FACTOR ? 1 + nh : 1, per_role = gridDim.x / roles;
+  const int role = blockIdx.x / per_role, bid = blockIdx.x % per_role;
+  const int wgs = (phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) ? 2 : 1, fpart = bid % wgs;
+  const int bx = bid / wgs;
+  const int B = per_role / (K * wgs), b = bx / K, j = bx % K;   // tables are lane-major: entry (lane j, problem b) at j * B + b
   const SftDev& P = probs[(size_t)j * B + b];
   SftSpec& S = specs[(size_t)j * B + b];
   auto peer = [&](int jj) -> const SftSpec& { return specs[(size_t)jj * B + b]; };
@@ -2753,6 +2757,12 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     // only READ here (the trial launch behind this one updates it): on a fresh linearisation of the first iteration the initial damping is
     // recomputed from H -- the same number the trial launch stores.
     if (!(P.tile_mode == 2 && P.split) || S.need_lin == 1) return;
+    if (S.qbase + j >= 10) return;
+    const int epoch = S.launches + 1;     // what the cross-workgroup flags of this launch hold (the sync words are cleared once per run)
+    if (role > 0) {   // a helper of the part: the far products of its block columns (sft_wide.h)
+      factor_wide_helper(P, fpart, role - 1, nh, epoch, ctl, panel);
+      return;
+    }
     double lam = S.lambda, ni = S.ni;
     if (S.need_lin == 2 && S.it == 0) {
       double mx = 0.0;
@@ -2762,11 +2772,12 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
       lam = 1e-5 * mx; ni = 2.0;
     }
     for (int t = 0; t < j; t++) { lam *= ni; ni *= 2.0; }
-    if (S.qbase + j >= 10) return;
     if (tid == 0) ctl->lambda = lam;
     __syncthreads();
     if (phase == SFT_SPEC_FACTOR) {
-      factor_wide(P, fpart, ctl, panel);
+      // with helpers (and for any band that fits the near window whole): the owner that works from registers and LDS
+      if (nh > 0 || P.part[fpart].wbt <= SFT_WIDE_NEAR) factor_part<SFT_WIDE_NEAR>(P, fpart, ctl, panel, epoch, nh);
+      else factor_wide(P, fpart, ctl, panel);
       return;
     }
     // ---- SFT_SPEC_SOLVE: the Schur contributions of the two parts are summed into the reduced (separator + camera) problem (which adds the
@@ -3221,7 +3232,7 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   if (backsub > panel) panel = backsub;
   const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 48 + 128 + 128;  // dataflow layout (the larger one) + step-trace stamps
   if (kd <= TS * BT) panel = tiles;
-  else if (kd <= TS * WB) panel = std::max(panel, (size_t)2 * WB * TS * TS + TILE_LDS + 640);   // wide mode: two staged tile rows, W, corners (or the band panel)
+  else if (kd <= TS * WB) panel = std::max(panel, std::max((size_t)2 * WB * TS * TS + TILE_LDS + 704, (size_t)(SFT_WIDE_NEAR + 2) * SFT_WIDE_NEAR * TS * TS + 2 * TILE_LDS + 704 + (size_t)32 * TS * TS + (size_t)(WB - SFT_WIDE_NEAR) * TS * TS));   // wide mode: two staged tile rows, W, corners (or the band panel)
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }
@@ -3273,14 +3284,15 @@ extern "C" hipError_t sft_vec_sum2(const double* a, const double* b, double* out
   return hipGetLastError();
 }
 
-extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
   const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
   if (lds > *configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_spec_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     *configured = lds;
   }
-  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K * ((phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) ? 2 : 1)), dim3(512), lds, stream, d_probs, d_spec, K, phase);
+  const int wgs = (phase == SFT_SPEC_FACTOR || phase == SFT_SPEC_SOLVE) ? 2 : 1, roles = phase == SFT_SPEC_FACTOR ? 1 + nh : 1;
+  hipLaunchKernelGGL(sft_spec_kernel<8>, dim3(B * K * wgs * roles), dim3(512), lds, stream, d_probs, d_spec, K, phase, nh);
   return hipGetLastError();
 }
 

@@ -119,6 +119,9 @@ struct SftPart {
   SFT_G double *Lb, *Lt, *LbT, *Lbord, *Linv, *x;
   SFT_G double* xchg;                  // parts 0/1: the part's Schur contribution in the layout of the reduced problem's input
                                        //   [H tiles sT*tpr_r*256 | border 8 x 16 sT | corner 56 | failed flag 8]; part[2]: the sum (its Hb points into it)
+  // parts 0/1, latency mode with helper workgroups (sft_wide.h: factor_wide_helper): the far sums of a block column formed on another CU
+  SFT_G double *Pf, *PfB;              // Pf: tile (J, d) = far(J + d, J), layout of Lt; PfB: tile J = the border's far sum
+  SFT_G int32_t* sync;                 // [0] the owner's progress (epoch << 16 | finished block columns), [16 + J] == epoch: column J's far sums are stored
 };
 
 struct SftDev {

@@ -45,6 +45,8 @@ struct WideView {
   bool reversed, corner_from_H, finish;
   const SFT_G double *Hb, *Hbord, *Hcorner;
   SFT_G double *Lb, *Lt, *LbT, *Lbord, *Linv, *x, *xchg;
+  SFT_G double *Pf, *PfB;            // parts: the far sums of a block column formed by helper workgroups (factor_wide_helper)
+  SFT_G int32_t* sync;               // parts: [0] the owner's progress word, [WIDE_SYNC_READY + J] column J's far sums are in Pf / PfB
 };
 __device__ __forceinline__ WideView wide_view(const SftDev& P, int which) {
   WideView v;
@@ -56,11 +58,13 @@ __device__ __forceinline__ WideView wide_view(const SftDev& P, int which) {
     v.xr_tpr = 0; v.xr_nT = 0; v.reversed = false; v.corner_from_H = true; v.finish = true;
     v.Hb = uni(P.Hb); v.Hbord = uni(P.Hbord); v.Hcorner = uni(P.Hcorner);
     v.Lb = uni(P.Lb); v.Lt = uni(P.Lt); v.LbT = uni(P.LbT); v.Lbord = uni(P.Lbord); v.Linv = uni(P.Linv); v.x = uni(P.x); v.xchg = nullptr;
+    v.Pf = nullptr; v.PfB = nullptr; v.sync = nullptr;
     return v;
   }
   const auto& q = P.part[which];
   v.nT = uni(q.nT); v.nS = uni(q.nS); v.tpr = uni(q.tpr); v.wb = uni(q.wbt);
   v.Hb = uni(q.Hb); v.Lb = uni(q.Lb); v.Lt = uni(q.Lt); v.LbT = uni(q.LbT); v.Lbord = uni(q.Lbord); v.Linv = uni(q.Linv); v.x = uni(q.x); v.xchg = uni(q.xchg);
+  v.Pf = uni(q.Pf); v.PfB = uni(q.PfB); v.sync = uni(q.sync);
   v.xr_tpr = uni(P.part[2].tpr); v.xr_nT = uni(P.part[2].nT);
   if (which >= 2) {   // the reduced problem (2, or its second copy 3): its input is the summed exchange buffer
     v.lam_lo = 0; v.lam_hi = uni(P.sp_s);
@@ -77,7 +81,154 @@ __device__ __forceinline__ WideView wide_view(const SftDev& P, int which) {
   return v;
 }
 
-// lam_corner: damping of the 6x6 camera block (a part that does not start from H_cc adds none; the reduced problem's corner carries it already)
+// ---- Helper workgroups of a part (latency mode: CUs idle anyway).  The products of a block column J are cut at K = J - near:
+//   far(I,J)  = sum_{K <  Ks} L(J,K) L(I,K)^T      Ks = min(nS, max(0, J - near)): block columns that were finished `near` columns ago
+//   near(I,J) = sum_{K >= Ks} L(J,K) L(I,K)^T      the last `near` block columns: the critical path, always the owner's
+//   acc(I,J)  = (H(I,J) - far) - near
+// A helper workgroup forms the far sums of whole block columns (rows, diagonal tile, border; factor_wide_helper) on another CU from the
+// finished L tiles and leaves them in Pf / PfB; the owner picks them up when they are there and otherwise forms them itself, in the same
+// order -- so the result does not depend on whether, when or how many helpers ran (the owner never blocks on one for long; a helper only
+// ever waits for the owner).  What crosses CUs (the owner's Lt / LbT tiles, the helpers' far sums, the flags) is stored and loaded at
+// agent scope (sc1): the L2 of another XCD holds no stale line of it.
+#ifndef SFT_WIDE_NEAR
+#define SFT_WIDE_NEAR 4
+#endif
+__device__ __forceinline__ int wide_near(int wb) { return SFT_WIDE_NEAR; }
+#define WIDE_SYNC_READY 16          // sync[WIDE_SYNC_READY + J] == epoch: column J's far sums are stored
+#ifndef WIDE_OWNER_POLLS
+#define WIDE_OWNER_POLLS 24         // how often the owner looks for a helper's column before it forms the far sums itself
+#endif
+#define WIDE_HELPER_POLLS 40000     // a helper that sees no progress of its owner for this long leaves
+
+__device__ __forceinline__ v4d tile_ld_agent(const SFT_G double* p) {
+  v4d r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+__device__ __forceinline__ void tile_st_agent(SFT_G double* p, const v4d& v) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) __hip_atomic_store(p + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 32 bytes per lane at agent scope through a buffer resource: two 16-byte loads the compiler keeps exact wait counts for
+typedef int v4i_w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const SFT_G double* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(const double*)p, 0, 0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ v4d tile_ld_rsrc(__amdgpu_buffer_rsrc_t r, unsigned lane32, unsigned tile_bytes) {
+  union { v4i_w i[2]; v4d d; } u;
+  u.i[0] = __builtin_amdgcn_raw_buffer_load_b128(r, lane32, tile_bytes, 16);        // aux 16 = sc1
+  u.i[1] = __builtin_amdgcn_raw_buffer_load_b128(r, lane32 + 16, tile_bytes, 16);
+  return u.d;
+}
+
+// a tile's 32 bytes per lane through a buffer resource: the address is (scalar resource, one shared lane offset, scalar tile offset) -- no
+// 64-bit per-lane pointer lives in vector registers.  AUX 0: plain, 16: agent scope (sc1)
+template <int AUX>
+__device__ __forceinline__ v4d gb_ld(__amdgpu_buffer_rsrc_t r, unsigned lane32, unsigned tile_bytes) {
+  union { v4i_w i[2]; v4d d; } u;
+  u.i[0] = __builtin_amdgcn_raw_buffer_load_b128(r, lane32, tile_bytes, AUX);
+  u.i[1] = __builtin_amdgcn_raw_buffer_load_b128(r, lane32 + 16, tile_bytes, AUX);
+  return u.d;
+}
+template <int AUX>
+__device__ __forceinline__ void gb_st(__amdgpu_buffer_rsrc_t r, unsigned lane32, unsigned tile_bytes, const v4d& v) {
+  union { v4i_w i[2]; v4d d; } u;
+  u.d = v;
+  __builtin_amdgcn_raw_buffer_store_b128(u.i[0], r, lane32, tile_bytes, AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(u.i[1], r, lane32 + 16, tile_bytes, AUX);
+}
+typedef double v2d_w __attribute__((ext_vector_type(2)));
+using lds_v2d_w = __attribute__((address_space(3))) v2d_w;
+// Staged tiles live in LDS as two 1 KB planes (registers 0,1 of every lane, then registers 2,3): every ds_read_b128 /
+// ds_write_b128 touches 64 consecutive 16-byte words.
+__device__ __forceinline__ v4d wide_lds_read(const lds_double* tile, int lane) {
+  const v2d_w lo = *reinterpret_cast<const lds_v2d_w*>(tile + 2 * lane);
+  const v2d_w hi = *reinterpret_cast<const lds_v2d_w*>(tile + 128 + 2 * lane);
+  return (v4d){lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void wide_lds_write(lds_double* tile, int lane, const v4d& v) {
+  *reinterpret_cast<lds_v2d_w*>(tile + 2 * lane) = (v2d_w){v[0], v[1]};
+  *reinterpret_cast<lds_v2d_w*>(tile + 128 + 2 * lane) = (v2d_w){v[2], v[3]};
+}
+__device__ __forceinline__ void wide_mfma4(const v4d& a, const v4d& b, v4d& s0, v4d& s1) {
+  s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], s0, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], s1, 0, 0, 0);
+  s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s0, 0, 0, 0);
+  s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s1, 0, 0, 0);
+}
+#define WIDE_U 4
+// sum_{K = K0 .. Kend-1} L(J,K) L(I,K)^T for one row: A operand = row-J tile (LDS, slot J-K-1), B operand = the stored tile of row I, ldB(i) =
+// the tile of block column K0 + i.  The FP64 MFMA pipe bounds the products (two waves per SIMD: 573 cycles per product), so the tile loads
+// must not add their latency to it: NCH chunks of WIDE_U products, fully unrolled (straight-line code keeps exact wait counts), the loads of
+// chunk c+1 issued before the MFMAs of chunk c.  Every chunk issues WIDE_U loads (the last tile again beyond the row's end).  The order of
+// the sum (two accumulators, K ascending) does not depend on NCH.
+template <int NCH, class LD>
+__device__ __forceinline__ v4d wide_products_n(int lane, int J, int K0, int Kend, const lds_double* rowJ, LD ldB) {
+  constexpr int U = WIDE_U;
+  v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+  v4d buf[2][U];
+  const int last = max(Kend - 1 - K0, 0);
+#pragma unroll
+  for (int u = 0; u < U; u++) buf[0][u] = ldB(min(u, last));
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (c + 1 < NCH) {
+#pragma unroll
+      for (int u = 0; u < U; u++) buf[(c + 1) & 1][u] = ldB(min(U * (c + 1) + u, last));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int K = K0 + U * c + u;
+      if (K < Kend) wide_mfma4(wide_lds_read(rowJ + (size_t)(J - K - 1) * TS * TS, lane), buf[c & 1][u], s0, s1);
+    }
+  }
+  return s0 + s1;
+}
+template <class LD>
+__device__ __forceinline__ v4d wide_products(int lane, int J, int K0, int Kend, const lds_double* rowJ, LD ldB) {
+  const int n = Kend - K0;
+  if (n <= 0) return (v4d){0.0, 0.0, 0.0, 0.0};
+  if (n <= WIDE_U) return wide_products_n<1>(lane, J, K0, Kend, rowJ, ldB);
+  if (n <= 2 * WIDE_U) return wide_products_n<2>(lane, J, K0, Kend, rowJ, ldB);
+  return wide_products_n<4>(lane, J, K0, Kend, rowJ, ldB);
+}
+// sum_{i < n} T_i T_i^T with T_i = ld(i) as both operands: the diagonal tile's products, formed from the stored tiles
+template <int NCH, class LD>
+__device__ __forceinline__ v4d wide_squares_n(int n, LD ld) {
+  constexpr int U = WIDE_U;
+  v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+  v4d buf[2][U];
+  const int last = max(n - 1, 0);
+#pragma unroll
+  for (int u = 0; u < U; u++) buf[0][u] = ld(min(u, last));
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (c + 1 < NCH) {
+#pragma unroll
+      for (int u = 0; u < U; u++) buf[(c + 1) & 1][u] = ld(min(U * (c + 1) + u, last));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (U * c + u < n) wide_mfma4(buf[c & 1][u], buf[c & 1][u], s0, s1);
+  }
+  return s0 + s1;
+}
+template <class LD>
+__device__ __forceinline__ v4d wide_squares(int n, LD ld) {
+  if (n <= 0) return (v4d){0.0, 0.0, 0.0, 0.0};
+  if (n <= WIDE_U) return wide_squares_n<1>(n, ld);
+  return wide_squares_n<4>(n, ld);
+}
+
+#ifdef SFT_WIDE_TRACE   // A/B builds: where a block column's time goes, per role (100 MHz ticks summed over the columns of the last factorisation)
+#define WT_T0() long long wt_t__ = wall_clock64()
+#define WT_SEG(seg) do { const long long t1__ = wall_clock64(); if (lane == 0) wtrace[d * 8 + (seg)] += (double)(t1__ - wt_t__); wt_t__ = t1__; } while (0)
+#else
+#define WT_T0() do {} while (0)
+#define WT_SEG(seg) do {} while (0)
+#endif
+// (A part sums far and near products separately, like factor_part with its helpers: the two functions agree bit for bit.)
 __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, double* ws) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,6 +248,10 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
   const auto LbTg = V.LbT;
   const auto Lbord = V.Lbord;
   const auto Linv_g = V.Linv;
+  const bool is_part = which == 0 || which == 1;
+  const int near = wide_near(wb);
+  // first block column of the near products of column J (the far ones end there); everything is "near" unless this is a part
+  auto ksplit = [&](int J) -> int { return is_part ? min(nS, max(0, J - near)) : 0; };
   // border element (row, column j of this matrix) of H
   auto bord_h = [&](int row, int j) -> double {
     const int jj = (j >= V.b_lo && j < V.b_hi) ? j : V.b_lo;
@@ -113,85 +268,17 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
     }
   }
   if (tid == 0) ctl->fact_ok = 1;
+#ifdef SFT_WIDE_TRACE
+  lds_double* wtrace = Cn + 580;          // (the A/B build gets 64 doubles more of LDS: sft_lm_kernel_lds_bytes)
+  if (tid < 64) wtrace[tid] = 0.0;
+#endif
   __syncthreads();
 
-  // sum_K L(J,K) L(I,K)^T for one row: A operand = row-J tile (LDS), B operand = the stored tile of row I (memory).
-  // The FP64 MFMA pipe bounds the products (two waves per SIMD: 573 cycles per product), so the tile loads must not add
-  // their latency to it: NCH chunks of U products, fully unrolled (straight-line code keeps exact wait counts), the loads of
-  // chunk c+1 issued before the MFMAs of chunk c.  Every chunk issues U loads (the last tile again beyond the row's end).
-  constexpr int U = 4;
   const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-  // Staged tiles live in LDS as two 1 KB planes (registers 0,1 of every lane, then registers 2,3): every ds_read_b128 /
-  // ds_write_b128 touches 64 consecutive 16-byte words.
-  typedef double v2d_ __attribute__((ext_vector_type(2)));
-  using lds_v2d = __attribute__((address_space(3))) v2d_;
-  auto lds_tile_read = [&](const lds_double* tile) -> v4d {
-    const v2d_ lo = *reinterpret_cast<const lds_v2d*>(tile + 2 * lane);
-    const v2d_ hi = *reinterpret_cast<const lds_v2d*>(tile + 128 + 2 * lane);
-    return (v4d){lo.x, lo.y, hi.x, hi.y};
-  };
-  auto lds_tile_write = [&](lds_double* tile, const v4d& v) {
-    *reinterpret_cast<lds_v2d*>(tile + 2 * lane) = (v2d_){v[0], v[1]};
-    *reinterpret_cast<lds_v2d*>(tile + 128 + 2 * lane) = (v2d_){v[2], v[3]};
-  };
-  auto mfma4 = [&](const v4d& a, const v4d& b, v4d& s0, v4d& s1) {
-    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], s1, 0, 0, 0);
-    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s1, 0, 0, 0);
-  };
-  // (Kend: the products run over block columns K0 .. Kend-1 -- Kend = J for an eliminated column, the part's nS for a separator column)
-  auto products_n = [&](auto nch_c, int J, int Kend, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
-    // brow: tile of block column K0 for this row; the tile of block column K0 + i sits i * bstride doubles further
-    constexpr int NCH = decltype(nch_c)::value;
-    v4d s0 = zero4, s1 = zero4;
-    v4d buf[2][U];
-    const int last = max(Kend - 1 - K0, 0);
-#pragma unroll
-    for (int u = 0; u < U; u++) buf[0][u] = wide_ltile_load(brow + (long)min(u, last) * bstride + 4 * lane);
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      if (c + 1 < NCH) {
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          buf[(c + 1) & 1][u] = wide_ltile_load(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int K = K0 + U * c + u;
-        if (K < Kend) mfma4(lds_tile_read(rowJ + (size_t)(J - K - 1) * TS * TS), buf[c & 1][u], s0, s1);
-      }
-    }
-    return s0 + s1;
-  };
-  // sum_{K = K0 .. Kend-1} T_K T_K^T with T_K = the stored tile (I, K) from memory as both operands: the diagonal tile of the
-  // NEXT column, formed a column ahead (look-ahead) from the tiles that already exist.
-  auto squares = [&](const SFT_G double* brow, long bstride, int n) -> v4d {
-    v4d s0 = zero4, s1 = zero4;
-    v4d buf[2][U];
-    const int last = max(n - 1, 0);
-#pragma unroll
-    for (int u = 0; u < U; u++) buf[0][u] = wide_ltile_load(brow + (long)min(u, last) * bstride + 4 * lane);
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      if (c + 1 < 4) {
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          buf[(c + 1) & 1][u] = wide_ltile_load(brow + (long)min(U * (c + 1) + u, last) * bstride + 4 * lane);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        if (U * c + u < n) mfma4(buf[c & 1][u], buf[c & 1][u], s0, s1);
-    }
-    return s0 + s1;
-  };
-  auto products = [&](int J, int I, const lds_double* rowJ, const SFT_G double* brow, long bstride, int K0) -> v4d {
-    const int Kend = min(J, nS);
-    const int n = Kend - K0;
-    if (n <= 0) return zero4;
-    if (n <= 2 * U) return products_n(std::integral_constant<int, 2>{}, J, Kend, rowJ, brow, bstride, K0);
-    return products_n(std::integral_constant<int, 4>{}, J, Kend, rowJ, brow, bstride, K0);
-  };
+  const long kstride = (long)(tpr - 1) * TS * TS;        // tile (I, K+1) sits (tpr - 1) tiles after tile (I, K)
+  // tiles of this workgroup's own factor: plain loads
+  auto own_row = [&](int I, int K0) { const SFT_G double* brow = Ltg + wtile_off(tpr, K0, I - K0) + 4 * lane; return [=](int i) -> v4d { return wide_ltile_load(brow + (long)i * kstride); }; };
+  auto own_brd = [&](int K0) { const SFT_G double* brow = LbTg + (size_t)K0 * TS * TS + 4 * lane; return [=](int i) -> v4d { return wide_ltile_load(brow + (long)i * (TS * TS)); }; };
   // Schur contribution of a part: tile (I, J) of the separator block, transposed tile in accumulator layout like H's tiles, into the
   // exchange buffer (layout of the reduced problem's H).  Part 1 runs in reversed order: element (i, j) of its separator block is
   // element (s-1-j, s-1-i) of the natural one.
@@ -207,7 +294,6 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
 #pragma unroll
     for (int q = 0; q < 4; q++) dst[tile_elem(15 - ccol, 15 - (crow + 4 * q))] = t[q];
   };
-  const long kstride = (long)(tpr - 1) * TS * TS;        // tile (I, K+1) sits (tpr - 1) tiles after tile (I, K)
   // Look-ahead: the diagonal tile of column J+1 minus its products with block columns <= J-1 is formed during column J by the
   // wave that owns column J+1 next (roles rotate by one wave per column) and waits in its registers.
   v4d dlook = *reinterpret_cast<const SFT_G v4d*>(Hg + 4 * lane);     // column 0: H(0,0), no products
@@ -216,6 +302,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
   for (int J = 0; J < nT; J++) {
     lds_double* rowJ = Lrow + (size_t)(J & 1) * WB * TS * TS;
     lds_double* rowN = Lrow + (size_t)((J + 1) & 1) * WB * TS * TS;
+    const int Kend = min(J, nS), Ks = ksplit(J);
     // Roles rotate with the column.  The FP64 MFMA pipe is what the products are bound by (73 cycles per MFMA, two waves per
     // SIMD: tools/probes/lds_mfma_probe.hip), so the rows are dealt by their number of products, and the Cholesky is taken
     // off the path every wave waits for: role 0 (owner of column J) starts from the look-ahead tile, adds the one product
@@ -224,6 +311,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
     //   0: diag, J+10, J+12 (+ product-free J+16) | 1: look-ahead, J+13, J+14 | 2: J+1, J+11 | 3: J+2, J+9 | 4: J+3, J+8
     //   5: J+4, J+7 | 6: J+5, J+6 | 7: border, J+15
     const int d = (wave - J) & 7;
+    WT_T0();
     int Irow[3];
     Irow[0] = J + (d == 0 ? 10 : d == 1 ? 13 : d == 7 ? 15 : d - 1);
     Irow[1] = J + (d == 0 ? 12 : d == 1 ? 14 : d == 2 ? 11 : d == 3 ? 9 : d == 4 ? 8 : d == 5 ? 7 : d == 6 ? 6 : 99);
@@ -244,9 +332,9 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
       __builtin_amdgcn_s_setprio(3);
       v4d dt = dlook;
       if (J >= 1 && J - 1 < nS) {
-        const v4d a = lds_tile_read(rowJ);
+        const v4d a = wide_lds_read(rowJ, lane);
         v4d s0 = zero4, s1 = zero4;
-        mfma4(a, a, s0, s1);
+        wide_mfma4(a, a, s0, s1);
         dt -= s0 + s1;
       }
       if (elim) {
@@ -265,6 +353,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
       }
       __builtin_amdgcn_s_setprio(0);
     }
+    WT_SEG(0);
     v4d accT[3];
     bool have[3];
 #pragma unroll
@@ -273,17 +362,23 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
       have[t] = I < nT && I - J <= wb;
       if (have[t]) {
         const v4d h = *reinterpret_cast<const SFT_G v4d*>(Hg + wtile_off(tpr, I, I - J) + 4 * lane);
-        const int K0 = max(0, I - wb);
-        accT[t] = h - products(J, I, rowJ, Ltg + wtile_off(tpr, K0, I - K0), kstride, K0);
+        const int K0 = max(0, I - wb), Kn = max(K0, Ks);
+        v4d far = zero4;
+        if (Ks > K0) far = wide_products(lane, J, K0, Ks, rowJ, own_row(I, K0));
+        accT[t] = (h - far) - wide_products(lane, J, Kn, Kend, rowJ, own_row(I, Kn));
       }
     }
+    WT_SEG(1);
     if (d == 1 && J + 1 < nT) {
       // look-ahead for column J+1: H(J+1,J+1) - sum_{K <= J-1} L(J+1,K) L(J+1,K)^T  (the product with block column J follows
       // in the next column, when tile (J+1, J) exists)
-      const int I = J + 1, K0 = max(0, I - wb);
+      const int I = J + 1, K0 = max(0, I - wb), Ks1 = ksplit(I), Kn = max(K0, Ks1);
       const v4d h = *reinterpret_cast<const SFT_G v4d*>(Hg + wtile_off(tpr, I, 0) + 4 * lane);
-      dlook = h - squares(Ltg + wtile_off(tpr, K0, I - K0), kstride, min(J, nS) - K0);
+      v4d far = zero4;
+      if (Ks1 > K0) far = wide_squares(Ks1 - K0, own_row(I, K0));
+      dlook = (h - far) - wide_squares(Kend - Kn, own_row(I, Kn));
     }
+    WT_SEG(2);
     // border: accTb[j][i] = Hbord[i][16 J + j] - sum_K (L(J,K) Lb(K)^T)[j][i], i < 7
     v4d accTb = zero4;
     const bool bwave = d == 7;
@@ -293,13 +388,17 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
 #pragma unroll
         for (int q = 0; q < 4; q++) h[q] = bord_h(ccol, TS * J + crow + 4 * q);
       }
-      const int K0 = max(0, J - wb);
-      accTb = h - products(J, nT, rowJ, LbTg + (size_t)K0 * TS * TS, (long)TS * TS, K0);
+      const int K0 = max(0, J - wb), Kn = max(K0, Ks);
+      v4d far = zero4;
+      if (Ks > K0) far = wide_products(lane, J, K0, Ks, rowJ, own_brd(K0));
+      accTb = (h - far) - wide_products(lane, J, Kn, Kend, rowJ, own_brd(Kn));
     }
 #pragma unroll
     for (int h = 0; h < 2; h++)
-      if (staged[h]) lds_tile_write(rowN + (size_t)(1 + wave + 8 * h) * TS * TS, stage[h]);
+      if (staged[h]) wide_lds_write(rowN + (size_t)(1 + wave + 8 * h) * TS * TS, lane, stage[h]);
+    WT_SEG(3);
     lds_barrier();                                       // W_J is published
+    WT_SEG(4);
     // ---- TRSM: X^T = W accT (kept for the factor), X = acc W^T (kept for the back substitution) ----
     if (!elim) {
       // separator column of a part: the raw tiles are its Schur contribution (separator block, separator x camera/rhs border)
@@ -331,7 +430,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
       }
       *reinterpret_cast<SFT_G v4d*>(Ltg + wtile_off(tpr, J, I - J) + 4 * lane) = xT;
       *reinterpret_cast<SFT_G v4d*>(Lg + wtile_off(tpr, J, I - J) + 4 * lane) = x;
-      if (I == J + 1) lds_tile_write(rowN, xT);
+      if (I == J + 1) wide_lds_write(rowN, lane, xT);
     }
     if (bwave) {
       v4d xbT = zero4;
@@ -345,8 +444,15 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xbT[kk], -xbT[kk], cacc, 0, 0, 0);
     }
+    WT_SEG(5);
+    WT_SEG(6);
     __syncthreads();                                     // the column's tiles are in memory (and in rowN) for the next one
+    WT_SEG(7);
   }
+#ifdef SFT_WIDE_TRACE
+  __syncthreads();
+  if (is_part && tid < 64) P.dbg[64 * which + tid] = wtrace[tid];
+#endif
   // ---- corner: partial sums of the eight waves in a fixed order, then the 6x6 Schur complement of the camera ----
 #pragma unroll
   for (int q = 0; q < 2; q++) {
@@ -391,6 +497,512 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
       }
   }
   __syncthreads();
+}
+
+__device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J, lds_double* rowJ);   // (the view is rebuilt there: the caller's stays in registers)
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The owner of a part when helper workgroups deliver the far sums (latency mode; the arithmetic, order for order, of factor_wide(P, part)
+// -- the two are interchangeable bit for bit).  What is left to the owner are the products with the last NEAR block columns, and their
+// operands never leave the CU:
+//   * rows are owned by waves (row I on wave I mod 8: two live rows per wave, three on the pivot wave), and a wave keeps the last NEAR
+//     tiles of its rows -- its own TRSM results -- in registers (ring Lr, shifted by one tile per column): the B operands;
+//   * the tiles of a row that is about to become the pivot row (distance <= NEAR) also go to an LDS ring (row mod 8, column mod NEAR): the A
+//     operands of every wave NEAR columns later; the border tiles of the last NEAR columns likewise;
+//   * the far sum arrives as ONE tile per row, H(I,J)^T - far(I,J), formed by the helper and requested a column ahead;
+//   * the pivot chain runs inside one wave, a column ahead: the wave that owns row J+1 takes tile (J+1, J) out of its TRSM straight into the
+//     diagonal tile of column J+1, factors it and publishes W_{J+1} while the other waves finish column J -- so a column is products, TRSM and
+//     ONE barrier, and nobody waits for a Cholesky.
+// LDS: 8 x NEAR + NEAR staged tiles, two W, the corner partials.
+// One tile, global memory -> LDS without passing registers (LDS-DMA): two requests of 64 x 16 bytes; the lane's 32 bytes of the tile land as the
+// two planes wide_lds_read expects.  Not known to the compiler's wait counters: whoever reads the tile waits for vmcnt itself.
+template <bool AGENT>
+__device__ __forceinline__ void wide_dma_tile(lds_double* dst, const SFT_G double* tile_, unsigned lane32) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+  const SFT_G double* tile = uni(tile_);
+  if (AGENT)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 sc1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1 sc1"
+                 :: "s"(la), "s"(tile), "v"(lane32), "v"(lane32 + 16u) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1"
+                 :: "s"(la), "s"(tile), "v"(lane32), "v"(lane32 + 16u) : "memory", "m0");
+}
+
+template <int NEAR>
+__device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, double* ws, int epoch, int nh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WideView V = wide_view(P, which);
+  const int nT = V.nT, nS = V.nS;
+  const int tpr = V.tpr, wb = V.wb;
+  const int Dnp = TS * nT;
+  // [(I % (NEAR + 1)) * NEAR + K % NEAR]: X(I,K)^T of the rows within NEAR of becoming the pivot row (NEAR + 1 row slots: the border role reads
+  // all NEAR tiles of the pivot row while the row NEAR below it already writes its first)
+  lds_double* Aring = to_lds(ws);
+  lds_double* Bring = Aring + (NEAR + 1) * NEAR * TS * TS;       // [K % NEAR]: the border tile of block column K
+  lds_double* Wbuf = Bring + NEAR * TS * TS;               // [J & 1]: W_J, k-major padded: [k*TP + j] = W[j][k]
+  lds_double* Cn = Wbuf + 2 * TILE_LDS;                    // 8 partial 7x7 corners, then the corner itself
+  lds_int* hflag = (lds_int*)(Cn + 576);                   // [c & 3]: the far sums of block column c have been delivered by a helper
+  lds_double* Land = Cn + 704;                             // [wave * 4 + slot]: where the start tiles of a wave's next column land (slot 3: border / diagonal tile)
+  // the staging area of wide_far_column when the owner forms a column itself: far tiles sit in its slots NEAR .. wb-1, the area starts there
+  lds_double* Fstage = Land + 32 * TS * TS - NEAR * TS * TS;
+  lds_double* myland = Land + (size_t)wave * 4 * TS * TS;
+  const double lambda = ctl->lambda;
+  const int crow = lane >> 4, ccol = lane & 15;
+  const auto Hg = V.Hb;
+  const auto Hbord = V.Hbord;
+  const auto Lg = V.Lb;
+  const auto Ltg = V.Lt;
+  const auto LbTg = V.LbT;
+  const auto Lbord = V.Lbord;
+  const auto Linv_g = V.Linv;
+  const bool helped = nh > 0 && epoch > 0 && V.sync != nullptr;
+  const __amdgpu_buffer_rsrc_t rLt = wide_rsrc(Ltg), rLb = wide_rsrc(Lg), rLbT = wide_rsrc(LbTg), rLinv = wide_rsrc(Linv_g);
+  const unsigned lane32 = 32u * lane;
+  auto toff = [&](int I, int dd) -> unsigned { return (unsigned)(((unsigned)I * (unsigned)tpr + (unsigned)dd) * (TS * TS * 8u)); };
+  const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto ksplit = [&](int J) -> int { return min(nS, max(0, J - NEAR)); };
+  auto bord_h = [&](int row, int j) -> double {
+    const int jj = (j >= V.b_lo && j < V.b_hi) ? j : V.b_lo;
+    const double v = Hbord[(size_t)row * V.bstride + V.b_base + V.b_sign * jj];
+    return (j >= V.b_lo && j < V.b_hi) ? v : 0.0;
+  };
+  auto bord_tile = [&](int J) -> v4d {
+    v4d h = zero4;
+    if (ccol < SFT_BORDER) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) h[q] = bord_h(ccol, TS * J + crow + 4 * q);
+    }
+    return h;
+  };
+  auto schur_store = [&](int I, int J, const v4d& t) {
+    const int Ir = I - nS, Jr = J - nS;
+    if (!V.reversed) {
+      *reinterpret_cast<SFT_G v4d*>(V.xchg + wtile_off(V.xr_tpr, Ir, Ir - Jr) + 4 * lane) = t;
+      return;
+    }
+    const int It = V.xr_nT - 1 - Jr, Jt = V.xr_nT - 1 - Ir;
+    const auto dst = V.xchg + wtile_off(V.xr_tpr, It, It - Jt);
+#pragma unroll
+    for (int q = 0; q < 4; q++) dst[tile_elem(15 - ccol, 15 - (crow + 4 * q))] = t[q];
+  };
+  // The tile a row starts a column from -- H(I,J)^T - far(I,J) as a helper (or the fallback below) left it, or H(I,J)^T where no far product
+  // exists -- is requested into the wave's landing slot a column ahead
+  auto request_tile = [&](int slot, int I, int J) {
+    if (I >= nT || I - J > wb) return;
+    if (ksplit(J) > max(0, I - wb)) wide_dma_tile<true>(myland + slot * TS * TS, V.Pf + wtile_off(tpr, J, I - J), lane32);
+    else wide_dma_tile<false>(myland + slot * TS * TS, Hg + wtile_off(tpr, I, I - J), lane32);
+  };
+  auto request_border = [&](int J) {
+    if (ksplit(J) > max(0, J - wb)) wide_dma_tile<true>(myland + 3 * TS * TS, V.PfB + (size_t)J * TS * TS, lane32);
+    else wide_lds_write(myland + 3 * TS * TS, lane, bord_tile(J));
+  };
+  v4d cacc = zero4;
+  if (wave == 0 && V.corner_from_H) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = V.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
+    }
+  }
+  if (tid == 0) ctl->fact_ok = 1;
+  if (tid < 4) hflag[tid] = 0;
+#ifdef SFT_WIDE_TRACE
+  lds_double* wtrace = Cn + 580;
+  if (tid < 64) wtrace[tid] = 0.0;
+#endif
+  __syncthreads();
+  int misses = 0;
+#ifdef DSH_LAB
+  int st_got = 0, st_miss = 0, st_polls = 0;
+  long long st_wait = 0;
+#endif
+  auto look_for_helper = [&](int J) {
+    if (!helped || tid != 0) return;
+    const int c = J + 2;
+    int got = 0;
+    if (c < nT && ksplit(c) - max(0, c - wb) > 0) {
+#ifdef DSH_LAB
+      const long long t0 = wall_clock64();
+#endif
+      const int polls = misses >= 2 ? 1 : WIDE_OWNER_POLLS;
+      for (int i = 0; i < polls; i++) {
+#ifdef DSH_LAB
+        st_polls++;
+#endif
+        if (__hip_atomic_load(V.sync + WIDE_SYNC_READY + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { got = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      misses = got ? 0 : misses + 1;
+#ifdef DSH_LAB
+      st_wait += wall_clock64() - t0;
+      if (got) st_got++; else st_miss++;
+#endif
+    }
+    hflag[c & 3] = got;
+  };
+  // diagonal tile -> W (or, in a separator column, the part's Schur contribution): the pivot chain of block column Jp
+  auto pivot = [&](int Jp, v4d dt) {
+    if (Jp < nS) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (crow + 4 * q == ccol && TS * Jp + ccol >= V.lam_lo && TS * Jp + ccol < V.lam_hi) dt[q] += lambda;
+      v4d w = dt;
+      const bool ok = chol_inv_blocked(dt, w);
+      if (!ok && lane == 0) ctl->fact_ok = 0;
+      lds_double* dst = Wbuf + (size_t)(Jp & 1) * TILE_LDS + ccol * TP + crow;
+#pragma unroll
+      for (int q = 0; q < 4; q++) dst[4 * q] = w[q];
+      gb_st<0>(rLinv, lane32, (unsigned)Jp * (TS * TS * 8u), w);
+    } else {
+      schur_store(Jp, Jp, dt);
+    }
+  };
+  // ---- prologue: the tiles of column 0 and W_0
+  v4d Lr[2][NEAR];                   // ring of the wave's rows: at column J entry k is X(I, J - NEAR + k)^T
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int k = 0; k < NEAR; k++) Lr[s][k] = zero4;
+  // Sums over the block columns that were finished before the last barrier are formed a column ahead (pre-products): behind the barrier
+  // a row only waits for ONE product -- with the tile of row J received in the column before -- and its TRSM
+  v4d pre0[2] = {zero4, zero4}, pre1[2] = {zero4, zero4}, preS = zero4;
+  request_tile(0, wave, 0);
+  request_tile(1, wave + 8, 0);
+  if (wave == 0) request_tile(2, 16, 0);
+  if (wave == 7) request_border(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave == 0) pivot(0, wide_lds_read(myland, lane));
+  __syncthreads();
+
+#pragma unroll 1
+  for (int J = 0; J < nT; J++) {
+    const int d = (wave - J) & 7;
+    const int Kend = min(J, nS), Ks = ksplit(J);
+    const bool elim = J < nS;
+    const int Irow[3] = {J + d, J + d + 8, d == 0 ? J + 16 : nT};
+    const int nI[3] = {d == 0 ? J + 8 : (d == 1 ? nT : J + d), d == 0 ? J + 16 : J + d + 8, d == 1 ? J + 17 : nT};
+    WT_T0();
+    // (1) a column no helper has delivered (the verdict on column J+1 fell before the last barrier): the workgroup forms it itself, now
+    if (J + 1 < nT && ksplit(J + 1) > max(0, J + 1 - wb) && !uni(hflag[(J + 1) & 3])) wide_far_column_of(P, which, J + 1, Fstage);
+    // (2) the next pivot's diagonal tile: requested now (slot 3), used behind this column's first TRSM
+    if (d == 1 && J + 1 < nT) request_tile(3, J + 1, J + 1);
+    WT_SEG(0);
+    // (3) the last near product (block column J-1: its tile of row J arrived with the barrier), then the row's tile
+    const lds_double* Arow = Aring + (size_t)(J % (NEAR + 1)) * NEAR * TS * TS;
+    v4d cur[3] = {zero4, zero4, zero4}, curB = zero4;
+    {
+      const int K = J - 1;
+      const bool kin = K >= 0 && K < Kend;
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        const int I = Irow[s];
+        if ((s == 0 && d == 0) || I >= nT || I - J > wb) continue;
+        const v4d st = wide_lds_read(myland + s * TS * TS, lane);
+        if (s < 2) {
+          if (kin && K >= max(max(0, I - wb), Ks)) wide_mfma4(wide_lds_read(Arow + (size_t)(K % NEAR) * TS * TS, lane), Lr[s][NEAR - 1], pre0[s], pre1[s]);
+          cur[s] = st - (pre0[s] + pre1[s]);
+        } else {
+          cur[s] = st - zero4;
+        }
+      }
+      if (d == 7) {   // the border: all of its near products here (the role moves from wave to wave)
+        const int Klo = max(max(0, J - wb), Ks);
+        v4d s0 = zero4, s1 = zero4;
+#pragma unroll
+        for (int k = 0; k < NEAR; k++) {
+          const int Kb = J - NEAR + k;
+          if (Kb >= Klo && Kb < Kend)
+            wide_mfma4(wide_lds_read(Arow + (size_t)(Kb % NEAR) * TS * TS, lane), wide_lds_read(Bring + (size_t)(Kb % NEAR) * TS * TS, lane), s0, s1);
+        }
+        curB = wide_lds_read(myland + 3 * TS * TS, lane) - (s0 + s1);
+      }
+    }
+    // the start tiles of the next column (the landing slots are free again); the wave with the pivot chain asks behind the chain
+    if (d != 1 && J + 1 < nT) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) request_tile(s, nI[s], J + 1);
+      if (d == 0) request_border(J + 1);
+    }
+    WT_SEG(1);
+    // (4) TRSM with W_J (published a column ago), nearest row first; the wave that owns the next pivot row runs the pivot chain of
+    //     column J+1 right behind its first tile
+    double wv[4];
+    if (elim) {
+      const lds_double* Wj = Wbuf + (size_t)(J & 1) * TILE_LDS;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) wv[kk] = Wj[(4 * kk + crow) * TP + ccol];
+    }
+    v4d newC = zero4;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int I = Irow[s];
+      const bool have = !(s == 0 && d == 0) && I < nT && I - J <= wb;
+      v4d xT = zero4, x = zero4;
+      if (have && elim) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          xT = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], cur[s][kk], xT, 0, 0, 0);
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[s][kk], wv[kk], x, 0, 0, 0);
+        }
+        if (I - J <= NEAR) wide_lds_write(Aring + ((size_t)(I % (NEAR + 1)) * NEAR + (J % NEAR)) * TS * TS, lane, xT);
+      }
+      if (s == 0 && d == 1 && J + 1 < nT) {
+        // the pivot chain of column J+1: start tile - the squares of the row's ring (block columns <= J-1: summed a column ago), then - the
+        // square of the tile that has just left the TRSM
+        const int Ip = J + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the diagonal tile has landed
+        v4d dt = wide_lds_read(myland + 3 * TS * TS, lane);
+        dt = dt - preS;
+        if (elim) {
+          v4d t0 = zero4, t1 = zero4;
+          wide_mfma4(xT, xT, t0, t1);
+          dt -= t0 + t1;
+        }
+        pivot(Ip, dt);
+        if (J + 1 < nT) {
+#pragma unroll
+          for (int t = 0; t < 3; t++) request_tile(t, nI[t], J + 1);
+        }
+      }
+      if (have) {
+        if (elim) {
+          if (helped) gb_st<16>(rLt, lane32, toff(J, I - J), xT);
+          else gb_st<0>(rLt, lane32, toff(J, I - J), xT);
+          gb_st<0>(rLb, lane32, toff(J, I - J), x);
+        } else {
+          schur_store(I, J, cur[s]);
+        }
+      }
+      if (s < 2) {
+#pragma unroll
+        for (int k = 0; k + 1 < NEAR; k++) Lr[s][k] = Lr[s][k + 1];
+        Lr[s][NEAR - 1] = xT;
+      } else {
+        newC = xT;
+      }
+    }
+    WT_SEG(2);
+    // (5) the border's TRSM, the corner's update
+    if (d == 7) {
+      if (elim) {
+        v4d xbT = zero4;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) xbT = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[kk], curB[kk], xbT, 0, 0, 0);
+        wide_lds_write(Bring + (size_t)(J % NEAR) * TS * TS, lane, xbT);
+        if (helped) gb_st<16>(rLbT, lane32, (unsigned)J * (TS * TS * 8u), xbT);
+        else gb_st<0>(rLbT, lane32, (unsigned)J * (TS * TS * 8u), xbT);
+        if (ccol < SFT_BORDER) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) Lbord[(size_t)ccol * Dnp + TS * J + crow + 4 * q] = xbT[q];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xbT[kk], -xbT[kk], cacc, 0, 0, 0);
+      } else if (ccol < SFT_BORDER) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int jl = TS * (J - nS) + crow + 4 * q;
+          V.xchg[(size_t)V.xr_nT * V.xr_tpr * (TS * TS) + (size_t)ccol * (TS * V.xr_nT) + (V.reversed ? TS * V.xr_nT - 1 - jl : jl)] = curB[q];
+        }
+      }
+    }
+    WT_SEG(3);
+    // (6) the rows move up a slot behind the pivot row
+    if (d == 0) {
+#pragma unroll
+      for (int k = 0; k < NEAR; k++) { Lr[0][k] = Lr[1][k]; Lr[1][k] = k + 1 < NEAR ? zero4 : newC; }
+    }
+    // (7) the pre-products of column J+1: everything but its last block column (ring entry k is block column J + 1 - NEAR + k now)
+    {
+      const int J1 = J + 1, Kend1 = min(J1, nS), Ks1 = ksplit(J1);
+      const lds_double* Arow1 = Aring + (size_t)(J1 % (NEAR + 1)) * NEAR * TS * TS;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        pre0[s] = zero4; pre1[s] = zero4;
+        const int I = nI[s];
+        if (I >= nT || I - J1 > wb) continue;
+        const int Klo = max(max(0, I - wb), Ks1);
+#pragma unroll
+        for (int k = 0; k + 1 < NEAR; k++) {
+          const int K = J1 - NEAR + k;
+          if (K >= Klo && K < Kend1) wide_mfma4(wide_lds_read(Arow1 + (size_t)(K % NEAR) * TS * TS, lane), Lr[s][k], pre0[s], pre1[s]);
+        }
+      }
+      if (d == 2) {   // the pivot chain of the next column: the squares of row J+2's ring (block columns <= J)
+        const int Ip = J + 2, Klo = max(max(0, Ip - wb), ksplit(Ip));
+        v4d s0 = zero4, s1 = zero4;
+#pragma unroll
+        for (int k = 0; k < NEAR; k++) {
+          const int K = J1 - NEAR + k;
+          if (K >= Klo && K < Kend1) wide_mfma4(Lr[0][k], Lr[0][k], s0, s1);
+        }
+        preS = s0 + s1;
+      }
+    }
+    WT_SEG(4);
+    look_for_helper(J);
+    WT_SEG(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this column's stores have arrived (a helper may read them), the next column's tiles have landed
+    WT_SEG(6);
+    __syncthreads();
+    WT_SEG(7);
+    if (helped && tid == 0) __hip_atomic_store(V.sync, (epoch << 16) | (J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#ifdef SFT_WIDE_TRACE
+  __syncthreads();
+  if (tid < 64) P.dbg[64 * which + tid] = wtrace[tid];
+#endif
+#ifdef DSH_LAB
+  if (helped && tid == 0) {
+    atomicAdd((int*)V.sync + 1, st_got); atomicAdd((int*)V.sync + 2, st_miss); atomicAdd((int*)V.sync + 3, st_polls); atomicAdd((int*)V.sync + 4, (int)st_wait);
+  }
+#endif
+  // ---- corner: partial sums of the eight waves in a fixed order; the part's corner contribution and whether its factorisation failed
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int r = crow + 4 * q;
+    if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[64 * wave + r * 7 + ccol] = cacc[q];
+  }
+  __syncthreads();
+  if (tid < 49) {
+    double sum = 0.0;
+    for (int w = 0; w < 8; w++) sum += Cn[64 * w + tid];
+    Cn[512 + tid] = sum;
+  }
+  __syncthreads();
+  const auto xc = V.xchg + (size_t)V.xr_nT * V.xr_tpr * (TS * TS) + (size_t)8 * TS * V.xr_nT;
+  if (tid < 49) xc[tid] = Cn[512 + tid];
+  if (tid == 0) xc[56] = ctl->fact_ok ? 0.0 : 1.0;
+  __syncthreads();
+}
+
+// The far sums of block column J of a part, by one workgroup (a helper's -- or the owner's own, for a column no helper delivered in time:
+// one routine, one order of summation): the far tiles of tile row J staged in LDS (rowJ, slot J - K - 1), then far(I,J) for every row of the
+// column, the diagonal tile and the border -- one or two of them per wave, dealt by their number of products.  What is stored (agent scope)
+// is the tile the owner starts the column from: H(I,J)^T - far(I,J).  Every tile of a wave's item is requested before the first product.
+__device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_double* rowJ) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nT = V.nT, nS = V.nS, tpr = V.tpr, wb = V.wb;
+  const int Ks = min(nS, J - SFT_WIDE_NEAR), K0d = max(0, J - wb);
+  if (Ks <= K0d) return;
+  const __amdgpu_buffer_rsrc_t rLt = wide_rsrc(V.Lt);
+  const unsigned lane32 = 32u * lane;
+  const int crow = lane >> 4, ccol = lane & 15;
+  const long kstride = (long)(tpr - 1) * TS * TS;
+  for (int s = wave; s < Ks - K0d; s += 8) {
+    const int K = K0d + s;
+    wide_lds_write(rowJ + (size_t)(J - K - 1) * TS * TS, lane, tile_ld_rsrc(rLt, lane32, (unsigned)(wtile_off(tpr, K, J - K) * 8)));
+  }
+  lds_barrier();
+  // items by falling number of products: 0 border, 1 diagonal tile, i >= 2 row J + i - 1; wave w takes items w and 15 - w
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int item = pass == 0 ? wave : 15 - wave;
+    if (item == 0) {
+      v4d h = {0.0, 0.0, 0.0, 0.0};
+      if (ccol < SFT_BORDER) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int j = TS * J + crow + 4 * q;
+          const bool in = j >= V.b_lo && j < V.b_hi;
+          const double v = V.Hbord[(size_t)ccol * V.bstride + V.b_base + V.b_sign * (in ? j : V.b_lo)];
+          h[q] = in ? v : 0.0;
+        }
+      }
+      const SFT_G double* brow = V.LbT + (size_t)K0d * TS * TS + 4 * lane;
+      const v4d far = wide_products(lane, J, K0d, Ks, rowJ, [=](int i) -> v4d { return tile_ld_agent(brow + (long)i * (TS * TS)); });
+      tile_st_agent(V.PfB + (size_t)J * TS * TS + 4 * lane, h - far);
+    } else if (item == 1) {
+      const v4d h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(tpr, J, 0) + 4 * lane);
+      const unsigned b0 = (unsigned)(wtile_off(tpr, K0d, J - K0d) * 8), bs = (unsigned)(kstride * 8);
+      const v4d far = wide_squares(Ks - K0d, [=](int i) -> v4d { return tile_ld_rsrc(rLt, lane32, b0 + (unsigned)i * bs); });
+      tile_st_agent(V.Pf + wtile_off(tpr, J, 0) + 4 * lane, h - far);
+    } else {
+      const int I = J + item - 1, K0 = max(0, I - wb);
+      if (I < nT && I - J <= wb && Ks > K0) {
+        const v4d h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(tpr, I, I - J) + 4 * lane);
+        const unsigned b0 = (unsigned)(wtile_off(tpr, K0, I - K0) * 8), bs = (unsigned)(kstride * 8);
+        const v4d far = wide_products(lane, J, K0, Ks, rowJ, [=](int i) -> v4d { return tile_ld_rsrc(rLt, lane32, b0 + (unsigned)i * bs); });
+        tile_st_agent(V.Pf + wtile_off(tpr, J, I - J) + 4 * lane, h - far);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                        // every wave's tiles have arrived
+}
+
+__device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J, lds_double* rowJ) {
+  const WideView V = wide_view(P, which);
+  wide_far_column(V, J, rowJ);
+}
+
+// A helper workgroup of part `which` (see the comment in front of factor_wide): hidx of nh, block columns near + 1 + hidx, + nh, ...
+// For its column J it waits until the owner has finished the block columns below Ks = min(nS, J - near), forms the column (wide_far_column)
+// and raises its flag.  It never makes the owner wait: a column the owner has already decided about is skipped, and a helper whose owner
+// shows no progress (or is not there) leaves.
+__device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int hidx, int nh, int epoch, Ctl* ctl, double* ws) {
+  const int tid = threadIdx.x;
+  const WideView V = wide_view(P, which);
+  if (V.sync == nullptr || nh <= 0) return;
+  const int nT = V.nT, nS = V.nS, wb = V.wb;
+  const int near = wide_near(wb);
+  lds_double* rowJ = to_lds(ws);                        // far tiles of tile row J, slot J - K - 1 like the owner's
+  lds_int* cmd = (lds_int*)(rowJ + 2 * WB * TS * TS);   // thread 0's verdict on the column: 1 go, 0 skip, -1 leave
+  int polls_left = WIDE_HELPER_POLLS;
+#ifdef DSH_LAB
+  int st_done = 0, st_skip = 0;
+  long long st_wait = 0, st_work = 0;
+#endif
+  int J = near + 1 + hidx;
+#pragma unroll 1
+  while (J < nT) {
+    const int Ks = min(nS, J - near), K0d = max(0, J - wb);
+#ifdef DSH_LAB
+    const long long t0 = wall_clock64();
+#endif
+    if (tid == 0) {
+      int c = 0;
+      while (true) {
+        const int w = __hip_atomic_load(V.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int cols = (w >> 16) == epoch ? (w & 0xffff) : 0;
+        if (cols >= nT) { c = -1; break; }                // the owner is through
+        if (cols >= J - 1) {                              // the owner has decided about this column (or is past it): on to the first column it has not
+          cmd[1] = J + ((cols + 2 - J + nh - 1) / nh) * nh;
+          c = 0;
+          break;
+        }
+        if (cols >= Ks) { c = 1; break; }
+        if (--polls_left <= 0) { c = -1; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      cmd[0] = c;
+    }
+    __syncthreads();
+    const int go = uni(cmd[0]), Jskip = uni(cmd[1]);
+    __syncthreads();                                      // (cmd is rewritten for the next column)
+#ifdef DSH_LAB
+    const long long t1 = wall_clock64();
+    st_wait += t1 - t0;
+    if (go <= 0 && tid == 0) {
+      if (go == 0) st_skip++;
+      if (go < 0) { atomicAdd((int*)V.sync + 5, st_done); atomicAdd((int*)V.sync + 6, st_skip); atomicAdd((int*)V.sync + 7, (int)st_wait); atomicAdd((int*)V.sync + 8, (int)st_work); }
+    }
+#endif
+    if (go < 0) return;
+    if (go == 0) { J = Jskip; continue; }
+    if (Ks <= K0d) { J += nh; continue; }
+    wide_far_column(V, J, rowJ);
+    if (tid == 0) __hip_atomic_store(V.sync + WIDE_SYNC_READY + J, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DSH_LAB
+    st_work += wall_clock64() - t1;
+    st_done++;
+#endif
+    J += nh;
+  }
+#ifdef DSH_LAB
+  if (tid == 0) { atomicAdd((int*)V.sync + 5, st_done); atomicAdd((int*)V.sync + 6, st_skip); atomicAdd((int*)V.sync + 7, (int)st_wait); atomicAdd((int*)V.sync + 8, (int)st_work); }
+#endif
 }
 
 // Back substitution for the wide band: x_J = W_J^T (y_J - sum_{I > J} X(I,J)^T x_I - L_cJ^T x_cam), block columns from the

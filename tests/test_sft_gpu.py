@@ -106,10 +106,11 @@ def test_c5_batch_of_16_equals_singles_bit_for_bit(gpu_ctx):
 
 def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
     """The configuration bench.py reports, checked against the oracle where it runs: the PRODUCT library, >= 1024 C2 problems in one
-    launch (so that the throughput shape is chosen: four wavefronts per problem, at least two problems resident per CU -- asserted through
-    dsh_sft_batch_problem_info), every compute unit loaded with other problems while the sampled ones are solved.  Sampled ids: first,
-    last, middle, and both co-residents of CU pairs; LM trajectory, vertices, pose, outliers against oracle.sft_solve through _compare.
-    The launch is repeated three times and must reproduce itself bit for bit (no race in the hand-overs between the wavefronts)."""
+    batch (so that the throughput shape is chosen: rounds of LIN / FACTOR / TRIAL phase kernels with ONE wavefront per factorisation,
+    four factorisations resident per CU -- asserted through dsh_sft_batch_problem_info: wavefronts per problem == 1), every compute unit
+    loaded with other problems while the sampled ones are solved.  Sampled ids: first, last, middle, and neighbours in the work lists the
+    persistent workgroups pull from; LM trajectory, vertices, pose, outliers against oracle.sft_solve through _compare.  The run is
+    repeated three times and must reproduce itself bit for bit (the order in which the workgroups pull problems varies, the results must not)."""
     from defslam_amd import sft, synth
     B = 1024
     rows, cols, m = synth.CONFIGS["C2"]
@@ -120,7 +121,7 @@ def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
     frames = [sft.frame_from_synth(fr) for fr in syn]
     gpu_ctx.batch_upload(frames, *regs, 1, 50)
     _, counts = gpu_ctx.problem_info(0)
-    assert int(counts[7]) in (1, 4), "a batch of 1024 C2 problems must take the throughput launch shape"
+    assert int(counts[7]) == 1, "a batch of 1024 C2 problems must run as rounds of phase kernels (one wavefront per factorisation)"
     snaps = []
     for _ in range(3):
         gpu_ctx.batch_run()
