@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector == matrix peak
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def kernel_source_hash() -> str:
@@ -167,7 +167,7 @@ def spawn_ranks(n: int, dry: bool = False) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def rank_plan(gpus, dry_ranks, all_on_device, backend, env, device_count):
+def rank_plan(gpus, dry_ranks, all_on_device, backend, env, device_count, shared_camera="auto"):
     """Which device this rank computes on and which collective backend carries the barrier -- from the launcher's environment alone, so that
     the rule is testable without a GPU.  Under the driver's `torch.distributed.run --nproc-per-node N bench.py --gpus N` every rank takes
     device LOCAL_RANK (one process per GPU, RCCL); a rank whose device does not exist, or a WORLD_SIZE that contradicts --gpus, is an error."""
@@ -185,8 +185,11 @@ def rank_plan(gpus, dry_ranks, all_on_device, backend, env, device_count):
             backend = "gloo"      # RCCL: "duplicate GPU detected" for two ranks of one communicator on one device
     elif device_count <= local_rank:
         return {"error": f"rank {rank} needs GPU {local_rank} but the node exposes {device_count}"}
+    # the optional joint-problem leg is a collective of the library's own RCCL communicator: on by default with ONE rank only -- with several, a
+    # collective that has never run on the node must not be able to cost the replica line (asked for explicitly it runs under a watchdog)
+    want_shared = shared_camera == "on" or (shared_camera == "auto" and world == 1)
     return {"rank": rank, "world": world, "device": device, "ranks_per_device": ranks_per_device, "backend": backend,
-            "parallelism": f"{world} x independent problems (no collective)"}
+            "parallelism": f"{world} x independent problems (no collective)", "shared_camera": bool(want_shared and backend == "nccl")}
 
 
 def e2e_legs(ctx, tmpl, m, frames, regs):
@@ -344,7 +347,7 @@ def main():
     import torch
     from defslam_amd import sft, synth
 
-    plan = rank_plan(args.gpus, args.dry_ranks, args.all_ranks_on_device, args.dist_backend, os.environ, torch.cuda.device_count())
+    plan = rank_plan(args.gpus, args.dry_ranks, args.all_ranks_on_device, args.dist_backend, os.environ, torch.cuda.device_count(), args.shared_camera)
     if "error" in plan:
         print("bench.py: " + plan["error"], file=sys.stderr)
         sys.exit(2)
@@ -426,8 +429,7 @@ def main():
     # RCCL all-reduce of the camera block (collective: every rank takes part)
     shared = None
     shared_hung = False
-    want_shared = args.shared_camera == "on" or (args.shared_camera == "auto" and world == 1)
-    if want_shared and not args.no_extra_legs and args.config == "C2" and args.dist_backend == "nccl":
+    if plan["shared_camera"] and not args.no_extra_legs and args.config == "C2":
         # The leg is a collective of the library's own RCCL communicator: with several ranks it runs under a watchdog, so that a rank
         # that fails (or a communicator that cannot be formed on this node) costs this optional object, never the replica line above.
         box = {}
@@ -543,6 +545,25 @@ def main():
         }
         if shared is not None:
             out["shared_camera"] = shared
+        curve = None
+        if not args.no_extra_legs and not shared_hung and int(counts[7]) == 1 and world == 1:
+            # The throughput claim at the batch sizes a multi-template / multi-keyframe user would actually have: the PRODUCT library on prefixes of
+            # the same batch, HIP events on its stream (3 steps after a warm-up step); the rounds per step are added from the lab build below
+            curve = {"what": "product library, prefixes of the benched batch, HIP events on dsh_stream(), 3 timed steps after one warm-up; rounds_per_step = "
+                             "rounds of LIN / FACTOR / TRIAL launches one step takes (from the lab build's per-launch events on the same batches)", "points": []}
+            for Bc in [b for b in (512, 1024, 2048, 4096) if b < args.batch] + [args.batch]:
+                ctx.batch_upload(frames[:Bc], *regs, 1, 50)
+                ctx.batch_run()
+                ctx.synchronize()
+                ms_c = ctx.batch_run_timed(3) / 3
+                it_c, tr_c = ctx.batch_counts()
+                _, cc = ctx.problem_info(0)
+                curve["points"].append({"problems": Bc, "iters_per_s": it_c / (ms_c * 1e-3), "ms_per_step": ms_c, "iters": int(it_c), "trials": int(tr_c),
+                                        "wavefronts_per_problem": int(cc[7]), "rounds_per_step": None})
+            full = curve["points"][-1]["iters_per_s"]
+            for pt in curve["points"]:
+                pt["fraction_of_full_batch_rate"] = pt["iters_per_s"] / full
+            out["batch_curve"] = curve
         if not args.no_extra_legs and not shared_hung:   # (a context stuck in a hung collective cannot run the other legs)
             # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
             ctx.batch_upload(frames[:1], *regs, 1, 50)
@@ -565,6 +586,14 @@ def main():
             ctx.close()
             lab = sft.Context(local_rank, lab=True)
             lab.template_build(tmpl.xyz0, tmpl.facets)
+            if curve is not None:   # rounds per step of the smaller batches of the curve
+                for pt in curve["points"][:-1]:
+                    if pt["wavefronts_per_problem"] != 1:
+                        continue
+                    lab.batch_upload(frames[:pt["problems"]], *regs, 1, 50)
+                    lab.batch_run()
+                    lab.synchronize()
+                    pt["rounds_per_step"] = lab.rounds_timed()[1]
             lab.batch_upload(frames, *regs, 1, 50)
             lab.batch_run()
             lab.synchronize()
@@ -573,6 +602,8 @@ def main():
                 # device code; the product library has no timing entry points).  The dominant kernel is the one-wavefront factorisation
                 # (FP64 roofline); the Jacobian assembly is its own kernel now, so its HBM roofline is a production number.
                 ph, n_rounds = lab.rounds_timed()
+                if curve is not None:
+                    curve["points"][-1]["rounds_per_step"] = n_rounds
                 rf = out["roofline"]
                 tf = flops_per_launch / (ph["factor"] * 1e-3) / 1e12
                 rf.update({"kernel": "sftb_factor_kernel", "kernel_ms": ph["factor"], "achieved": tf, "frac": tf / FP64_PEAK_TFLOPS,

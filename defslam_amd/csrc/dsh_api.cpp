@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,15 @@ extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, si
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
+
+// The dynamic LDS size a kernel has been enabled for (hipFuncSetAttribute) is a property of the (device, kernel) pair, not of a context: two
+// contexts on one GPU -- tracking and mapping, say -- must not lower each other's setting.  One high-water mark per device and kernel for the
+// whole process; the launchers only ever raise it, under this lock.
+struct LdsMarks { size_t lm[2] = {0, 0}, sc = 0, spec = 0, cn = 0, b[2] = {0, 0}; };
+static LdsMarks g_lds_marks[64];
+static std::mutex g_lds_mu;
+#define LDS_MARKS(c) (g_lds_marks[(c)->device & 63])
+#define LDS_LOCK() std::lock_guard<std::mutex> lds_lock__(g_lds_mu)
 extern "C" hipError_t sft_sc_launch(const SftDev* d_probs, SftSc* d_sc, int B, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream_t stream);
 extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phase, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
@@ -122,9 +132,6 @@ struct dsh_ctx : dsh_ctx_base {
   size_t jl_doubles = 0;
   size_t xyz_doubles = 0;   // LDS copy of the node positions in the TRIAL kernel of the phase rounds (largest problem of the batch)
   int nw = 8;        // wavefronts per problem of the persistent kernel (4: two problems share a CU)
-  size_t lds_configured[2] = {0, 0};   // dynamic LDS size the two launch shapes were last enabled for on THIS device
-  size_t lds_configured_sc = 0;        // the same for the phase kernel of the shared-camera mode
-  size_t lds_configured_spec = 0;      // and for the speculative-trial kernel
   // latency mode: K workgroups per problem run the next K damping trials of an iteration side by side (sft_kernels.hip: sft_spec_kernel)
   int spec_k = 1;
   int spec_nh = 0;                     // helper workgroups per part of a two-sided factorisation (FACTOR launches of the latency mode, sft_wide.h)
@@ -138,13 +145,11 @@ struct dsh_ctx : dsh_ctx_base {
   SftSc* d_sc = nullptr;               // shared-camera mode: LM state between the phase kernels
   int force_waves = 0;                 // set while the shared-camera mode packs its problem (always the 8-wavefront shape)
   bool force_split = false;            // set while the connected-mesh mode packs its problem: the two-sided cut with one workgroup (rank) per part
-  size_t lds_configured_cn = 0;
   // throughput shape (sft_batch.h): rounds of LIN / FACTOR / TRIAL launches over the whole batch, one wavefront per factorisation
   bool rounds_mode = false;
   SftRun* d_runs = nullptr;            // B controller states + the done counter behind them, inside d_batch
   int* d_counters = nullptr;
   int* d_linlist = nullptr;            // B ints behind the counters: the problems the next LIN launch linearises (sft_batch.h)
-  size_t lds_configured_b[2] = {0, 0};
   int rounds_hint = 24;                // rounds the previous run of this context needed
   // The batch runs as up to kMaxSub sub-batches on streams of their own: the launches of a round are enqueued sub-batch by sub-batch, so
   // the tail of one sub-batch's FACTOR launch (waves that have run out of work) overlaps with the next launches of the others.
@@ -303,7 +308,16 @@ int pack_problem(dsh_ctx* c, const dsh_sft_frame& f, bool wide_off, Packed& P, s
 // One solve of the uploaded batch.  K == 1: the persistent kernel, one launch, asynchronous.  K > 1 (latency mode): one launch
 // per round of K damping trials; an iteration that accepts one of its first K trials takes one launch, so max_iters + 1 launches
 // finish the typical frame; the done flags are read back behind them and further rounds are launched only while needed.
+int run_rounds_enqueue(dsh_ctx* c);
+// (Blocking: the rounds end with read-backs of the done counters.  On an error every sub-stream is drained before the error is returned, so that
+// what the caller enqueues next on the context's stream cannot race with work left on another one.)
 int run_rounds(dsh_ctx* c) {
+  const int rc = run_rounds_enqueue(c);
+  if (rc != DSH_OK)
+    for (int s = 0; s < c->n_sub; s++) if (c->sub_stream[s]) (void)hipStreamSynchronize(c->sub_stream[s]);
+  return rc;
+}
+int run_rounds_enqueue(dsh_ctx* c) {
   // Throughput shape: every problem of the batch advances by one damping trial per round (LIN for those that start an iteration, FACTOR,
   // TRIAL).  As many rounds as the previous run needed are enqueued in one go, then the done counters are read back and rounds are added
   // in pairs while a problem still runs (a finished problem's workgroups leave at their first instruction).
@@ -313,7 +327,8 @@ int run_rounds(dsh_ctx* c) {
   auto launch = [&](int s, int phase) {
     const bool ev = c->phase_events && S == 1;
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
-    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->xyz_doubles, c->lds_configured_b,
+    LDS_LOCK();
+    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->xyz_doubles, LDS_MARKS(c).b,
                                      c->num_cus, c->sub_stream[s]);
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
     return r;
@@ -349,7 +364,8 @@ int run_rounds(dsh_ctx* c) {
 int run_once(dsh_ctx* c) {
   if (c->rounds_mode) return run_rounds(c);
   if (c->spec_k <= 1) {
-    HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
+    LDS_LOCK();
+    HIPCHK(c, sft_lm_launch(c->d_probs, c->B, c->max_kd, c->jl_doubles, c->nw, LDS_MARKS(c).lm, c->stream));
     return DSH_OK;
   }
   const int K = c->spec_k, B = c->B;
@@ -360,7 +376,7 @@ int run_once(dsh_ctx* c) {
   // launch.  First group: as many rounds as the previous run of this context needed (tracking is coherent from frame to frame:
   // usually exact), then the done flags are read back and rounds of two are added while a problem still runs.  Launches behind the
   // end of a problem cost a few microseconds each (it leaves at the first instruction); a read-back costs a stream synchronisation.
-  auto launch = [&](int phase) { return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->spec_nh, c->max_kd, c->jl_doubles, &c->lds_configured_spec, c->stream); };
+  auto launch = [&](int phase) { LDS_LOCK(); return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->spec_nh, c->max_kd, c->jl_doubles, &LDS_MARKS(c).spec, c->stream); };
   if (c->spec_nh > 0) HIPCHK(c, hipMemsetAsync(c->d_sync, 0, c->sync_bytes, c->stream));   // progress words and column flags of the helper workgroups: epochs count from here
   HIPCHK(c, launch(SFT_SPEC_INIT));
   int rounds = 0, group = std::max(2, std::min(worst, c->spec_hint));
@@ -590,6 +606,13 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   int K = 1;
   if (nw == 8 && !c->force_waves && !c->host_only) {
     K = (4 * B <= c->num_cus) ? 4 : ((2 * B <= c->num_cus) ? 2 : 1);
+    // Wide bands (two-sided factorisation with helper workgroups, sft_wide.h): a part's helpers are worth more than the third and fourth lane when
+    // the device cannot hold both -- two lanes with three helpers per part against four lanes without (C5 x 16: 47.2 against 51.0 ms per step)
+    {
+      bool wide = c->opt.split != 0;
+      for (int b = 0; b < B; b++) wide = wide && c->packed[b].h.kd > kTS * 11;
+      if (wide && K == 4 && (long long)B * 4 * 2 * 3 > c->num_cus && (long long)B * 2 * 2 * 3 <= c->num_cus) K = 2;
+    }
     if (c->opt.speculate >= 1 && c->opt.speculate <= SFT_SPEC_MAXK) K = c->opt.speculate;   // lab builds only
     for (int b = 0; b < B; b++) if (c->packed[b].f.max_iters < 1) K = 1;
   }
@@ -640,7 +663,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     hh.lds_class = (c->rounds_mode && used + need3 <= lds_budget) ? 3 : (used + need2 <= lds_budget) ? 2 : ((used + need1 <= lds_budget) ? 1 : 0);
     used += hh.lds_class == 3 ? need3 : hh.lds_class == 2 ? need2 : (hh.lds_class == 1 ? need1 : 0);
     jl_doubles = std::max(jl_doubles, used);
-    xyz_doubles = std::max(xyz_doubles, ((3 * (size_t)hh.n + 1) & ~(size_t)1));
+    if (hh.lds_class >= 1) xyz_doubles = std::max(xyz_doubles, ((3 * (size_t)hh.n + 1) & ~(size_t)1));   // (sftb_trial_kernel stages the positions of exactly these)
     max_kd = std::max(max_kd, hh.tile_mode == 2 ? std::max(hh.kd, kTS * kBT + 1) : hh.kd);   // (LDS of the wide-tile solver whenever a problem runs on it)
   }
   if (c->host_only) {  // packed on the host only; dsh_sft_batch_problem_info works, running does not
@@ -848,7 +871,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   c->jl_doubles = jl_doubles;
   c->xyz_doubles = xyz_doubles;
   c->nw = nw;
-  return DSH_OK;   // asynchronous: the launch of dsh_sft_batch_run is ordered behind the copy on the same stream
+  return DSH_OK;   // asynchronous: the launch of dsh_sft_batch_run is ordered behind the copy on the same stream (dsh_sft_batch_run itself BLOCKS in the
+                   // latency mode and in the rounds of phase kernels: it reads done flags / counters back between groups of launches)
 }
 
 int dsh_sft_batch_run(dsh_ctx* c) {
@@ -1005,7 +1029,8 @@ int sc_phase(std::vector<ScRank>& R, int phase, std::string& err) {
   for (auto& r : R) {
     dsh_ctx* c = r.c;
     (void)hipSetDevice(c->device);
-    if (sft_sc_launch(c->d_probs, c->d_sc, 1, phase, c->max_kd, c->jl_doubles, &c->lds_configured_sc, c->stream) != hipSuccess) { err = "phase kernel launch failed"; return DSH_ERR_HIP; }
+    LDS_LOCK();
+    if (sft_sc_launch(c->d_probs, c->d_sc, 1, phase, c->max_kd, c->jl_doubles, &LDS_MARKS(c).sc, c->stream) != hipSuccess) { err = "phase kernel launch failed"; return DSH_ERR_HIP; }
   }
   return DSH_OK;
 }
@@ -1180,7 +1205,8 @@ int cn_phase(std::vector<ScRank>& R, int phase, std::string& err) {
   for (auto& r : R) {
     dsh_ctx* c = r.c;
     (void)hipSetDevice(c->device);
-    if (sft_cn_launch(c->d_probs, c->d_sc, phase, c->max_kd, c->jl_doubles, &c->lds_configured_cn, c->stream) != hipSuccess) { err = "phase kernel launch failed"; return DSH_ERR_HIP; }
+    LDS_LOCK();
+    if (sft_cn_launch(c->d_probs, c->d_sc, phase, c->max_kd, c->jl_doubles, &LDS_MARKS(c).cn, c->stream) != hipSuccess) { err = "phase kernel launch failed"; return DSH_ERR_HIP; }
   }
   return DSH_OK;
 }
@@ -1467,7 +1493,7 @@ int dsh_lab_sft_system(dsh_ctx* c, int b, int32_t D, double* H, double* bvec, do
   h.mode = 1;
   h.split = 0;   // the one-workgroup kernel assembles into the undivided band matrix
   HIPCHK(c, hipMemcpy(c->d_probs + b, &h, sizeof(SftDev), hipMemcpyHostToDevice));
-  HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, c->lds_configured, c->stream));
+  { LDS_LOCK(); HIPCHK(c, sft_lm_launch(c->d_probs + b, 1, c->max_kd, c->jl_doubles, c->nw, LDS_MARKS(c).lm, c->stream)); }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ran = false;   // the state of problem b was reset: a download would not return the results of the last run
   h.mode = mode_saved;

@@ -3309,8 +3309,9 @@ extern "C" hipError_t sft_sc_local_reduce(SftSc* const* d_ptrs, int G, hipStream
   return hipGetLastError();
 }
 
-// `configured` (two slots, owned by the calling context, i.e. per device): the dynamic LDS size the two kernels were last
-// enabled for on that device -- the function attribute is per device, a process-wide cache would skip the second GPU.
+// `configured` (two slots of the caller's per-DEVICE table, dsh_api.cpp: LdsMarks): the largest dynamic LDS size the two kernels have been
+// enabled for on that device by anybody in this process -- the function attribute belongs to (device, kernel): it is only ever raised,
+// under the caller's lock, so that two contexts on one GPU cannot lower each other's setting.
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream) {
   const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
   const int slot = nw == 4 ? 0 : 1;
@@ -3341,8 +3342,8 @@ extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int whic
 }
 #endif
 
-// Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the calling context): the dynamic LDS sizes the
-// LIN and TRIAL kernels were last enabled for on that device.
+// Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the per-device table): the largest dynamic LDS
+// sizes the LIN and TRIAL kernels have been enabled for on that device (see sft_lm_launch).
 extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream) {
   const size_t head = 512 + (16 * 27 + 5 + 32) * sizeof(double) + 64;
   if (phase == SFTB_PH_INIT) {

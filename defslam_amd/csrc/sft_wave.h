@@ -256,7 +256,7 @@ __device__ __forceinline__ v4d wv_gather_vgpr(const WvProb& W, const unsigned (&
 // border tile Bd(J)^T from the 8-row border of H (rows 0-5 camera, 6 right-hand side, 7 zero): lane (g, c), register q = Hbord[c][16 J + g + 4q]
 __device__ __forceinline__ v4d wv_border_fresh(const WvProb& W, int J, int lane) {
   v4d v;
-  const SFT_G double* p = W.Hbord + TS * (J < W.nT ? J : W.nT);   // (behind the matrix: the zero padding of the border rows; lanes c >= 8 mirror c - 8)
+  const SFT_G double* p = W.Hbord + TS * (J < W.nT ? J : W.nT);   // (behind the matrix, J >= nT: the row pitch is Dnp, so what is read there is finite data of the NEXT border row -- never consumed: those ring slots are never a pivot column and their Y operands are zero; lanes c >= 8 mirror c - 8)
 #pragma unroll
   for (int q = 0; q < 4; q++) v[q] = p[W.bofs + 4 * q];
   return v;

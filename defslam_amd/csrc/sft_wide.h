@@ -514,6 +514,48 @@ __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int 
 //     diagonal tile of column J+1, factors it and publishes W_{J+1} while the other waves finish column J -- so a column is products, TRSM and
 //     ONE barrier, and nobody waits for a Cholesky.
 // LDS: 8 x NEAR + NEAR staged tiles, two W, the corner partials.
+// The rare paths of factor_part, out of line (their per-lane address arithmetic would otherwise be hoisted out of the column loop and held --
+// or spilled -- across it): a separator column's tiles into the exchange buffer, the border tile gathered from H's border rows.
+__device__ __noinline__ void wide_schur_store_of(const SftDev& P, int which, int I, int J, v4d t) {
+  const WideView V = wide_view(P, which);
+  const int lane = threadIdx.x & 63, crow = lane >> 4, ccol = lane & 15;
+  const int Ir = I - V.nS, Jr = J - V.nS;
+  if (!V.reversed) {
+    *reinterpret_cast<SFT_G v4d*>(V.xchg + wtile_off(V.xr_tpr, Ir, Ir - Jr) + 4 * lane) = t;
+    return;
+  }
+  // t[q] = T[b][a] with a = crow + 4 q (column index inside tile J), b = ccol (row index inside tile I); part 1 runs in reversed order
+  const int It = V.xr_nT - 1 - Jr, Jt = V.xr_nT - 1 - Ir;          // natural tile (It, Jt), It >= Jt
+  const auto dst = V.xchg + wtile_off(V.xr_tpr, It, It - Jt);
+#pragma unroll
+  for (int q = 0; q < 4; q++) dst[tile_elem(15 - ccol, 15 - (crow + 4 * q))] = t[q];
+}
+__device__ __noinline__ void wide_schur_border_of(const SftDev& P, int which, int J, v4d t) {
+  const WideView V = wide_view(P, which);
+  const int lane = threadIdx.x & 63, crow = lane >> 4, ccol = lane & 15;
+  if (ccol >= SFT_BORDER) return;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int jl = TS * (J - V.nS) + crow + 4 * q;                    // column inside the separator block, this part's order
+    V.xchg[(size_t)V.xr_nT * V.xr_tpr * (TS * TS) + (size_t)ccol * (TS * V.xr_nT) + (V.reversed ? TS * V.xr_nT - 1 - jl : jl)] = t[q];
+  }
+}
+__device__ __noinline__ v4d wide_bord_tile_of(const SftDev& P, int which, int J) {
+  const WideView V = wide_view(P, which);
+  const int lane = threadIdx.x & 63, crow = lane >> 4, ccol = lane & 15;
+  v4d h = {0.0, 0.0, 0.0, 0.0};
+  if (ccol < SFT_BORDER) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = TS * J + crow + 4 * q;
+      const bool in = j >= V.b_lo && j < V.b_hi;
+      const double v = V.Hbord[(size_t)ccol * V.bstride + V.b_base + V.b_sign * (in ? j : V.b_lo)];
+      h[q] = in ? v : 0.0;
+    }
+  }
+  return h;
+}
+
 // One tile, global memory -> LDS without passing registers (LDS-DMA): two requests of 64 x 16 bytes; the lane's 32 bytes of the tile land as the
 // two planes wide_lds_read expects.  Not known to the compiler's wait counters: whoever reads the tile waits for vmcnt itself.
 template <bool AGENT>
@@ -562,30 +604,8 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
   auto toff = [&](int I, int dd) -> unsigned { return (unsigned)(((unsigned)I * (unsigned)tpr + (unsigned)dd) * (TS * TS * 8u)); };
   const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
   auto ksplit = [&](int J) -> int { return min(nS, max(0, J - NEAR)); };
-  auto bord_h = [&](int row, int j) -> double {
-    const int jj = (j >= V.b_lo && j < V.b_hi) ? j : V.b_lo;
-    const double v = Hbord[(size_t)row * V.bstride + V.b_base + V.b_sign * jj];
-    return (j >= V.b_lo && j < V.b_hi) ? v : 0.0;
-  };
-  auto bord_tile = [&](int J) -> v4d {
-    v4d h = zero4;
-    if (ccol < SFT_BORDER) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) h[q] = bord_h(ccol, TS * J + crow + 4 * q);
-    }
-    return h;
-  };
-  auto schur_store = [&](int I, int J, const v4d& t) {
-    const int Ir = I - nS, Jr = J - nS;
-    if (!V.reversed) {
-      *reinterpret_cast<SFT_G v4d*>(V.xchg + wtile_off(V.xr_tpr, Ir, Ir - Jr) + 4 * lane) = t;
-      return;
-    }
-    const int It = V.xr_nT - 1 - Jr, Jt = V.xr_nT - 1 - Ir;
-    const auto dst = V.xchg + wtile_off(V.xr_tpr, It, It - Jt);
-#pragma unroll
-    for (int q = 0; q < 4; q++) dst[tile_elem(15 - ccol, 15 - (crow + 4 * q))] = t[q];
-  };
+  auto bord_tile = [&](int J) -> v4d { return wide_bord_tile_of(P, which, J); };
+  auto schur_store = [&](int I, int J, const v4d& t) { wide_schur_store_of(P, which, I, J, t); };
   // The tile a row starts a column from -- H(I,J)^T - far(I,J) as a helper (or the fallback below) left it, or H(I,J)^T where no far product
   // exists -- is requested into the wave's landing slot a column ahead
   auto request_tile = [&](int slot, int I, int J) {
@@ -671,7 +691,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
   request_tile(1, wave + 8, 0);
   if (wave == 0) request_tile(2, 16, 0);
   if (wave == 7) request_border(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) -- as a builtin: the compiler's own wait counters take note */
   if (wave == 0) pivot(0, wide_lds_read(myland, lane));
   __syncthreads();
 
@@ -751,7 +771,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
         // the pivot chain of column J+1: start tile - the squares of the row's ring (block columns <= J-1: summed a column ago), then - the
         // square of the tile that has just left the TRSM
         const int Ip = J + 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the diagonal tile has landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) -- as a builtin: the compiler's own wait counters take note */      // the diagonal tile has landed
         v4d dt = wide_lds_read(myland + 3 * TS * TS, lane);
         dt = dt - preS;
         if (elim) {
@@ -798,12 +818,8 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
         }
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xbT[kk], -xbT[kk], cacc, 0, 0, 0);
-      } else if (ccol < SFT_BORDER) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int jl = TS * (J - nS) + crow + 4 * q;
-          V.xchg[(size_t)V.xr_nT * V.xr_tpr * (TS * TS) + (size_t)ccol * (TS * V.xr_nT) + (V.reversed ? TS * V.xr_nT - 1 - jl : jl)] = curB[q];
-        }
+      } else {
+        wide_schur_border_of(P, which, J, curB);
       }
     }
     WT_SEG(3);
@@ -842,7 +858,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
     WT_SEG(4);
     look_for_helper(J);
     WT_SEG(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this column's stores have arrived (a helper may read them), the next column's tiles have landed
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) -- as a builtin: the compiler's own wait counters take note */     // this column's stores have arrived (a helper may read them), the next column's tiles have landed
     WT_SEG(6);
     __syncthreads();
     WT_SEG(7);
@@ -881,26 +897,34 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
 // column, the diagonal tile and the border -- one or two of them per wave, dealt by their number of products.  What is stored (agent scope)
 // is the tile the owner starts the column from: H(I,J)^T - far(I,J).  Every tile of a wave's item is requested before the first product.
 __device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_double* rowJ) {
+  constexpr int MAXN = WB - SFT_WIDE_NEAR;              // most far products of a tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nT = V.nT, nS = V.nS, tpr = V.tpr, wb = V.wb;
   const int Ks = min(nS, J - SFT_WIDE_NEAR), K0d = max(0, J - wb);
   if (Ks <= K0d) return;
-  const __amdgpu_buffer_rsrc_t rLt = wide_rsrc(V.Lt);
+  const __amdgpu_buffer_rsrc_t rLt = wide_rsrc(V.Lt), rLbT = wide_rsrc(V.LbT);
   const unsigned lane32 = 32u * lane;
   const int crow = lane >> 4, ccol = lane & 15;
-  const long kstride = (long)(tpr - 1) * TS * TS;
-  for (int s = wave; s < Ks - K0d; s += 8) {
-    const int K = K0d + s;
-    wide_lds_write(rowJ + (size_t)(J - K - 1) * TS * TS, lane, tile_ld_rsrc(rLt, lane32, (unsigned)(wtile_off(tpr, K, J - K) * 8)));
-  }
-  lds_barrier();
-  // items by falling number of products: 0 border, 1 diagonal tile, i >= 2 row J + i - 1; wave w takes items w and 15 - w
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    const int item = pass == 0 ? wave : 15 - wave;
+  const unsigned ks8 = (unsigned)(tpr - 1) * (TS * TS * 8u);
+  // items by falling number of products: 0 border, 1 diagonal tile, i >= 2 row J + i - 1; wave w takes items w and 15 - w.  Every operand
+  // tile of an item is requested before its first product (the latency of one request, not of a chain of them, is what an item costs).
+  v4d bt[MAXN], h;
+  int n = 0, K0 = 0;
+  bool sq = false;
+  auto request = [&](int item) {
+    n = 0; sq = item == 1;
+    const int I = item <= 1 ? J : J + item - 1;
+    if (I >= nT || I - J > wb) return;
+    K0 = item == 0 ? K0d : max(0, I - wb);
+    n = Ks - K0;
+    if (n <= 0) { n = 0; return; }
+    const __amdgpu_buffer_rsrc_t r = item == 0 ? rLbT : rLt;
+    const unsigned b0 = item == 0 ? (unsigned)K0 * (TS * TS * 8u) : (unsigned)(wtile_off(tpr, K0, I - K0) * 8), bs = item == 0 ? (TS * TS * 8u) : ks8;
+#pragma unroll
+    for (int i = 0; i < MAXN; i++) bt[i] = tile_ld_rsrc(r, lane32, b0 + (unsigned)min(i, n - 1) * bs);
     if (item == 0) {
-      v4d h = {0.0, 0.0, 0.0, 0.0};
+      h = (v4d){0.0, 0.0, 0.0, 0.0};
       if (ccol < SFT_BORDER) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -910,24 +934,29 @@ __device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_do
           h[q] = in ? v : 0.0;
         }
       }
-      const SFT_G double* brow = V.LbT + (size_t)K0d * TS * TS + 4 * lane;
-      const v4d far = wide_products(lane, J, K0d, Ks, rowJ, [=](int i) -> v4d { return tile_ld_agent(brow + (long)i * (TS * TS)); });
-      tile_st_agent(V.PfB + (size_t)J * TS * TS + 4 * lane, h - far);
-    } else if (item == 1) {
-      const v4d h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(tpr, J, 0) + 4 * lane);
-      const unsigned b0 = (unsigned)(wtile_off(tpr, K0d, J - K0d) * 8), bs = (unsigned)(kstride * 8);
-      const v4d far = wide_squares(Ks - K0d, [=](int i) -> v4d { return tile_ld_rsrc(rLt, lane32, b0 + (unsigned)i * bs); });
-      tile_st_agent(V.Pf + wtile_off(tpr, J, 0) + 4 * lane, h - far);
     } else {
-      const int I = J + item - 1, K0 = max(0, I - wb);
-      if (I < nT && I - J <= wb && Ks > K0) {
-        const v4d h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(tpr, I, I - J) + 4 * lane);
-        const unsigned b0 = (unsigned)(wtile_off(tpr, K0, I - K0) * 8), bs = (unsigned)(kstride * 8);
-        const v4d far = wide_products(lane, J, K0, Ks, rowJ, [=](int i) -> v4d { return tile_ld_rsrc(rLt, lane32, b0 + (unsigned)i * bs); });
-        tile_st_agent(V.Pf + wtile_off(tpr, J, I - J) + 4 * lane, h - far);
-      }
+      h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(tpr, I, I - J) + 4 * lane);
     }
+  };
+  auto finish = [&](int item) {
+    if (n <= 0) return;
+    v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < MAXN; i++)
+      if (i < n) wide_mfma4(sq ? bt[i] : wide_lds_read(rowJ + (size_t)(J - (K0 + i) - 1) * TS * TS, lane), bt[i], s0, s1);
+    const v4d t = h - (s0 + s1);
+    if (item == 0) tile_st_agent(V.PfB + (size_t)J * TS * TS + 4 * lane, t);
+    else tile_st_agent(V.Pf + wtile_off(tpr, J, item == 1 ? 0 : item - 1) + 4 * lane, t);
+  };
+  request(wave);
+  for (int s = wave; s < Ks - K0d; s += 8) {
+    const int K = K0d + s;
+    wide_lds_write(rowJ + (size_t)(J - K - 1) * TS * TS, lane, tile_ld_rsrc(rLt, lane32, (unsigned)(wtile_off(tpr, K, J - K) * 8)));
   }
+  lds_barrier();
+  finish(wave);
+  request(15 - wave);
+  finish(15 - wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                        // every wave's tiles have arrived
 }

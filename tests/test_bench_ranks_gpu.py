@@ -81,6 +81,29 @@ def test_dry_ranks_8_is_the_eight_rank_launch_on_the_devices_that_exist():
     assert abs(frames - 8 * 64) < 1e-6 * 512
 
 
+@pytest.mark.gpu
+def test_dry_ranks_8_of_the_stress_config_two_problems_per_rank():
+    """BASELINE configs[4] as the driver would launch it on an 8-GPU node: 16 C5 problems (2000 nodes, 4000 matches) round-robin on eight ranks =
+    two per rank, i.e. the latency shape (speculative lanes, two-sided factorisation with helper workgroups) on every rank.  One JSON line, eight
+    per-rank step times, the optional collective leg off."""
+    import torch
+    ndev = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C5", "--dry-ranks", "8", "--steps", "1", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--no-extra-legs"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["ranks"] == 8 and d["config"]["dry_ranks"] is True and d["config"]["problems_per_gpu"] == 2
+    assert d["config"]["workload"].startswith("C5")
+    assert d["n_gpus"] == min(8, ndev)
+    assert len(d["rank_ms_per_step"]) == 8 and all(v > 0 for v in d["rank_ms_per_step"])
+    assert "shared_camera" not in d
+    frames = d["frames_per_s"] * d["ms_per_step"] * 1e-3
+    assert abs(frames - 16) < 1e-6 * 16
+    assert 8.0 < d["iters_per_frame"] < 16.0
+
+
 def _bench_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
@@ -110,3 +133,18 @@ def test_rank_plan_under_the_drivers_launcher_one_gpu_per_rank():
     # single process
     p = b.rank_plan(1, 0, -1, "nccl", {}, 1)
     assert p["device"] == 0 and p["world"] == 1
+
+
+def test_rank_plan_keeps_the_shared_camera_leg_off_with_several_ranks():
+    """The optional joint-problem leg (a collective of the library's own RCCL communicator) runs by default with ONE rank only: the first
+    multi-GPU launch must not depend on a collective that has never run on that node.  `--shared-camera on` asks for it explicitly; without
+    RCCL (the gloo rehearsal) it cannot run at all."""
+    b = _bench_module()
+    assert b.rank_plan(1, 0, -1, "nccl", {}, 1)["shared_camera"] is True
+    for n in (2, 4, 8):
+        env = {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": str(n)}
+        assert b.rank_plan(n, 0, -1, "nccl", env, 8)["shared_camera"] is False                 # auto
+        assert b.rank_plan(n, 0, -1, "nccl", env, 8, "off")["shared_camera"] is False
+        assert b.rank_plan(n, 0, -1, "nccl", env, 8, "on")["shared_camera"] is True            # asked for
+        assert b.rank_plan(n, n, -1, "nccl", env, 1, "on")["shared_camera"] is False           # rehearsal on one device: gloo
+    assert b.rank_plan(1, 0, -1, "nccl", {}, 1, "off")["shared_camera"] is False

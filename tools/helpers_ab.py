@@ -23,6 +23,11 @@ if "--batch" in args:
     i = args.index("--batch")
     batch = int(args[i + 1])
     del args[i:i + 2]
+spec = 0
+if "--speculate" in args:   # lanes per problem (0: automatic)
+    i = args.index("--speculate")
+    spec = int(args[i + 1])
+    del args[i:i + 2]
 cfgs = args or ["C5", "C2"]
 ctx = sft.Context(0, lab=True)
 for cfg in cfgs:
@@ -32,6 +37,7 @@ for cfg in cfgs:
     ref = None
     for nh in (0, -1, 1, 2, 3):
         ctx.set_option("helpers", nh)
+        ctx.set_option("speculate", spec)
         fs = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(batch)]
         ctx.batch_upload(fs, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
         ctx.batch_run()
