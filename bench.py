@@ -235,17 +235,32 @@ def e2e_legs(ctx, tmpl, m, frames, regs):
     # frame a keyframe whose mapping work (Schwarp initialisation + search + fit, normals, Shape-from-Normals, registration, new template +
     # embedding) runs between two frames; the frame after it is solved on the new template with RegTemp = 0 (DefTracking.cc:109-115)
     from defslam_amd import seqmap
-    seq = synth.make_interleaved_sequence(**synth.SEQMAP)
-    seqmap.run(ctx, seq)                                    # warm-up (graph cache, scratch)
-    st = seqmap.run(ctx, seq)
-    tot = st["t_track"] + st["t_map"]
-    out["seq_mapping"] = {"frames": st["frames"], "keyframes": st["keyframes"], "templates": st["templates"], "frames_e2e_per_s": st["frames"] / tot,
-                          "ms_tracking_per_frame": 1e3 * st["t_track"] / st["frames"], "ms_mapping_per_keyframe": 1e3 * st["t_map"] / max(st["keyframes"], 1),
-                          "iters_per_frame": st["iters"] / st["frames"], "min_inlier_fraction": float(min(st["inliers"])),
-                          "switch_frames": len(st["switch_frames"]), "solves": st["frames"] + len(st["switch_frames"]),
-                          "what": "synth.SEQMAP: wall clock inside the C-ABI calls of defslam_amd/seqmap.py (tracking every frame, the whole mapping chain every "
-                                  "10th frame, template switch on the next one -- that frame is solved twice like DefTracking.cc:109-123 + :244-247: RegTemp = 0 first, then the regular solve without the observations the first one flagged); synthetic data generation excluded; tests/test_seqmap_gpu.py checks every stage "
-                                  "of this loop against its oracle"}
+    def seq_leg(cfg, what):
+        seq = synth.make_interleaved_sequence(**cfg)
+        legs = {}
+        for route in ("device", "host"):
+            seqmap.run(ctx, seq, route=route)                   # warm-up (graph cache, scratch)
+            st = seqmap.run(ctx, seq, route=route)
+            tot = st["t_track"] + st["t_map"]
+            legs[route] = {"frames_e2e_per_s": st["frames"] / tot, "ms_tracking_per_frame": 1e3 * st["t_track"] / st["frames"],
+                           "ms_mapping_per_keyframe": 1e3 * st["t_map"] / max(st["keyframes"], 1), "iters_per_frame": st["iters"] / st["frames"],
+                           "min_inlier_fraction": float(min(st["inliers"])), "frames": st["frames"], "keyframes": st["keyframes"], "templates": st["templates"],
+                           "switch_frames": len(st["switch_frames"]), "solves": st["frames"] + len(st["switch_frames"]), "db_records": st.get("db_records")}
+        r = dict(legs["device"])
+        r["route"] = "device: DiffProp records resident in HBM (dsh_schwarp_fit_batch_store -> dsh_normals_estimate_db -> dsh_sfn_estimate_db)"
+        r["host_record_route"] = legs["host"]
+        r["template_nodes"] = int(cfg["mesh"][0] * cfg["mesh"][1])
+        r["what"] = what
+        return r
+
+    out["seq_mapping"] = seq_leg(dict(synth.SEQMAP),
+                                 "synth.SEQMAP: wall clock inside the C-ABI calls of defslam_amd/seqmap.py (tracking every frame, the whole mapping chain every "
+                                 "10th frame, template switch on the next one -- that frame is solved twice like DefTracking.cc:109-123 + :244-247: RegTemp = 0 first, then the "
+                                 "regular solve without the observations the first one flagged); synthetic data generation excluded; tests/test_seqmap_gpu.py checks every "
+                                 "stage of this loop against its oracle and the two record routes against each other (bit-identical)")
+    c2 = dict(synth.SEQMAP)
+    c2["mesh"] = (20, 25)
+    out["seq_mapping_c2_template"] = seq_leg(c2, "the same sequence on the 500-node template of BASELINE configs[1] (20 x 25 grid)")
     return out
 
 

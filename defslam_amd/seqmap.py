@@ -12,6 +12,13 @@ updateTemplate, DefLocalMapping.cc:115-234), with every numeric stage on the GPU
 
 `hooks` (optional) is called with the inputs and outputs of every stage -- tests/test_seqmap_gpu.py passes a checker that runs the
 oracle of the stage on the same inputs; bench.py passes nothing and times the loop.
+
+Two routes for the DiffProp records between the mapping stages (`route`):
+    "host"    the host-buffer calls: the fit returns the records, the host keeps them per map point like WarpDatabase::mapPointsDB_
+              (WarpDatabase.h:61) and hands them to the normal solve, whose normals it hands to Shape-from-Normals;
+    "device"  the records stay in HBM (dsh_diffdb): dsh_schwarp_fit_batch_store -> dsh_normals_estimate_db -> dsh_sfn_estimate_db; what comes
+              back are the drop flags of a fit, the per-point normals / status of the solve and the surface -- no DiffProp record crosses PCIe.
+The two routes give bit-identical results (tests/test_seqmap_gpu.py runs both).
 """
 from __future__ import annotations
 
@@ -27,9 +34,13 @@ class _NoHooks:
         return lambda *a, **k: None
 
 
-def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-3, chi_limit=0.2):
-    """Runs the whole sequence.  Returns a dict of counters and timings (seconds of host wall clock inside the C-ABI calls)."""
+def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-3, chi_limit=0.2, route="host", record=None):
+    """Runs the whole sequence.  Returns a dict of counters and timings (seconds of host wall clock inside the C-ABI calls).
+    record (optional list): every stage output that the next stage or the result depends on is appended to it (the route comparison)."""
+    assert route in ("host", "device")
+    dev = route == "device"
     hooks = hooks or _NoHooks()
+    rec_out = record.append if record is not None else (lambda *a: None)
     regs = regs or (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     P, nt = seq["kp0"].shape[0], seq["n_tracked"]
     b2, b1 = nrsfm.Bbs(*seq["bbs2"]), nrsfm.Bbs(*seq["bbs1"])
@@ -50,6 +61,8 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
     T = seq["frames"][0]["Tcw_gt"].astype(np.float32)
     x = nodes_rest.copy()
     recs_per_point = [[] for _ in range(P)]
+    n_recs = np.zeros(P, np.int64)                                         # records per map point (device route: the records themselves are in HBM)
+    db = nrsfm.DiffDatabase(ctx, (len(seq["kfs"]) + 1) * P) if dev else None
     prev_normal = np.zeros((P, 2), np.float32)
     has_prev = np.zeros(P, np.uint8)
     mean_depth = float(seq["depth"].mean())
@@ -75,14 +88,24 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         kp2_pix = kfd["pix"][np.r_[kfd["index_of_point"][:nt], mg[found]]]
         kp2n = ((kp2_pix - cam[2:]) / cam[:2]).astype(np.float32)
         fit_args = (seq["kp0"][sel], kp2n, seq["invsig"][sel], fy, fx, lam_fit, fx, fy, x0, 3)
-        t0 = time.perf_counter()
-        xg, dg, drop, info, costs = nrsfm.calculateSchwarps(ctx, b2, *fit_args)
-        dt += time.perf_counter() - t0
+        if dev:
+            idx2 = np.r_[kfd["index_of_point"][:nt], mg[found]].astype(np.int32)
+            prob = dict(bbs=b2, kp1=fit_args[0], kp2=kp2n, invsig=fit_args[2], fx_slot=fy, fy_slot=fx, lam=lam_fit, fx=fx, fy=fy, x0=x0, max_iters=3,
+                        point_id=sel.astype(np.int32), idx2=idx2, tag=stats["schwarp_fits"])
+            t0 = time.perf_counter()
+            (xg, dg, drop, info, costs), = nrsfm.calculateSchwarpsBatch(ctx, [prob], db=db, want_records=False)
+            dt += time.perf_counter() - t0
+        else:
+            t0 = time.perf_counter()
+            xg, dg, drop, info, costs = nrsfm.calculateSchwarps(ctx, b2, *fit_args)
+            dt += time.perf_counter() - t0
+            hooks.schwarp(key, fit_args, xg, dg, drop, info, costs)
+            for j, p in enumerate(sel):
+                if not drop[j]:
+                    recs_per_point[p].append(dg[j])
         stats["schwarp_fits"] += 1
-        hooks.schwarp(key, fit_args, xg, dg, drop, info, costs)
-        for j, p in enumerate(sel):
-            if not drop[j]:
-                recs_per_point[p].append(dg[j])
+        n_recs[sel[~np.asarray(drop, bool)]] += 1
+        rec_out(("fit", key, xg.copy(), np.asarray(drop).copy(), info.copy(), costs.copy()))
         return dt
 
     stats = dict(frames=0, keyframes=0, templates=1, iters=0, trials=0, inliers=[], switch_frames=[], switch_solves=0, switch_dropped=0, schwarp_fits=0, normals=0)
@@ -129,6 +152,7 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         stats["trials"] += f.trials
         stats["inliers"].append(inl / max(int(inside.sum()), 1))
         T, x = f.Tcw.copy(), f.nodes_xyz.copy()
+        rec_out(("frame", k, T.copy(), x.copy(), int(inl), int(f.iters), int(f.trials), f.mvbOutlier.copy()))
         if k not in seq["kfs"]:
             continue
         # ---- mapping: frame k is a keyframe (every 10th frame, DefTracking.cc:175)
@@ -136,16 +160,22 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         stats["keyframes"] += 1
         t_map += add_keyframe(k)
         # NormalEstimator::ObtainK1K2 over every point with records (reference keyframe = the anchor), previous normals as start values
-        pts = [p for p in range(P) if recs_per_point[p]]
-        rec_ptr = np.r_[0, np.cumsum([len(recs_per_point[p]) for p in pts])].astype(np.int32)
-        recs = np.concatenate([np.stack(recs_per_point[p]) for p in pts]).astype(np.float32)
-        R = recs.shape[0]
-        nargs = (rec_ptr, recs, np.ones(R, np.uint8), np.zeros((R, 2), np.float32), np.zeros(R, np.uint8), prev_normal[pts].copy(), has_prev[pts].copy(), seq["kp0"][pts])
-        t0 = time.perf_counter()
-        ng = nrsfm.ObtainK1K2(ctx, *nargs)
-        t_map += time.perf_counter() - t0
+        pts = [p for p in range(P) if n_recs[p]]
+        if dev:
+            t0 = time.perf_counter()
+            ng = nrsfm.ObtainK1K2Database(ctx, db, np.asarray(pts, np.int32), prev_normal[pts].copy(), has_prev[pts].copy(), seq["kp0"][pts], per_record=False)
+            t_map += time.perf_counter() - t0
+        else:
+            rec_ptr = np.r_[0, np.cumsum([len(recs_per_point[p]) for p in pts])].astype(np.int32)
+            recs = np.concatenate([np.stack(recs_per_point[p]) for p in pts]).astype(np.float32)
+            R = recs.shape[0]
+            nargs = (rec_ptr, recs, np.ones(R, np.uint8), np.zeros((R, 2), np.float32), np.zeros(R, np.uint8), prev_normal[pts].copy(), has_prev[pts].copy(), seq["kp0"][pts])
+            t0 = time.perf_counter()
+            ng = nrsfm.ObtainK1K2(ctx, *nargs)
+            t_map += time.perf_counter() - t0
+            hooks.normals(k, nargs, ng)
         stats["normals"] += len(pts)
-        hooks.normals(k, nargs, ng)
+        rec_out(("normals", k, ng.k1k2.copy(), ng.status.copy(), ng.normal_ref.copy(), ng.iters.copy()))
         okn = ng.status == 0
         pts = np.asarray(pts)
         prev_normal[pts[okn]] = ng.normal_ref[okn][:, :2]
@@ -154,9 +184,14 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         un, vn = seq["kp0"][pts[okn], 0].astype(float), seq["kp0"][pts[okn], 1].astype(float)
         sargs = (un, vn, ng.normal_ref[okn], bending, mean_depth, seq["kp0"][:, 0].astype(float), seq["kp0"][:, 1].astype(float))
         t0 = time.perf_counter()
-        ok_sfn, raw, ctrl, surf = nrsfm.ShapeFromNormals(ctx, b1, *sargs)
+        if dev:   # the normals are picked on the device from the solve above (sel = index of the requested point)
+            ok_sfn, raw, ctrl, surf = nrsfm.ShapeFromNormalsDatabase(ctx, b1, db, np.flatnonzero(okn), sargs[0], sargs[1], *sargs[3:])
+        else:
+            ok_sfn, raw, ctrl, surf = nrsfm.ShapeFromNormals(ctx, b1, *sargs)
         t_map += time.perf_counter() - t0
-        hooks.sfn(k, sargs, ok_sfn, raw, ctrl, surf)
+        if not dev:
+            hooks.sfn(k, sargs, ok_sfn, raw, ctrl, surf)
+        rec_out(("sfn", k, ok_sfn, raw.copy(), ctrl.copy(), surf.copy()))
         if not ok_sfn:
             continue
         Twc = seq["Twc"].astype(np.float64)
@@ -168,6 +203,7 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         rg = register.registerSurfaces(ctx, surf_w[both], map_pts[both], kf["u_stream"], seq["Twc"], chi_limit=chi_limit)
         t_map += time.perf_counter() - t0
         hooks.registration(k, surf_w[both], map_pts[both], kf["u_stream"], seq["Twc"], chi_limit, rg)
+        rec_out(("registration", k, {kk: (np.array(vv).copy() if isinstance(vv, np.ndarray) else vv) for kk, vv in rg.items()}))
         if not rg["registered"]:
             continue
         # createTemplate (DefMap.cc:55-64): the registered surface sampled on the regular grid, map points embedded again
@@ -187,5 +223,8 @@ def run(ctx, seq, regs=None, hooks=None, lam_init=1e-2, lam_fit=0.1, bending=1e-
         x = nodes_rest.copy()                                              # the new template starts at its rest shape, the camera where tracking left it
         stats["templates"] += 1
         switch = True
-    stats["t_track"], stats["t_map"] = t_track, t_map
+    if db is not None:
+        stats["db_records"] = len(db)
+        db.close()
+    stats["t_track"], stats["t_map"], stats["route"] = t_track, t_map, route
     return stats

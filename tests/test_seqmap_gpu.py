@@ -123,3 +123,42 @@ def test_tracking_and_mapping_interleaved_in_one_sequence_against_the_oracles(gp
     assert c["tracking_switch"] == 2 * len(st["switch_frames"]) and c["tracking_switch_second"] == len(st["switch_frames"]) and c["tracking"] >= 2 * n_kf
     assert min(st["inliers"]) > 0.9                                         # tracking holds through every template switch
     assert st["iters"] / st["frames"] < 12
+
+
+def _same(a, b, what):
+    if isinstance(a, dict):
+        assert a.keys() == b.keys(), what
+        for k in a:
+            _same(a[k], b[k], f"{what}.{k}")
+    elif isinstance(a, np.ndarray):
+        np.testing.assert_array_equal(a, b, err_msg=what)
+    elif isinstance(a, (tuple, list)):
+        assert len(a) == len(b), what
+        for i, (u, v) in enumerate(zip(a, b)):
+            _same(u, v, f"{what}[{i}]")
+    else:
+        assert a == b, what
+
+
+@pytest.mark.parametrize("mesh", [None, (20, 25)])
+def test_device_resident_record_chain_gives_the_sequence_of_the_host_record_route_bit_for_bit(gpu_ctx, mesh):
+    """The same sequence twice: DiffProp records handed from stage to stage through host buffers (what the oracle hooks above check), and
+    resident in HBM (dsh_schwarp_fit_batch_store -> dsh_normals_estimate_db -> dsh_sfn_estimate_db).  Every stage output either route produces --
+    warp fits, drop flags, normals, status, surfaces, registrations, and every tracked frame's pose, vertices, inliers, iterations, outlier
+    flags -- must be the same bits; also on the 500-node template of BASELINE configs[1] (20 x 25)."""
+    from defslam_amd import seqmap, synth
+    cfg = dict(synth.SEQMAP)
+    if mesh is not None:
+        cfg["mesh"] = mesh
+    seq = synth.make_interleaved_sequence(**cfg)
+    rec_h, rec_d = [], []
+    st_h = seqmap.run(gpu_ctx, seq, route="host", record=rec_h)
+    st_d = seqmap.run(gpu_ctx, seq, route="device", record=rec_d)
+    assert st_d["route"] == "device" and st_d["db_records"] > 0
+    assert len(rec_h) == len(rec_d) and len(rec_h) > seq["n_frames"]
+    for i, (a, b) in enumerate(zip(rec_h, rec_d)):
+        assert a[0] == b[0] and a[1] == b[1], (i, a[0], b[0])
+        _same(a[2:], b[2:], f"{a[0]} {a[1]}")
+    for k in ("frames", "keyframes", "templates", "iters", "trials", "switch_frames", "switch_solves", "switch_dropped", "schwarp_fits", "normals"):
+        assert st_h[k] == st_d[k], k
+    assert st_h["templates"] == 1 + st_h["keyframes"] and min(st_d["inliers"]) > 0.9
