@@ -26,13 +26,14 @@
 
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream);
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, int tail_below, hipStream_t stream);
+extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 
 // The dynamic LDS size a kernel has been enabled for (hipFuncSetAttribute) is a property of the (device, kernel) pair, not of a context: two
 // contexts on one GPU -- tracking and mapping, say -- must not lower each other's setting.  One high-water mark per device and kernel for the
 // whole process; the launchers only ever raise it, under this lock.
-struct LdsMarks { size_t lm[2] = {0, 0}, sc = 0, spec = 0, cn = 0, b[2] = {0, 0}; };
+struct LdsMarks { size_t lm[2] = {0, 0}, sc = 0, spec = 0, cn = 0, b[2] = {0, 0}, tail = 0; };
 static LdsMarks g_lds_marks[64];
 static std::mutex g_lds_mu;
 #define LDS_MARKS(c) (g_lds_marks[(c)->device & 63])
@@ -158,11 +159,12 @@ struct dsh_ctx : dsh_ctx_base {
   hipEvent_t sub_event[kMaxSub] = {nullptr, nullptr, nullptr, nullptr};
   int n_sub = 1;
   std::vector<hipEvent_t>* phase_events = nullptr;   // lab builds (dsh_lab_sft_rounds_timed): an event in front of and behind every phase launch
+  std::vector<int> phase_ids;                        // ... and which phase it was (SFTB_PH_*)
   int num_cus = 256;
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = 2; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -324,12 +326,22 @@ int run_rounds_enqueue(dsh_ctx* c) {
   const int B = c->B, S = c->n_sub;
   int b0[dsh_ctx::kMaxSub + 1];
   for (int s = 0; s <= S; s++) b0[s] = (int)((long long)B * s / S);
+  // The last problems of a step go to the tail kernel (sft_batch.h): one workgroup runs each of them to its end.  It pays from about two
+  // problems per CU downwards (a round costs one whole one-wavefront factorisation, 1 ms, however few problems it carries; a workgroup of the
+  // tail kernel takes 0.5 ms per trial).  WHEN the rounds end is decided on the device, by the first kernel of a round from the count the
+  // previous round left -- the results do not depend on how the launches are grouped here; a tail launch in front of the switch, like a round
+  // behind it, leaves at its first instruction.
+  const int tail_below = (c->opt.tail && S == 1) ? c->opt.tail * c->num_cus : -1;
   auto launch = [&](int s, int phase) {
     const bool ev = c->phase_events && S == 1;
-    if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
-    LDS_LOCK();
-    const hipError_t r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->xyz_doubles, LDS_MARKS(c).b,
-                                     c->num_cus, c->sub_stream[s]);
+    if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); c->phase_ids.push_back(phase); } }
+    hipError_t r;
+    {
+      LDS_LOCK();
+      if (phase == SFTB_PH_TAIL) r = sftb_tail_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, b0[s + 1] - b0[s], c->max_kd, c->jl_doubles, &LDS_MARKS(c).tail, c->num_cus, c->sub_stream[s]);
+      else r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->xyz_doubles, LDS_MARKS(c).b,
+                           c->num_cus, tail_below, c->sub_stream[s]);
+    }
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); } }
     return r;
   };
@@ -340,7 +352,9 @@ int run_rounds_enqueue(dsh_ctx* c) {
   }
   for (int s = 0; s < S; s++) HIPCHK(c, launch(s, SFTB_PH_INIT));
   const int worst = std::max(1, c->max_iters_batch) * 10 + 1;
+  // first group: the rounds the previous run of this context needed in front of its tail kernel (or, without one, to the end)
   int rounds = 0, group = std::max(1, std::min(worst, c->rounds_hint));
+  if (tail_below >= B) group = 0;   // (a batch this small: the tail kernel from the start)
   HIPCHK(c, c->spec_done.ensure(64 * dsh_ctx::kMaxSub, true));
   int rc = DSH_OK;
   while (true) {
@@ -350,11 +364,14 @@ int run_rounds_enqueue(dsh_ctx* c) {
         HIPCHK(c, launch(s, SFTB_PH_FACTOR));
         HIPCHK(c, launch(s, SFTB_PH_TRIAL));
       }
-    for (int s = 0; s < S; s++) HIPCHK(c, hipMemcpyAsync(c->spec_done.p + 64 * s, c->d_counters + 16 * s, sizeof(int), hipMemcpyDeviceToHost, c->sub_stream[s]));
+    if (tail_below >= 0) HIPCHK(c, launch(0, SFTB_PH_TAIL));
+    // [0] finished problems, [6] tail mode, [7] the round that switched to it
+    for (int s = 0; s < S; s++) HIPCHK(c, hipMemcpyAsync(c->spec_done.p + 64 * s, c->d_counters + 16 * s, 8 * sizeof(int), hipMemcpyDeviceToHost, c->sub_stream[s]));
     for (int s = 0; s < S; s++) HIPCHK(c, hipStreamSynchronize(c->sub_stream[s]));
     int done = 0;
     for (int s = 0; s < S; s++) done += *reinterpret_cast<const int*>(c->spec_done.p + 64 * s);
-    if (done >= B) { c->rounds_hint = rounds; break; }
+    const int* c0 = reinterpret_cast<const int*>(c->spec_done.p);
+    if (done >= B) { c->rounds_hint = (tail_below >= 0 && c0[6]) ? std::max(1, c0[7]) : rounds; break; }
     if (rounds >= worst) { rc = fail(c, DSH_ERR_STATE, "batched rounds: a problem did not terminate within its trial budget"); break; }
     group = 2;
   }
@@ -434,12 +451,12 @@ int dsh_create(dsh_ctx** out, int device) {
   }
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
-  // streams of the sub-batches of the throughput shape ([0] is the context's stream) and the events that order them behind it
+  // streams of the sub-batches of the throughput shape: [0] is the context's stream; the others are created when a batch is first split (the
+  // lab option "streams": measured and not the default).  Not before: HIP multiplexes the streams of a process onto four hardware queues, and a
+  // context that holds three idle streams pushes the streams of OTHER contexts onto shared queues -- the two contexts of a connected-mesh or
+  // shared-camera group then ran their phase kernels one after the other (17.5 instead of 9.5 ms per C2 frame next to a third context).
   c->sub_stream[0] = c->stream;
-  for (int i = 0; i < dsh_ctx::kMaxSub; i++) {
-    if (i > 0 && hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) != hipSuccess) c->sub_stream[i] = nullptr;
-    if (hipEventCreateWithFlags(&c->sub_event[i], hipEventDisableTiming) != hipSuccess) c->sub_event[i] = nullptr;
-  }
+  if (hipEventCreateWithFlags(&c->sub_event[0], hipEventDisableTiming) != hipSuccess) c->sub_event[0] = nullptr;
   *out = c;
   return DSH_OK;
 }
@@ -599,6 +616,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
       const int want = c->opt.streams > 0 ? c->opt.streams : 1;
       while (c->n_sub < want && c->n_sub < dsh_ctx::kMaxSub && B / (c->n_sub + 1) >= 16 * c->num_cus) c->n_sub++;
       if (c->opt.streams > 0) c->n_sub = std::min(std::min(c->opt.streams, (int)dsh_ctx::kMaxSub), std::max(1, B / 64));
+      for (int i = 1; i < c->n_sub; i++)   // (created on first use)
+        if (!c->sub_stream[i] && hipStreamCreateWithFlags(&c->sub_stream[i], hipStreamNonBlocking) != hipSuccess) c->sub_stream[i] = nullptr;
       for (int i = 0; i < c->n_sub; i++) if (!c->sub_stream[i] || !c->sub_event[0]) c->n_sub = 1;
     }
   }
@@ -1327,6 +1346,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "streams") { if (value < 0 || value > dsh_ctx::kMaxSub) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: streams is 0 (automatic) or 1..4 sub-batches"); c->opt.streams = value; }
   else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
   else if (k == "helpers") { if (value < -1 || value > 3) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers is -1 (automatic) or 0..3 workgroups per part"); c->opt.helpers = value; }
+  else if (k == "tail") { if (value < 0 || value > 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: tail is 0 (rounds to the end) or the number of problems per CU from which downwards the last problems go to the tail kernel (default 2)"); c->opt.tail = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;
@@ -1416,18 +1436,21 @@ int dsh_lab_sft_rounds_timed(dsh_ctx* c, double* ms4, int32_t* rounds) {
   (void)hipSetDevice(c->device);
   std::vector<hipEvent_t> ev;
   c->phase_events = &ev;
+  c->phase_ids.clear();
   const int rc = run_rounds(c);
   c->phase_events = nullptr;
   (void)hipStreamSynchronize(c->stream);
-  // launches in order: INIT, then (LIN, FACTOR, TRIAL) per round
-  for (int i = 0; i < 4; i++) ms4[i] = 0.0;
+  // launches by phase: ms[0] INIT, [1] LIN, [2] FACTOR, [3] TRIAL, [4] the tail kernel
+  for (int i = 0; i < 5; i++) ms4[i] = 0.0;
+  int n_trial = 0;
   for (size_t i = 0; i + 1 < ev.size(); i += 2) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-    const size_t l = i / 2;
-    ms4[l == 0 ? 0 : 1 + (l - 1) % 3] += ms;
+    const int ph = c->phase_ids[i / 2];
+    ms4[ph == SFTB_PH_INIT ? 0 : ph == SFTB_PH_LIN ? 1 : ph == SFTB_PH_FACTOR ? 2 : ph == SFTB_PH_TRIAL ? 3 : 4] += ms;
+    n_trial += ph == SFTB_PH_TRIAL;
   }
-  if (rounds) *rounds = ev.size() >= 2 ? (int32_t)((ev.size() / 2 - 1) / 3) : 0;
+  if (rounds) *rounds = n_trial;
   for (hipEvent_t e : ev) (void)hipEventDestroy(e);
   if (rc == DSH_OK) c->ran = true;
   return rc;

@@ -36,8 +36,13 @@ __device__ __forceinline__ void sftb_ctl_lds(char* smem, Ctl*& ctl, double*& red
   panel = out + 32;
 }
 
-__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list) {
+// counters (zeroed by the host in front of INIT): [0] finished problems, [1] FACTOR's work counter, [2] entries of the LIN list, [3] LIN's work
+// counter, [5] the tail kernel's work counter, [7] rounds that ran, [6] tail mode: few enough problems are left (B - counters[0] <= tail_below, decided by the
+// first kernel of a round from the count the previous round left, so the switch does not depend on how the host groups its launches):
+// the phase kernels leave at their first instruction, the tail kernel runs the rest
+__global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list, int tail_below) {
   const SftDev& P = probs[blockIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (int)gridDim.x <= tail_below) counters[6] = 1;
   init_state<64 * SFTB_NW>(P);
   if (threadIdx.x == 0) {
     SftRun& R = runs[blockIdx.x];
@@ -48,18 +53,47 @@ __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev
   }
 }
 
+// One linearisation (LIN, and the tail kernel below): residuals, records, normal equations; the first iteration also fixes the initial damping
+template <int NW>
+__device__ __forceinline__ void sftb_lin_problem(const SftDev& P, SftRun& R, Ctl* ctl, double* red, double* out, double* panel) {
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x;
+  auto nothing = [] {};
+  const double chi0 = linearise<NW, decltype(nothing), true>(P, ctl, red, out, panel, nothing);
+  double lambda = R.lambda;
+  if (R.it == 0) {
+    double mx = 0.0;
+    for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+    if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+    mx = block_max(mx, red);
+    lambda = 1e-5 * mx;
+  }
+  if (tid == 0) {
+    if (R.it == 0) { R.lambda = lambda; R.ni = 2.0; R.nbad = 0; }
+    R.chi_cur = chi0; R.chi_ini = chi0; R.qmax = 0; R.rho = 0.0; R.accepted = 0; R.all_ok = 1; R.lambda_start = lambda;
+    R.state = SFTB_TRIAL;
+  }
+}
+
 // LIN: a problem that starts an outer iteration is linearised; the first iteration also fixes the initial damping (tau = 1e-5).
 // Persistent workgroups pull the problems from the list the previous TRIAL (or INIT) launch appended them to (counters[2] entries, work counter
 // counters[3]; FACTOR resets both): a launch over all B problems spent 0.1-0.2 ms per round on workgroups that found nothing to do -- each of
 // them holds a CU's LDS while it finds out.  The order of the list varies from run to run; the problems are independent, the results do not.
 __global__ __launch_bounds__(64 * SFTB_LIN_NW, SFTB_LIN_WAVES) void sftb_lin_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters,
-                                                                                  const int* __restrict__ lin_list) {
+                                                                                  const int* __restrict__ lin_list, int B, int tail_below) {
   constexpr int NW = SFTB_LIN_NW, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int next_b;
   Ctl* ctl; double *red, *out, *panel;
   sftb_ctl_lds(smem, ctl, red, out, panel);
   const int tid = threadIdx.x;
+  // the first kernel of a round: few enough problems left for the tail kernel?  (nobody changes counters[0] during this launch: every workgroup
+  // sees the same count; workgroup 0 leaves the verdict for FACTOR and TRIAL)
+  if (counters[6] || B - counters[0] <= tail_below) {
+    if (blockIdx.x == 0 && tid == 0) counters[6] = 1;
+    return;
+  }
+  if (blockIdx.x == 0 && tid == 0) counters[7]++;   // rounds that ran (what the host enqueues in one go next time)
   while (true) {
     __syncthreads();   // (the previous problem is done with the LDS)
     if (tid == 0) {
@@ -69,23 +103,7 @@ __global__ __launch_bounds__(64 * SFTB_LIN_NW, SFTB_LIN_WAVES) void sftb_lin_ker
     __syncthreads();
     const int b = __builtin_amdgcn_readfirstlane(next_b);
     if (b < 0) break;
-    SftRun& R = runs[b];
-    const SftDev& P = probs[b];
-    auto nothing = [] {};
-    const double chi0 = linearise<NW, decltype(nothing), true>(P, ctl, red, out, panel, nothing);
-    double lambda = R.lambda;
-    if (R.it == 0) {
-      double mx = 0.0;
-      for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
-      if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
-      mx = block_max(mx, red);
-      lambda = 1e-5 * mx;
-    }
-    if (tid == 0) {
-      if (R.it == 0) { R.lambda = lambda; R.ni = 2.0; R.nbad = 0; }
-      R.chi_cur = chi0; R.chi_ini = chi0; R.qmax = 0; R.rho = 0.0; R.accepted = 0; R.all_ok = 1; R.lambda_start = lambda;
-      R.state = SFTB_TRIAL;
-    }
+    sftb_lin_problem<NW>(probs[b], runs[b], ctl, red, out, panel);
   }
 }
 
@@ -95,6 +113,7 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_double* lds = to_lds(reinterpret_cast<double*>(smem));
   const int lane = threadIdx.x;
+  if (counters[6]) return;                                        // tail mode
   for (int i = lane; i < WV_LDS_DOUBLES; i += 64) lds[i] = 0.0;   // (the landing buffer is multiplied by ring zeros before its first fill)
   if (blockIdx.x == 0 && lane == 0) { counters[2] = 0; counters[3] = 0; }   // the LIN list of this round is consumed; TRIAL appends the next one
   WvPrev Q;
@@ -115,24 +134,14 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
   if (Q.active) wv_backsub_now(Q, lane);
 }
 
-// TRIAL: push, x applied, scale, chi2 at the trial state, the controller's verdict; pop on rejection; at the end of an iteration the stop
-// rules; at the end of the problem the classification.
-__global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list) {
-  constexpr int NW = SFTB_NW, NT = 64 * NW;
-  SftRun& R = runs[blockIdx.x];
-  const int st = R.state;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[1] = 0;   // the work counter of the FACTOR launch in front of this one: ready for the next round
-  if (st != SFTB_TRIAL && st != SFTB_FINISH) return;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const SftDev& P = probs[blockIdx.x];
-  Ctl* ctl; double *red, *out, *panel;
-  sftb_ctl_lds(smem, ctl, red, out, panel);
+// One damping trial behind its factorisation (TRIAL, and the tail kernel below): push, x applied, scale, chi2 at the trial state, the
+// controller's verdict; pop on rejection; at the end of an iteration the stop rules; at the end of the problem the classification.
+// Returns 0: the same H is factored again with the next damping; 1: the iteration is over, the next one starts with a linearisation; 2: done.
+// lin_list: where a problem that starts a new iteration is appended for the next LIN launch (nullptr: the caller linearises itself).
+template <int NW>
+__device__ __forceinline__ int sftb_trial_problem(const SftDev& P, SftRun& R, Ctl* ctl, double* red, double* out, double* panel, int* counters, int* lin_list, int b) {
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
-  if (st == SFTB_FINISH) {   // max_iters == 0: nothing but the classification of the initial state; no error was ever computed (chi2 = 0, like the oracle)
-    classify<NT>(P, ctl, panel, 0, 0);
-    if (tid == 0) { R.state = SFTB_DONE; atomicAdd(&counters[0], 1); }
-    return;
-  }
   const int Dn = P.Dn;
   const int Dnp = ((Dn + NB - 1) / NB) * NB;
   const int ok = R.fact_ok;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
     for (int i = tid; i < 3 * P.n; i += NT) P.xyz[i] = staged.xyz_l[i];
   }
   const bool again = (ctl->rho < 0) && (ctl->qmax < 10);
-  if (again) return;   // the next round factors the same H with the new damping
+  if (again) return 0;   // the next round factors the same H with the new damping
   // ---- the outer iteration is over
   __syncthreads();
   if (tid == 0) {
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
     ctl->it = R.iters;
     ctl->accepted = R.trials;
     R.state = term ? SFTB_DONE : SFTB_LIN;
-    if (!term) lin_list[atomicAdd(&counters[2], 1)] = blockIdx.x;
+    if (!term && lin_list) lin_list[atomicAdd(&counters[2], 1)] = b;
   }
   __syncthreads();
   if (ctl->nbad) {
@@ -224,5 +233,82 @@ __global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_ker
     __syncthreads();
     classify<NT>(P, ctl, panel, iters, trials);
     if (tid == 0) atomicAdd(&counters[0], 1);
+    return 2;
+  }
+  return 1;
+}
+
+// TRIAL: one workgroup per problem of the batch (a finished problem's leaves at its first instruction).
+__global__ __launch_bounds__(64 * SFTB_NW, SFTB_TRIAL_WAVES) void sftb_trial_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list) {
+  constexpr int NW = SFTB_NW, NT = 64 * NW;
+  SftRun& R = runs[blockIdx.x];
+  const int st = R.state;
+  if (counters[6]) return;                                    // tail mode
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[1] = 0;   // the work counter of the FACTOR launch in front of this one: ready for the next round
+  if (st != SFTB_TRIAL && st != SFTB_FINISH) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SftDev& P = probs[blockIdx.x];
+  Ctl* ctl; double *red, *out, *panel;
+  sftb_ctl_lds(smem, ctl, red, out, panel);
+  const int tid = threadIdx.x;
+  if (st == SFTB_FINISH) {   // max_iters == 0: nothing but the classification of the initial state; no error was ever computed (chi2 = 0, like the oracle)
+    classify<NT>(P, ctl, panel, 0, 0);
+    if (tid == 0) { R.state = SFTB_DONE; atomicAdd(&counters[0], 1); }
+    return;
+  }
+  (void)sftb_trial_problem<NW>(P, R, ctl, red, out, panel, counters, lin_list, blockIdx.x);
+}
+
+// (Out of line, the LDS workspace handed over as offsets: with the generic pointers of the caller as arguments -- inlined or not -- the call of
+// the factorisation from the tail kernel sends hipcc 7.2 into "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base".)
+__device__ __noinline__ void sftb_solve8(const SftDev& P, unsigned ctl_off, unsigned ws_off, double lambda) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  Ctl* ctl = reinterpret_cast<Ctl*>((char*)(lds_char*)(size_t)__builtin_amdgcn_readfirstlane(ctl_off));
+  double* ws = reinterpret_cast<double*>((char*)(lds_char*)(size_t)__builtin_amdgcn_readfirstlane(ws_off));
+  factor_tiles_df8<1>(P, ctl, ws, lambda, true);
+  backsub_tiles<8>(P, ctl, ws);
+}
+
+// TAIL: the last rounds of a step carry a handful of problems -- fewer than there are SIMDs, so a round costs one whole one-wavefront
+// factorisation (1 ms) for next to nothing.  Once few enough problems are left, every one of them gets a workgroup of its own that runs it to
+// the end from its SftRun record: linearisations and trials are the code of LIN and TRIAL (same bits), the factorisation is the eight-wavefront
+// register-window solver of the persistent kernel (0.35 ms per trial; its x agrees with the one-wavefront solver's to 5e-13).  Persistent
+// workgroups pull problem indices from counters[5].
+__global__ __launch_bounds__(64 * SFTB_NW, SFT_WAVES_PER_EU) void sftb_tail_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int B) {
+  constexpr int NW = SFTB_NW, NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctl* ctl; double *red, *out, *panel;
+  sftb_ctl_lds(smem, ctl, red, out, panel);
+  const int tid = threadIdx.x;
+  if (!counters[6]) return;   // not yet: the rounds go on
+  while (true) {
+    __syncthreads();
+    if (tid == 0) ctl->it = atomicAdd(&counters[5], 1);
+    __syncthreads();
+    const int b = __builtin_amdgcn_readfirstlane(ctl->it);
+    __syncthreads();
+    if (b >= B) break;
+    SftRun& R = runs[b];
+    const SftDev& P = probs[b];
+    int st = R.state;
+    if (st == SFTB_FINISH) {
+      classify<NT>(P, ctl, panel, 0, 0);
+      if (tid == 0) { R.state = SFTB_DONE; atomicAdd(&counters[0], 1); }
+      continue;
+    }
+    while (st == SFTB_LIN || st == SFTB_TRIAL) {
+      if (st == SFTB_LIN) {
+        sftb_lin_problem<NW>(P, R, ctl, red, out, panel);
+        __syncthreads();
+      }
+      if (tid == 0) ctl->lambda = R.lambda;
+      __syncthreads();
+      sftb_solve8(P, (unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)ctl, (unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)panel, R.lambda);
+      if (tid == 0) R.fact_ok = ctl->fact_ok;
+      __syncthreads();
+      const int r = sftb_trial_problem<NW>(P, R, ctl, red, out, panel, counters, nullptr, b);
+      __syncthreads();
+      st = r == 0 ? SFTB_TRIAL : (r == 1 ? SFTB_LIN : SFTB_DONE);
+    }
   }
 }

@@ -1579,6 +1579,9 @@ __device__ __forceinline__ void corner_finish(const SftDev& P, Ctl* ctl, lds_dou
 
 // lam_corner: damping added to the 6x6 camera block (the shared-camera mode adds it on one rank only); finish_corner = false leaves the
 // 7x7 Schur complement of the camera (lower triangle + right-hand side row) in P.Lcorner instead of solving for the camera update.
+// (INST: the tail kernel of the batched rounds takes an instance of its own -- a call of the shared one from there sends hipcc 7.2 into
+// "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+template <int INST = 0>
 __device__ __noinline__ void factor_tiles_df8(const SftDev& P, Ctl* ctl, double* ws, double lam_corner, bool finish_corner) {
   constexpr int NW = 8, NT = 64 * NW, BOFF = 2;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -3271,6 +3274,17 @@ extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phas
   return hipGetLastError();
 }
 
+extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream) {
+  const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);   // the larger of the linearisation's records and the solver's workspace
+  if (lds > *configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sftb_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    *configured = lds;
+  }
+  hipLaunchKernelGGL(sftb_tail_kernel, dim3(std::min(B, num_cus)), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs, d_counters, B);
+  return hipGetLastError();
+}
+
 // out_a[i] = out_b[i] = a[i] + b[i]: the in-process stand-in of a two-rank all-reduce (dsh_sft_connected_solve_group); in place is fine
 __global__ void sft_vec_sum2_kernel(const double* a, const double* b, double* out_a, double* out_b, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -3344,12 +3358,12 @@ extern "C" hipError_t sft_wave_lab_launch(const SftDev* d_probs, int B, int whic
 
 // Phase launches of the batched throughput shape (sft_batch.h).  `configured` (two slots of the per-device table): the largest dynamic LDS
 // sizes the LIN and TRIAL kernels have been enabled for on that device (see sft_lm_launch).
-extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, hipStream_t stream) {
+extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, int tail_below, hipStream_t stream) {
   const size_t head = 512 + (16 * 27 + 5 + 32) * sizeof(double) + 64;
   if (phase == SFTB_PH_INIT) {
     hipError_t e = hipMemsetAsync(d_counters, 0, 16 * sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sftb_init_kernel, dim3(B), dim3(64 * SFTB_NW), 0, stream, d_probs, d_runs, d_counters, d_list);
+    hipLaunchKernelGGL(sftb_init_kernel, dim3(B), dim3(64 * SFTB_NW), 0, stream, d_probs, d_runs, d_counters, d_list, tail_below);
   } else if (phase == SFTB_PH_LIN) {
     const size_t lds = head + jl_doubles * sizeof(double);
     if (lds > configured[0]) {
@@ -3358,7 +3372,7 @@ extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_
       configured[0] = lds;
     }
     const int per_cu = lds > 80 * 1024 ? 1 : 2;   // persistent workgroups: as many as are resident at once
-    hipLaunchKernelGGL(sftb_lin_kernel, dim3(std::min(B, per_cu * num_cus)), dim3(64 * SFTB_LIN_NW), lds, stream, d_probs, d_runs, d_counters, d_list);
+    hipLaunchKernelGGL(sftb_lin_kernel, dim3(std::min(B, per_cu * num_cus)), dim3(64 * SFTB_LIN_NW), lds, stream, d_probs, d_runs, d_counters, d_list, B, tail_below);
   } else if (phase == SFTB_PH_FACTOR) {
     hipLaunchKernelGGL(sftb_factor_kernel, dim3(std::min(B, 4 * num_cus)), dim3(64), WV_LDS_DOUBLES * sizeof(double), stream, d_probs, d_runs, d_counters, B);   // one wave per SIMD
   } else {

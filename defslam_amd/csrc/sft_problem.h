@@ -95,6 +95,7 @@ struct SftSpec {
 #define SFTB_PH_LIN 1
 #define SFTB_PH_FACTOR 2
 #define SFTB_PH_TRIAL 3
+#define SFTB_PH_TAIL 4     // the last problems of a step: one workgroup runs each to its end (sft_batch.h: sftb_tail_kernel)
 struct SftRun {
   double lambda, ni, chi_cur, chi_ini, rho, lambda_start;
   double pose_bak[8];

@@ -630,6 +630,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
 #ifdef SFT_WIDE_TRACE
   lds_double* wtrace = Cn + 580;
   if (tid < 64) wtrace[tid] = 0.0;
+  const long long wt_c0 = clock64(), wt_w0 = wall_clock64();
 #endif
   __syncthreads();
   int misses = 0;
@@ -867,6 +868,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
 #ifdef SFT_WIDE_TRACE
   __syncthreads();
   if (tid < 64) P.dbg[64 * which + tid] = wtrace[tid];
+  if (tid == 0) { P.dbg[64 * which + 62] = (double)(clock64() - wt_c0); P.dbg[64 * which + 63] = (double)(wall_clock64() - wt_w0); }   // shader clocks, 100 MHz ticks
 #endif
 #ifdef DSH_LAB
   if (helped && tid == 0) {

@@ -143,8 +143,71 @@ def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
         assert frames[p].trials == r.trials
 
 
+@pytest.fixture
+def rounds_ctx(lab_ctx):
+    """The rounds of phase kernels run to the END of every problem (lab option tail = 0): since r05 the product hands the last problems of a step
+    -- from two per CU downwards, i.e. all of a 512-problem batch -- to sftb_tail_kernel, and these tests are about the one-wavefront solver of the
+    rounds on small, ragged, failing and budgeted problems.  (The tail kernel has its own test below; the product's default, rounds + tail, is
+    what test_benched_shape_matches_oracle_under_load runs.)"""
+    lab_ctx.set_option("tail", 0)
+    yield lab_ctx
+    lab_ctx.set_option("tail", 2)
+
+
+def test_tail_kernel_finishes_what_the_rounds_leave_like_the_rounds_would(lab_ctx, oracle_mod):
+    """sftb_tail_kernel: once at most two problems per CU are still running, each of them gets a workgroup that runs it to its end from the
+    controller record the rounds left (linearisations and trials: the code of LIN / TRIAL; factorisation: the eight-wavefront register-window
+    solver).  A ragged batch of 1100 problems (every third sees part of the template; the rounds run until 512 are left) with the tail kernel and
+    with rounds to the end: identical LM trajectories, outliers and inlier counts, vertices to 1e-9 relative; sampled ids against the oracle;
+    two runs with the tail kernel bit-identical (where the rounds end is decided on the device, not by the host's launch groups)."""
+    from defslam_amd import sft, synth
+    B = 1100
+    tmpl = synth.make_grid_template(9, 14)
+    lab_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = []
+    for p in range(B):
+        fr = synth.make_frame(tmpl, 420, p)
+        if p % 3 == 1:   # a partial view: no observation on the last column(s) of the template
+            keep = [c + 14 * r for r in range(9) for c in range(14 - 1 - (p % 2))]
+            sel = np.all(np.isin(fr.obs_nodes, keep), axis=1)
+            for k in ["obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+                setattr(fr, k, getattr(fr, k)[sel])
+        syn.append(fr)
+    runs = {}
+    for key, tail in (("rounds", 0), ("tail", 2), ("tail2", 2)):
+        lab_ctx.set_option("tail", tail)
+        frames = [sft.frame_from_synth(fr) for fr in syn]
+        lab_ctx.batch_upload(frames, *regs, 1, 50)
+        _, counts = lab_ctx.problem_info(0)
+        assert int(counts[7]) == 1
+        lab_ctx.batch_run()
+        inl = lab_ctx.batch_download()
+        runs[key] = (frames, [int(i) for i in inl])
+        if tail:
+            ph, nr = lab_ctx.rounds_timed()
+            assert ph["tail"] > 0.0 and nr >= 1, (ph, nr)            # both parts of the step ran
+    lab_ctx.set_option("tail", 2)
+    fr_r, in_r = runs["rounds"]
+    fr_t, in_t = runs["tail"]
+    fr_u, in_u = runs["tail2"]
+    assert in_r == in_t == in_u
+    for a, b, c in zip(fr_r, fr_t, fr_u):
+        assert (a.iters, a.trials) == (b.iters, b.trials)
+        np.testing.assert_array_equal(a.trace[:a.iters, [2, 6]], b.trace[:b.iters, [2, 6]])
+        np.testing.assert_array_equal(a.mvbOutlier, b.mvbOutlier)
+        assert np.abs(a.nodes_xyz - b.nodes_xyz).max() <= 1e-9 * np.abs(a.nodes_xyz).max()
+        np.testing.assert_array_equal(b.nodes_xyz, c.nodes_xyz)
+        np.testing.assert_array_equal(b.pose7, c.pose7)
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    for p in (0, 1, 2, 511, 512, 700, 1099):
+        fr = syn[p]
+        r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+        _compare(fr_t[p], in_t[p], r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+
+
 @pytest.mark.parametrize("shape,m", [((3, 3), 60), ((5, 6), 200), ((7, 7), 300), ((10, 10), 300), ((9, 14), 420)])
-def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mod, shape, m):
+def test_rounds_of_phase_kernels_on_small_and_ragged_problems(rounds_ctx, oracle_mod, shape, m):
     """The throughput shape (LIN / FACTOR / TRIAL rounds, one wavefront per factorisation) away from the benched size: block-row counts
     below, at and just above the 8-tile window (2, 6, 10, 19, 24 block rows), active blocks that are not a multiple of the tile size, and
     -- every third problem sees only part of the template -- different dimensions inside one batch.  512 problems per batch (the smallest
@@ -153,7 +216,7 @@ def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mo
     B = 512
     rows, cols = shape
     tmpl = synth.make_grid_template(rows, cols)
-    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    rounds_ctx.template_build(tmpl.xyz0, tmpl.facets)
     regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     syn = []
     for p in range(B):
@@ -165,11 +228,11 @@ def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mo
                 setattr(fr, k, getattr(fr, k)[sel])
         syn.append(fr)
     frames = [sft.frame_from_synth(fr) for fr in syn]
-    gpu_ctx.batch_upload(frames, *regs, 1, 50)
-    _, counts = gpu_ctx.problem_info(0)
+    rounds_ctx.batch_upload(frames, *regs, 1, 50)
+    _, counts = rounds_ctx.problem_info(0)
     assert int(counts[7]) == 1, "512 narrow-band problems must run as rounds of phase kernels"
-    gpu_ctx.batch_run()
-    inl = gpu_ctx.batch_download()
+    rounds_ctx.batch_run()
+    inl = rounds_ctx.batch_download()
     tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
     dims = set()
     relaxed = []
@@ -205,7 +268,7 @@ def test_rounds_of_phase_kernels_on_small_and_ragged_problems(gpu_ctx, oracle_mo
         assert len(relaxed) <= 12, relaxed
 
 
-def test_rounds_of_phase_kernels_when_the_camera_records_do_not_fit_lds(gpu_ctx, oracle_mod):
+def test_rounds_of_phase_kernels_when_the_camera_records_do_not_fit_lds(rounds_ctx, oracle_mod):
     """The benched template with four times the observations (4000 matches): the camera records of placement class 3 (five doubles per
     observation) no longer fit the LDS budget of the LIN kernel next to the other record classes, the upload falls back to class 2 (128-byte
     records in the workspace) -- same throughput shape, same results."""
@@ -213,14 +276,14 @@ def test_rounds_of_phase_kernels_when_the_camera_records_do_not_fit_lds(gpu_ctx,
     B = 512
     rows, cols, _ = synth.CONFIGS["C2"]
     tmpl = synth.make_grid_template(rows, cols)
-    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    rounds_ctx.template_build(tmpl.xyz0, tmpl.facets)
     regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     syn = [synth.make_frame(tmpl, 4000, p) for p in range(B)]
     frames = [sft.frame_from_synth(fr) for fr in syn]
-    gpu_ctx.batch_upload(frames, *regs, 1, 50)
-    assert int(gpu_ctx.problem_info(0)[1][7]) == 1
-    gpu_ctx.batch_run()
-    inl = gpu_ctx.batch_download()
+    rounds_ctx.batch_upload(frames, *regs, 1, 50)
+    assert int(rounds_ctx.problem_info(0)[1][7]) == 1
+    rounds_ctx.batch_run()
+    inl = rounds_ctx.batch_download()
     tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
     for p in (0, 255, 511):
         fr = syn[p]
@@ -228,7 +291,7 @@ def test_rounds_of_phase_kernels_when_the_camera_records_do_not_fit_lds(gpu_ctx,
         _compare(frames[p], int(inl[p]), r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
 
 
-def test_rounds_of_phase_kernels_with_failing_factorisations(gpu_ctx, oracle_mod):
+def test_rounds_of_phase_kernels_with_failing_factorisations(rounds_ctx, oracle_mod):
     """Problems whose normal equations are not positive definite (observations with NEGATIVE information: H = sum w J^T J is indefinite) among
     healthy ones in one batch of the throughput shape: the one-wavefront Cholesky reports the non-positive pivot, the trial counts as failed
     (g2o: `_solver->solve` returns false, the step is rejected, optimization_algorithm_levenberg.cpp:103-113), the state is restored, status
@@ -236,17 +299,17 @@ def test_rounds_of_phase_kernels_with_failing_factorisations(gpu_ctx, oracle_mod
     from defslam_amd import sft, synth
     B = 512
     tmpl = synth.make_grid_template(10, 10)
-    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    rounds_ctx.template_build(tmpl.xyz0, tmpl.facets)
     regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     syn = [synth.make_frame(tmpl, 300, p) for p in range(B)]
     poisoned = (3, 77, 300, 511)
     for p in poisoned:
         syn[p].obs_invsig2 = -50.0 * np.abs(syn[p].obs_invsig2)
     frames = [sft.frame_from_synth(fr) for fr in syn]
-    gpu_ctx.batch_upload(frames, *regs, 1, 50)
-    assert int(gpu_ctx.problem_info(0)[1][7]) == 1
-    gpu_ctx.batch_run()
-    inl = gpu_ctx.batch_download()
+    rounds_ctx.batch_upload(frames, *regs, 1, 50)
+    assert int(rounds_ctx.problem_info(0)[1][7]) == 1
+    rounds_ctx.batch_run()
+    inl = rounds_ctx.batch_download()
     tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
     for p in list(poisoned) + [2, 4, 76, 78, 299, 301, 510, 0, 1]:
         fr = syn[p]
@@ -267,22 +330,22 @@ def test_rounds_of_phase_kernels_with_failing_factorisations(gpu_ctx, oracle_mod
 
 
 @pytest.mark.parametrize("max_iters", [0, 1, 3])
-def test_rounds_of_phase_kernels_with_an_iteration_budget(gpu_ctx, oracle_mod, max_iters):
+def test_rounds_of_phase_kernels_with_an_iteration_budget(rounds_ctx, oracle_mod, max_iters):
     """The throughput shape when the caller's iteration budget ends the solve: 0 (classification of the initial state only -- the batch never
     enters a LIN / FACTOR round), 1 and 3 iterations (problems stop on the budget in different rounds, each with its own number of rejected
     dampings).  512 problems on the 10 x 10 mesh, 24 of them against the oracle with the same budget."""
     from defslam_amd import sft, synth
     B = 512
     tmpl = synth.make_grid_template(10, 10)
-    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    rounds_ctx.template_build(tmpl.xyz0, tmpl.facets)
     regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
     syn = [synth.make_frame(tmpl, 300, p) for p in range(B)]
     frames = [sft.frame_from_synth(fr) for fr in syn]
-    gpu_ctx.batch_upload(frames, *regs, 1, max_iters)
-    _, counts = gpu_ctx.problem_info(0)
+    rounds_ctx.batch_upload(frames, *regs, 1, max_iters)
+    _, counts = rounds_ctx.problem_info(0)
     assert int(counts[7]) == 1
-    gpu_ctx.batch_run()
-    inl = gpu_ctx.batch_download()
+    rounds_ctx.batch_run()
+    inl = rounds_ctx.batch_download()
     tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
     zero_it = []
     for p in list(range(16)) + [255, 256, 257, 509, 510, 511, 300, 301]:
@@ -304,7 +367,7 @@ def test_rounds_of_phase_kernels_with_an_iteration_budget(gpu_ctx, oracle_mod, m
             assert f.trials == r.trials
     for p, outl, chi2, rep, n_in in zero_it[:4]:
         fr = syn[p]
-        f1, i1 = _solve_gpu(gpu_ctx, tmpl.xyz0, tmpl.facets, dict(Tcw=fr.Tcw, K=fr.K, n_frame=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary,
+        f1, i1 = _solve_gpu(rounds_ctx, tmpl.xyz0, tmpl.facets, dict(Tcw=fr.Tcw, K=fr.K, n_frame=fr.n_frame, obs_nodes=fr.obs_nodes, obs_bary=fr.obs_bary,
                                                                   obs_uv=fr.obs_uv, obs_invsig2=fr.obs_invsig2, xyz=fr.xyz), regs, 1, 0)
         np.testing.assert_array_equal(f1.mvbOutlier, outl)
         np.testing.assert_array_equal(f1.chi2_obs, chi2)

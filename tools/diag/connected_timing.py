@@ -10,6 +10,17 @@ sys.path.insert(0, ROOT)
 from defslam_amd import sft, synth  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+if "--torch" in sys.argv:   # the process bench.py measures in: torch imported, its CUDA context alive
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(4, device="cuda")
+if "--big" in sys.argv:     # ... and a third context holding a large batch arena
+    big = sft.Context(0)
+    t2, _ = synth.make_problem("C2", 0)
+    big.template_build(t2.xyz0, t2.facets)
+    big.batch_upload([sft.frame_from_synth(synth.make_frame(t2, 1000, p)) for p in range(2048)], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
+    big.batch_run()
+    big.synchronize()
 tmpl, fr = synth.make_problem(cfg, 0)
 regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
 ctxs = [sft.Context(0), sft.Context(0)]

@@ -36,6 +36,9 @@ for nh in (0, -1):
     for g in (0, 1):
         ncol = (info["c0"] if g == 0 else info["n1p"]) // 16 + info["s"] // 16 if "c0" in info else 204
         print(f"  part {g} ({ncol} columns): us per column by role (rows) and segment (columns 0..7), last column: sum")
+        raw = d[g].ravel()
+        if raw[63] > 0:
+            print(f"    shader clock over the factorisation: {raw[62] / raw[63] * 100:.0f} MHz ({raw[63] * 1e-2:.0f} us)")
         for r in range(8):
             us = d[g, r] * 1e-2 / ncol
             print("    role %d: " % r + " ".join(f"{v:6.2f}" for v in us) + f"   {us.sum():6.2f}")
