@@ -620,23 +620,30 @@ def main():
                 if curve is not None:
                     curve["points"][-1]["rounds_per_step"] = n_rounds
                 rf = out["roofline"]
-                tf = flops_per_launch / (ph["factor"] * 1e-3) / 1e12
+                # the damping trials the FACTOR launches factored (the last problems of a step are run to their end by sftb_tail_kernel: not counted here)
+                n_fact = ph.pop("factorisations_in_rounds")
+                n_lin = ph.pop("linearisations_in_rounds")
+                flops_factor = flops_trial * float(n_fact)
+                tf = flops_factor / (ph["factor"] * 1e-3) / 1e12
                 rf.update({"kernel": "sftb_factor_kernel", "kernel_ms": ph["factor"], "achieved": tf, "frac": tf / FP64_PEAK_TFLOPS,
                            "traffic": traffic_phase.get("factor"), "traffic_GBps": (traffic_phase["factor"] / (ph["factor"] * 1e-3) / 1e9) if "factor" in traffic_phase else None,
                            "traffic_what": "HBM bytes of the kernel's launches of one step (PMC)",
                            "timing": "HIP events in front of and behind every launch of one step (dsh_lab_sft_rounds_timed, libdefslam_hip_lab.so: the device code of "
                                      "the timed product run); kernel_ms = the sum over the step's sftb_factor_kernel launches",
                            "phases_ms": ph, "rounds_per_step": n_rounds, "phases_sum_over_step": sum(ph.values()) / ms_per_step,
+                           "algorithmic_flops_per_launch": flops_factor, "factorisations_in_rounds": int(n_fact), "damping_trials_per_step": int(trials),
                            "note": "a step = rounds of LIN (residuals + Jacobian assembly), FACTOR (banded-arrowhead Cholesky + back substitution, one wavefront per "
-                                   "problem, FP64 MFMA) and TRIAL (update, chi2, LM control) launches; frac = algorithmic solve flops / FP64 peak over the FACTOR "
+                                   "problem, FP64 MFMA) and TRIAL (update, chi2, LM control) launches, then ONE launch of the tail kernel for the last problems (two per CU "
+                                   "and fewer: phases_ms.tail); frac = algorithmic solve flops / FP64 peak over the FACTOR "
                                    "kernel's own time; hbm_assembly = SURVEY 8d assembly bytes over the LIN kernel's own time"})
-                lin_gbs = bytes_per_launch / (ph["lin"] * 1e-3) / 1e9
+                bytes_lin = (alg_bytes / args.batch) * float(n_lin)     # the linearisations the LIN launches performed (the last problems': tail kernel)
+                lin_gbs = bytes_lin / (ph["lin"] * 1e-3) / 1e9
                 rf["hbm_assembly"] = {"kernel": "sftb_lin_kernel", "kernel_ms": ph["lin"], "achieved": lin_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
-                                      "traffic": traffic_phase.get("lin"), "traffic_over_algorithmic": (traffic_phase["lin"] / bytes_per_launch) if "lin" in traffic_phase else None,
+                                      "frac": lin_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_lin, "linearisations_in_rounds": int(n_lin), "linearisations_per_step": int(iters),
+                                      "traffic": traffic_phase.get("lin"), "traffic_over_algorithmic": (traffic_phase["lin"] / bytes_lin) if "lin" in traffic_phase else None,
                                       "what": "every linearisation of a step (residuals + records + normal equations of the problems that start an iteration), "
                                               "algorithmic bytes over the kernel's own time"}
-                fs = (stream_bytes) / (ph["factor"] * 1e-3) / 1e9
+                fs = (stream_trial * float(n_fact)) / (ph["factor"] * 1e-3) / 1e9
                 rf["hbm_solver_stream"] = {"kernel": "sftb_factor_kernel", "achieved": fs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fs / HBM_PEAK_GBS,
                                            "bytes_per_trial": stream_trial, "achievable_stream_GBps_this_box": 5400.0,
                                            "what": "per damping trial the compact H blocks read once, L written once and read once by the deferred back substitution"}

@@ -1440,8 +1440,9 @@ int dsh_lab_sft_rounds_timed(dsh_ctx* c, double* ms4, int32_t* rounds) {
   const int rc = run_rounds(c);
   c->phase_events = nullptr;
   (void)hipStreamSynchronize(c->stream);
-  // launches by phase: ms[0] INIT, [1] LIN, [2] FACTOR, [3] TRIAL, [4] the tail kernel
-  for (int i = 0; i < 5; i++) ms4[i] = 0.0;
+  // launches by phase: ms[0] INIT, [1] LIN, [2] FACTOR, [3] TRIAL, [4] the tail kernel; [5] = factorisations done by the FACTOR launches, [6] = linearisations done by the LIN launches
+  for (int i = 0; i < 7; i++) ms4[i] = 0.0;
+  { int32_t cnt[16] = {0}; if (hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost) == hipSuccess) { ms4[5] = (double)cnt[8]; ms4[6] = (double)cnt[9]; } }
   int n_trial = 0;
   for (size_t i = 0; i + 1 < ev.size(); i += 2) {
     float ms = 0.f;

@@ -37,7 +37,7 @@ __device__ __forceinline__ void sftb_ctl_lds(char* smem, Ctl*& ctl, double*& red
 }
 
 // counters (zeroed by the host in front of INIT): [0] finished problems, [1] FACTOR's work counter, [2] entries of the LIN list, [3] LIN's work
-// counter, [5] the tail kernel's work counter, [7] rounds that ran, [6] tail mode: few enough problems are left (B - counters[0] <= tail_below, decided by the
+// counter, [5] the tail kernel's work counter, [7] rounds that ran, [8] factorisations by FACTOR launches, [9] linearisations by LIN launches, [6] tail mode: few enough problems are left (B - counters[0] <= tail_below, decided by the
 // first kernel of a round from the count the previous round left, so the switch does not depend on how the host groups its launches):
 // the phase kernels leave at their first instruction, the tail kernel runs the rest
 __global__ __launch_bounds__(64 * SFTB_NW, 2) void sftb_init_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int* __restrict__ lin_list, int tail_below) {
@@ -94,15 +94,17 @@ __global__ __launch_bounds__(64 * SFTB_LIN_NW, SFTB_LIN_WAVES) void sftb_lin_ker
     return;
   }
   if (blockIdx.x == 0 && tid == 0) counters[7]++;   // rounds that ran (what the host enqueues in one go next time)
+  // (the index of the problem after this one is fetched while this one is linearised: the atomic and the list entry are a round trip to memory
+  // each, on every workgroup's critical path otherwise)
+  auto fetch = [&]() { const int i = atomicAdd(&counters[3], 1); return i < counters[2] ? lin_list[i] : -1; };
+  int nxt = -1;
+  if (tid == 0) nxt = fetch();
   while (true) {
-    __syncthreads();   // (the previous problem is done with the LDS)
-    if (tid == 0) {
-      const int i = atomicAdd(&counters[3], 1);
-      next_b = i < counters[2] ? lin_list[i] : -1;
-    }
+    if (tid == 0) next_b = nxt;   // (the barriers inside the previous linearisation lie between this and the last read of next_b)
     __syncthreads();
     const int b = __builtin_amdgcn_readfirstlane(next_b);
     if (b < 0) break;
+    if (tid == 0) { nxt = fetch(); atomicAdd(&counters[9], 1); }   // in flight until the top of the loop; [9]: linearisations by LIN launches
     sftb_lin_problem<NW>(probs[b], runs[b], ctl, red, out, panel);
   }
 }
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
   if (blockIdx.x == 0 && lane == 0) { counters[2] = 0; counters[3] = 0; }   // the LIN list of this round is consumed; TRIAL appends the next one
   WvPrev Q;
   Q.Lg = nullptr; Q.Linv = nullptr; Q.x = nullptr; Q.nT = 0; Q.active = 0; Q.xb = 0.0;
+  int n_done = 0;
   while (true) {
     int b = 0;
     if (lane == 0) b = atomicAdd(&counters[1], 1);
@@ -130,8 +133,10 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
     const int ok = wv_factor(P, lambda, lambda, lds, Q, xcam);   // (Q's back substitution is complete when this returns)
     if (lane == 0) runs[b].fact_ok = ok;
     Q = wv_prev_of(P, ok, xcam, lane);
+    n_done++;
   }
   if (Q.active) wv_backsub_now(Q, lane);
+  if (lane == 0 && n_done) atomicAdd(&counters[8], n_done);   // factorisations of this kernel over the step (the tail kernel's are not among them)
 }
 
 // One damping trial behind its factorisation (TRIAL, and the tail kernel below): push, x applied, scale, chi2 at the trial state, the

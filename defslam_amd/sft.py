@@ -245,10 +245,10 @@ class Context:
     def rounds_timed(self):
         """One run of the uploaded batch as rounds of phase kernels with events around every launch (lab): (dict of total ms per phase, rounds)."""
         self._need_lab("dsh_lab_sft_rounds_timed")
-        ms = np.zeros(5)
+        ms = np.zeros(7)
         r = np.zeros(1, np.int32)
         self._check(self._L.dsh_lab_sft_rounds_timed(self._h, _ptr(ms, C.c_double), _ptr(r, C.c_int32)), "dsh_lab_sft_rounds_timed")
-        return dict(init=float(ms[0]), lin=float(ms[1]), factor=float(ms[2]), trial=float(ms[3]), tail=float(ms[4])), int(r[0])
+        return dict(init=float(ms[0]), lin=float(ms[1]), factor=float(ms[2]), trial=float(ms[3]), tail=float(ms[4]), factorisations_in_rounds=int(ms[5]), linearisations_in_rounds=int(ms[6])), int(r[0])
 
     def dump(self, b: int, what: int, n: int):
         self._need_lab("dsh_lab_sft_dump")

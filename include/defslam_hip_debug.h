@@ -55,9 +55,10 @@ int dsh_lab_sft_assemble_timed(dsh_ctx* ctx, int launches, double* total_ms);
  * only = 0: both, 1: the four-wavefront solver alone, 2: the one-wavefront solver alone (with the lambda the last reference run left). */
 int dsh_lab_sft_wave_check(dsh_ctx* ctx, double rel, int launches, int only, double* x_ref, double* x_new, int32_t* ok2, double* ms2);
 /* One run of the uploaded batch in the throughput shape (rounds of phase kernels, sft_batch.h) with a HIP event in front of and behind
- * every launch: ms4 = total device milliseconds of the INIT, LIN, FACTOR and TRIAL launches; *rounds (may be NULL) = rounds launched.
+ * every launch: ms7[0..4] = total device milliseconds of the INIT, LIN, FACTOR, TRIAL and tail-kernel launches, ms7[5] = factorisations the FACTOR
+ * launches performed, ms7[6] = linearisations the LIN launches performed (the last problems' are the tail kernel's); *rounds (may be NULL) = rounds of phase kernels launched.
  * What bench.py's roofline objects are computed from (sftb_factor_kernel: FP64; sftb_lin_kernel: the Jacobian assembly). */
-int dsh_lab_sft_rounds_timed(dsh_ctx* ctx, double* ms5, int32_t* rounds);
+int dsh_lab_sft_rounds_timed(dsh_ctx* ctx, double* ms7, int32_t* rounds);
 /* n doubles of a workspace array of problem b: what = 0 L tiles, 1 inverse diagonal tiles, 2 border rows of L, 3 compact H blocks, 4 border rows
  * of H, 5 x, 6 corner of H, 7 debug slots (tuning aid; no bounds check beyond n > 0). */
 int dsh_lab_sft_dump(dsh_ctx* ctx, int b, int what, int64_t n, double* out);
