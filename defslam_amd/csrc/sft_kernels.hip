@@ -582,7 +582,10 @@ __device__ __forceinline__ void assemble(const SftDev& P_, double* red, double* 
   // Tile mode 1 keeps H as compact 3x3 blocks (P.Hc; the factorisation gathers its tiles from them): a lane that finishes a
   // block stores its nine doubles, nothing is padded to tiles.  The other modes store into their band / tile layout element by element.
   const bool compact = P.tile_mode == 1;
-  constexpr int GN = 7;                      // block rows (nodes) per round of a wavefront: 8 lanes each for the diagonal blocks
+#ifndef SFT_ASM_GN
+#define SFT_ASM_GN 7
+#endif
+  constexpr int GN = SFT_ASM_GN;             // block rows (nodes) per round of a wavefront: 8 lanes each for the diagonal blocks
   const int ngroups = (P.nA + GN - 1) / GN;
   const auto Hg = P.Hb;
   const auto Hc = P.Hc;

@@ -29,6 +29,9 @@ ctx.batch_run()
 ctx.synchronize()
 ph, r = ctx.rounds_timed()
 it, tr = ctx.batch_counts()
+ph = {k: v for k, v in ph.items() if not k.endswith("_in_rounds")}
+asm_ms = ctx.batch_assemble_timed(5) / 5
 tot = sum(ph.values())
+print(f"{v or 'intree':12s} isolated assembly pass {asm_ms:6.3f} ms", flush=True)
 print(f"{v or 'intree':12s} lin {ph['lin']:7.2f}  factor {ph['factor']:7.2f}  trial {ph['trial']:6.2f}  sum {tot:7.2f} ms  ({it / (tot * 1e-3):.0f} it/s, {r} rounds)", flush=True)
 ctx.close()
