@@ -896,36 +896,50 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
 
 // The far sums of block column J of a part, by one workgroup (a helper's -- or the owner's own, for a column no helper delivered in time:
 // one routine, one order of summation): the far tiles of tile row J staged in LDS (rowJ, slot J - K - 1), then far(I,J) for every row of the
-// column, the diagonal tile and the border -- one or two of them per wave, dealt by their number of products.  What is stored (agent scope)
-// is the tile the owner starts the column from: H(I,J)^T - far(I,J).  Every tile of a wave's item is requested before the first product.
-__device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_double* rowJ) {
-  constexpr int MAXN = WB - SFT_WIDE_NEAR;              // most far products of a tile
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nT = V.nT, nS = V.nS, tpr = V.tpr, wb = V.wb;
-  const int Ks = min(nS, J - SFT_WIDE_NEAR), K0d = max(0, J - wb);
-  if (Ks <= K0d) return;
-  const __amdgpu_buffer_rsrc_t rLt = wide_rsrc(V.Lt), rLbT = wide_rsrc(V.LbT);
-  const unsigned lane32 = 32u * lane;
-  const int crow = lane >> 4, ccol = lane & 15;
-  const unsigned ks8 = (unsigned)(tpr - 1) * (TS * TS * 8u);
-  // items by falling number of products: 0 border, 1 diagonal tile, i >= 2 row J + i - 1; wave w takes items w and 15 - w.  Every operand
-  // tile of an item is requested before its first product (the latency of one request, not of a chain of them, is what an item costs).
-  v4d bt[MAXN], h;
-  int n = 0, K0 = 0;
-  bool sq = false;
-  auto request = [&](int item) {
-    n = 0; sq = item == 1;
-    const int I = item <= 1 ? J : J + item - 1;
-    if (I >= nT || I - J > wb) return;
-    K0 = item == 0 ? K0d : max(0, I - wb);
+// column, the diagonal tile and the border.  Items by falling number of products: 0 border, 1 diagonal tile, i >= 2 row J + i - 1; wave w
+// takes item w (pass 1: up to MAXN products) and item 15 - w (pass 2: at most MAXN2).  What is stored (agent scope) is the tile the owner
+// starts the column from: H(I,J)^T - far(I,J).  Every operand tile of an item is requested before its first product -- and the steps are
+// separate so that a helper can request the tiles of its NEXT column while it multiplies this one's (FarColumn::*, factor_wide_helper).
+// How a helper loads the finished L tiles.  They were written -- at agent scope, through to memory -- by the owner's CU BEFORE the helper learnt
+// (from the owner's progress word) that they exist, and a tile is written once per launch: no cache on the helper's side can hold an older
+// version of it from this launch, and what earlier launches left was invalidated when this kernel started (that is how two kernels on different
+// XCDs see each other's results at all).  So a plain load is as correct as an agent-scope one here, and unlike it, it leaves the tile in the
+// helper's L2 -- each tile is an operand of up to twelve block columns, and a CU keeps only about 64 KB of misses in flight (32 GB/s at 2 us:
+// 7 us for the 240 KB of a column, measured, against 1.3 us of MFMA time).  -DSFT_FAR_LD_AGENT restores the agent-scope loads (A/B).
+#ifdef SFT_FAR_LD_AGENT
+#define FAR_LD_AUX 16
+#else
+#define FAR_LD_AUX 0
+#endif
+struct FarColumn {
+  static constexpr int MAXN = WB - SFT_WIDE_NEAR;       // most far products of a tile
+  static constexpr int MAXN2 = 5;                       // ... of an item of the second pass (items 8 .. 15: rows J + 7 and beyond)
+  static_assert(WB - SFT_WIDE_NEAR - 7 <= MAXN2 && WB - SFT_WIDE_NEAR >= 1, "FarColumn: the second pass holds at most MAXN2 operand tiles");
+  v4d bt[MAXN], bt2[MAXN2], h1, h2, areg[2];
+  int n1, n2, K01, K02, na;                             // products and first block column of the two items; tiles of row J this wave stages
+
+  // which tiles an item multiplies: I (row), K0, n; false: nothing to do
+  __device__ __forceinline__ static bool item_of(const WideView& V, int J, int item, int& I, int& K0, int& n) {
+    const int Ks = min(V.nS, J - SFT_WIDE_NEAR), K0d = max(0, J - V.wb);
+    I = item <= 1 ? J : J + item - 1;
+    K0 = item == 0 ? K0d : max(0, I - V.wb);
     n = Ks - K0;
-    if (n <= 0) { n = 0; return; }
-    const __amdgpu_buffer_rsrc_t r = item == 0 ? rLbT : rLt;
-    const unsigned b0 = item == 0 ? (unsigned)K0 * (TS * TS * 8u) : (unsigned)(wtile_off(tpr, K0, I - K0) * 8), bs = item == 0 ? (TS * TS * 8u) : ks8;
+    if (I >= V.nT || I - J > V.wb || n <= 0) { n = 0; return false; }
+    return true;
+  }
+  template <int N>
+  __device__ __forceinline__ static void request_item(const WideView& V, int J, int item, int lane, v4d (&b)[N], v4d& h, int& n, int& K0) {
+    int I;
+    if (!item_of(V, J, item, I, K0, n)) return;
+    n = min(n, N);
+    const __amdgpu_buffer_rsrc_t r = wide_rsrc(item == 0 ? V.LbT : V.Lt);
+    const unsigned lane32 = 32u * lane;
+    const unsigned b0 = item == 0 ? (unsigned)K0 * (TS * TS * 8u) : (unsigned)(wtile_off(V.tpr, K0, I - K0) * 8);
+    const unsigned bs = item == 0 ? (TS * TS * 8u) : (unsigned)(V.tpr - 1) * (TS * TS * 8u);
 #pragma unroll
-    for (int i = 0; i < MAXN; i++) bt[i] = tile_ld_rsrc(r, lane32, b0 + (unsigned)min(i, n - 1) * bs);
+    for (int i = 0; i < N; i++) b[i] = gb_ld<FAR_LD_AUX>(r, lane32, b0 + (unsigned)min(i, n - 1) * bs);
     if (item == 0) {
+      const int crow = lane >> 4, ccol = lane & 15;
       h = (v4d){0.0, 0.0, 0.0, 0.0};
       if (ccol < SFT_BORDER) {
 #pragma unroll
@@ -937,29 +951,59 @@ __device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_do
         }
       }
     } else {
-      h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(tpr, I, I - J) + 4 * lane);
+      h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(V.tpr, I, I - J) + 4 * lane);
     }
-  };
-  auto finish = [&](int item) {
+  }
+  template <int N>
+  __device__ __forceinline__ static void finish_item(const WideView& V, int J, int item, int lane, const lds_double* rowJ, const v4d (&b)[N], const v4d& h, int n, int K0) {
     if (n <= 0) return;
+    const bool sq = item == 1;
     v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < MAXN; i++)
-      if (i < n) wide_mfma4(sq ? bt[i] : wide_lds_read(rowJ + (size_t)(J - (K0 + i) - 1) * TS * TS, lane), bt[i], s0, s1);
+    for (int i = 0; i < N; i++)
+      if (i < n) wide_mfma4(sq ? b[i] : wide_lds_read(rowJ + (size_t)(J - (K0 + i) - 1) * TS * TS, lane), b[i], s0, s1);
     const v4d t = h - (s0 + s1);
     if (item == 0) tile_st_agent(V.PfB + (size_t)J * TS * TS + 4 * lane, t);
-    else tile_st_agent(V.Pf + wtile_off(tpr, J, item == 1 ? 0 : item - 1) + 4 * lane, t);
-  };
-  request(wave);
-  for (int s = wave; s < Ks - K0d; s += 8) {
-    const int K = K0d + s;
-    wide_lds_write(rowJ + (size_t)(J - K - 1) * TS * TS, lane, tile_ld_rsrc(rLt, lane32, (unsigned)(wtile_off(tpr, K, J - K) * 8)));
+    else tile_st_agent(V.Pf + wtile_off(V.tpr, J, item == 1 ? 0 : item - 1) + 4 * lane, t);
   }
+  __device__ __forceinline__ void request1(const WideView& V, int J, int wave, int lane) { request_item<MAXN>(V, J, wave, lane, bt, h1, n1, K01); }
+  __device__ __forceinline__ void request2(const WideView& V, int J, int wave, int lane) { request_item<MAXN2>(V, J, 15 - wave, lane, bt2, h2, n2, K02); }
+  // the far tiles of tile row J this wave brings to LDS (every eighth): requested into registers ...
+  __device__ __forceinline__ void requestA(const WideView& V, int J, int wave, int lane) {
+    const int Ks = min(V.nS, J - SFT_WIDE_NEAR), K0d = max(0, J - V.wb);
+    const __amdgpu_buffer_rsrc_t rLt = wide_rsrc(V.Lt);
+    na = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int K = K0d + wave + 8 * i;
+      if (K < Ks) { areg[i] = gb_ld<FAR_LD_AUX>(rLt, 32u * lane, (unsigned)(wtile_off(V.tpr, K, J - K) * 8)); na = i + 1; }
+    }
+  }
+  // ... and written to their slots J - K - 1
+  __device__ __forceinline__ void stageA(const WideView& V, int J, int wave, int lane, lds_double* rowJ) {
+    const int K0d = max(0, J - V.wb);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      if (i < na) wide_lds_write(rowJ + (size_t)(J - (K0d + wave + 8 * i) - 1) * TS * TS, lane, areg[i]);
+  }
+  __device__ __forceinline__ void finish1(const WideView& V, int J, int wave, int lane, const lds_double* rowJ) { finish_item<MAXN>(V, J, wave, lane, rowJ, bt, h1, n1, K01); }
+  __device__ __forceinline__ void finish2(const WideView& V, int J, int wave, int lane, const lds_double* rowJ) { finish_item<MAXN2>(V, J, 15 - wave, lane, rowJ, bt2, h2, n2, K02); }
+};
+
+__device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_double* rowJ) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (min(V.nS, J - SFT_WIDE_NEAR) <= max(0, J - V.wb)) return;
+  FarColumn F;
+  F.n1 = F.n2 = 0;
+  F.request1(V, J, wave, lane);
+  F.request2(V, J, wave, lane);
+  F.requestA(V, J, wave, lane);
+  F.stageA(V, J, wave, lane, rowJ);
   lds_barrier();
-  finish(wave);
-  request(15 - wave);
-  finish(15 - wave);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  F.finish1(V, J, wave, lane, rowJ);
+  F.finish2(V, J, wave, lane, rowJ);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();                                        // every wave's tiles have arrived
 }
 
@@ -969,31 +1013,40 @@ __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int 
 }
 
 // A helper workgroup of part `which` (see the comment in front of factor_wide): hidx of nh, block columns near + 1 + hidx, + nh, ...
-// For its column J it waits until the owner has finished the block columns below Ks = min(nS, J - near), forms the column (wide_far_column)
-// and raises its flag.  It never makes the owner wait: a column the owner has already decided about is skipped, and a helper whose owner
-// shows no progress (or is not there) leaves.
+// For its column J it waits until the owner has finished the block columns below Ks = min(nS, J - near), forms the column (FarColumn) and
+// raises its flag.  While it multiplies, the operand tiles of its next column are already on their way when the owner's progress allows
+// (a helper that cannot keep up with its owner is bound by what it multiplies then, not by one memory round trip per step).  It never makes
+// the owner wait: a column the owner has already decided about is skipped, and a helper whose owner shows no progress (or is not there) leaves.
 __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int hidx, int nh, int epoch, Ctl* ctl, double* ws) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WideView V = wide_view(P, which);
   if (V.sync == nullptr || nh <= 0) return;
   const int nT = V.nT, nS = V.nS, wb = V.wb;
   const int near = wide_near(wb);
   lds_double* rowJ = to_lds(ws);                        // far tiles of tile row J, slot J - K - 1 like the owner's
-  lds_int* cmd = (lds_int*)(rowJ + 2 * WB * TS * TS);   // thread 0's verdict on the column: 1 go, 0 skip, -1 leave
+  lds_int* cmd = (lds_int*)(rowJ + 2 * WB * TS * TS);   // thread 0's verdict: [0] this column: 1 go, 0 skip, -1 leave; [1] where to skip to; [2] the next column may be requested
   int polls_left = WIDE_HELPER_POLLS;
 #ifdef DSH_LAB
   int st_done = 0, st_skip = 0;
-  long long st_wait = 0, st_work = 0;
+  long long st_wait = 0, st_work = 0, st_seg[4] = {0, 0, 0, 0};
+#define HT_SEG(i) do { const long long t__ = wall_clock64(); st_seg[i] += t__ - ht0; ht0 = t__; } while (0)
+#else
+#define HT_SEG(i) do {} while (0)
 #endif
+  FarColumn F;
+  F.n1 = F.n2 = F.na = 0;
+  bool have = false;                                    // the tiles of column J have been requested (in the iteration before)
   int J = near + 1 + hidx;
 #pragma unroll 1
   while (J < nT) {
     const int Ks = min(nS, J - near), K0d = max(0, J - wb);
+    const int Jn = J + nh, Ksn = min(nS, Jn - near);
 #ifdef DSH_LAB
     const long long t0 = wall_clock64();
 #endif
     if (tid == 0) {
-      int c = 0;
+      int c = 0, nx = 0;
       while (true) {
         const int w = __hip_atomic_load(V.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int cols = (w >> 16) == epoch ? (w & 0xffff) : 0;
@@ -1003,14 +1056,15 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int 
           c = 0;
           break;
         }
-        if (cols >= Ks) { c = 1; break; }
+        if (cols >= Ks) { c = 1; nx = Jn < nT && cols >= Ksn && cols < Jn - 1; break; }
         if (--polls_left <= 0) { c = -1; break; }
         __builtin_amdgcn_s_sleep(4);
       }
       cmd[0] = c;
+      cmd[2] = nx;
     }
     __syncthreads();
-    const int go = uni(cmd[0]), Jskip = uni(cmd[1]);
+    const int go = uni(cmd[0]), Jskip = uni(cmd[1]), next_ok = uni(cmd[2]);
     __syncthreads();                                      // (cmd is rewritten for the next column)
 #ifdef DSH_LAB
     const long long t1 = wall_clock64();
@@ -1021,18 +1075,41 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int 
     }
 #endif
     if (go < 0) return;
-    if (go == 0) { J = Jskip; continue; }
-    if (Ks <= K0d) { J += nh; continue; }
-    wide_far_column(V, J, rowJ);
+    if (go == 0) { J = Jskip; have = false; continue; }
+    if (Ks <= K0d) { J += nh; have = false; continue; }
+    if (!have) {
+      F.request1(V, J, wave, lane);
+      F.request2(V, J, wave, lane);
+      F.requestA(V, J, wave, lane);
+    }
+#ifdef DSH_LAB
+    long long ht0 = t1;
+#endif
+    F.stageA(V, J, wave, lane, rowJ);
+    lds_barrier();
+    HT_SEG(0);
+    F.finish1(V, J, wave, lane, rowJ);                    // (its result is stored at once: done long before the column's flag)
+    if (next_ok) { F.request1(V, Jn, wave, lane); F.requestA(V, Jn, wave, lane); }
+    HT_SEG(1);
+    F.finish2(V, J, wave, lane, rowJ);
+    if (next_ok) F.request2(V, Jn, wave, lane);
+    HT_SEG(2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // this column's tiles have arrived (and the next one's operands)
+    __syncthreads();
+    HT_SEG(3);
     if (tid == 0) __hip_atomic_store(V.sync + WIDE_SYNC_READY + J, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef DSH_LAB
     st_work += wall_clock64() - t1;
     st_done++;
 #endif
-    J += nh;
+    have = next_ok != 0;
+    J = Jn;
   }
 #ifdef DSH_LAB
-  if (tid == 0) { atomicAdd((int*)V.sync + 5, st_done); atomicAdd((int*)V.sync + 6, st_skip); atomicAdd((int*)V.sync + 7, (int)st_wait); atomicAdd((int*)V.sync + 8, (int)st_work); }
+  if (tid == 0) {
+    atomicAdd((int*)V.sync + 5, st_done); atomicAdd((int*)V.sync + 6, st_skip); atomicAdd((int*)V.sync + 7, (int)st_wait); atomicAdd((int*)V.sync + 8, (int)st_work);
+    for (int i = 0; i < 4; i++) atomicAdd((int*)V.sync + 9 + i, (int)st_seg[i]);
+  }
 #endif
 }
 

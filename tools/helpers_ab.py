@@ -57,6 +57,8 @@ for cfg in cfgs:
             for g in (0, 1):   # statistics of lane 0's part g over the 6 runs since the upload (lab build): owner / helper counters, 100 MHz ticks
                 try:
                     w = ctx.dump(0, 8 + g, 8).view(np.int32)
+                    if w[5]:
+                        print("      helper segments, us per column: stage + barrier %.2f, pass 1 (+ next requests) %.2f, pass 2 %.2f, drain + barrier %.2f" % tuple(w[9 + i] * 1e-2 / w[5] for i in range(4)))
                 except Exception as e:  # noqa: BLE001
                     print("   no statistics:", e)
                     break
