@@ -98,7 +98,7 @@ __device__ __forceinline__ int wide_near(int wb) { return SFT_WIDE_NEAR; }
 #ifndef WIDE_OWNER_POLLS
 #define WIDE_OWNER_POLLS 24         // how often the owner looks for a helper's column before it forms the far sums itself
 #endif
-#define WIDE_HELPER_POLLS 40000     // a helper that sees no progress of its owner for this long leaves
+#define WIDE_HELPER_POLLS 400       // a helper that sees no progress of its owner for this many looks (about half a millisecond) leaves: its CU may be what the owner waits for
 
 __device__ __forceinline__ v4d tile_ld_agent(const SFT_G double* p) {
   v4d r;
@@ -1026,7 +1026,7 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int 
   const int near = wide_near(wb);
   lds_double* rowJ = to_lds(ws);                        // far tiles of tile row J, slot J - K - 1 like the owner's
   lds_int* cmd = (lds_int*)(rowJ + 2 * WB * TS * TS);   // thread 0's verdict: [0] this column: 1 go, 0 skip, -1 leave; [1] where to skip to; [2] the next column may be requested
-  int polls_left = WIDE_HELPER_POLLS;
+  int polls_left = WIDE_HELPER_POLLS, cols_seen = -1;
 #ifdef DSH_LAB
   int st_done = 0, st_skip = 0;
   long long st_wait = 0, st_work = 0, st_seg[4] = {0, 0, 0, 0};
@@ -1057,6 +1057,7 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int 
           break;
         }
         if (cols >= Ks) { c = 1; nx = Jn < nT && cols >= Ksn && cols < Jn - 1; break; }
+        if (cols != cols_seen) { cols_seen = cols; polls_left = WIDE_HELPER_POLLS; }   // the owner moves: the patience starts over
         if (--polls_left <= 0) { c = -1; break; }
         __builtin_amdgcn_s_sleep(4);
       }

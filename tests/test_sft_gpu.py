@@ -830,3 +830,51 @@ def test_changing_view_sequence_through_the_graph_cache(gpu_ctx, oracle_mod):
             tc, args = oracle_args(oracle_mod, tmpl, fr)
             r = oracle_mod.sft_solve(*args)
             _compare(f, inl, r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+
+
+@pytest.mark.parametrize("cfg,batch", [("W16", 1), ("W12", 3), ("C5", 1), ("W16", 40)])
+def test_helper_workgroups_of_the_two_sided_factorisation_do_not_change_a_bit(lab_ctx, oracle_mod, cfg, batch):
+    """Wide bands in latency mode: helper workgroups form the far products of a part's block columns on other CUs (sft_wide.h: factor_part,
+    factor_wide_helper).  The owner takes a helper's column when it is there and forms it itself -- same routine, same order -- when it is not, so
+    every setting must give the SAME BITS: no helpers (the owner is factor_wide), one to three per part with four or two lanes, and a launch with
+    several times more workgroups than the device has CUs (40 problems x 4 lanes x 2 parts x 4 roles: helpers that start late or never, owners that
+    fall back, helpers that skip).  The first problem also against the oracle (not the full-size C5: its dense CPU solve takes minutes and
+    test_hip_matches_golden_vectors_full_size_c5 holds that comparison)."""
+    from defslam_amd import sft, synth
+    rows, cols, m = synth.CONFIGS[cfg]
+    tmpl = synth.make_grid_template(rows, cols)
+    lab_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = [synth.make_frame(tmpl, m, p) for p in range(batch)]
+    ref = None
+    settings = [(4, 0), (4, 3), (4, 1), (2, 2), (4, -1)] if batch < 8 else [(4, 0), (4, 3), (2, 3)]
+    try:
+        for K, nh in settings:
+            lab_ctx.set_option("speculate", K)
+            lab_ctx.set_option("helpers", nh)
+            frames = [sft.frame_from_synth(fr) for fr in syn]
+            lab_ctx.batch_upload(frames, *regs, 1, 50)
+            info = lab_ctx.solver_info(0)
+            assert info["split"] == 1 and info["lanes"] == K and info["tile_mode"] == 2
+            lab_ctx.batch_run()
+            inl = lab_ctx.batch_download()
+            res = [(int(i), f.iters, f.trials, f.nodes_xyz.copy(), f.pose7.copy(), f.chi2_obs.copy(), f.mvbOutlier.copy(), f.trace.copy()) for i, f in zip(inl, frames)]
+            if ref is None:
+                ref = res
+                continue
+            for p, (a, b) in enumerate(zip(ref, res)):
+                assert a[:3] == b[:3], (K, nh, p)
+                for u, v in zip(a[3:], b[3:]):
+                    np.testing.assert_array_equal(u, v, err_msg=f"lanes {K}, helpers {nh}, problem {p}")
+    finally:
+        lab_ctx.set_option("speculate", 0)
+        lab_ctx.set_option("helpers", -1)
+    if cfg == "C5":
+        return
+    fr = syn[0]
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+    a = ref[0]
+    assert (a[1], a[2], a[0]) == (r.iters, r.trials, r.ret)
+    assert np.abs(a[3] - r.xyz).max() <= 1e-7 * np.abs(r.xyz).max() and np.abs(a[4] - r.pose7).max() <= 1e-8
+    np.testing.assert_array_equal(a[6], np.asarray(r.outlier, bool))
