@@ -10,7 +10,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-hostname > $OUT/box.txt; (rocm-smi --showproductname 2>/dev/null | head -12; lscpu | grep "Model name") >> $OUT/box.txt
+(hostname; rocm-smi --showuniqueid --showserial --showproductname 2>/dev/null | grep -i "unique\|serial\|Card Model\|Node ID"; lscpu | grep "^Model name"; date -u) > $OUT/box.txt
 python bench.py > $OUT/bench_plain.log 2> $OUT/bench_plain.err
 cd /tmp
 BA="--no-cpu-baseline --no-extra-legs"
