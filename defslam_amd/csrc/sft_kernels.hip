@@ -3238,7 +3238,7 @@ extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles) {
   if (backsub > panel) panel = backsub;
   const size_t tiles = (size_t)(BT + 2 * (BT + 1) + 3) * TILE_LDS + 3 * SFT_BORDER * TS + 64 + 48 + 128 + 128;  // dataflow layout (the larger one) + step-trace stamps
   if (kd <= TS * BT) panel = tiles;
-  else if (kd <= TS * WB) panel = std::max(panel, std::max((size_t)2 * WB * TS * TS + TILE_LDS + 704, (size_t)(SFT_WIDE_NEAR + 2) * SFT_WIDE_NEAR * TS * TS + 2 * TILE_LDS + 704 + (size_t)32 * TS * TS + (size_t)(WB - SFT_WIDE_NEAR) * TS * TS));   // wide mode: two staged tile rows, W, corners (or the band panel)
+  else if (kd <= TS * WB) panel = std::max(panel, std::max((size_t)2 * WB * TS * TS + TILE_LDS + 704, (size_t)(SFT_WIDE_NEAR + 2) * SFT_WIDE_NEAR * TS * TS + 2 * TILE_LDS + 704 + (size_t)32 * TS * TS + (size_t)(WB - SFT_WIDE_NEAR + 1) * TS * TS));   // wide mode: two staged tile rows, W, corners (or the band panel)
   if (jl_doubles > panel) panel = jl_doubles;
   return 512 + (16 * 27 + 5 + 32 + panel) * sizeof(double) + 64;
 }

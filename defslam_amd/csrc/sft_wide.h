@@ -588,6 +588,9 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
   lds_double* Land = Cn + 704;                             // [wave * 4 + slot]: where the start tiles of a wave's next column land (slot 3: border / diagonal tile)
   // the staging area of wide_far_column when the owner forms a column itself: far tiles sit in its slots NEAR .. wb-1, the area starts there
   lds_double* Fstage = Land + 32 * TS * TS - NEAR * TS * TS;
+  // the diagonal tile of the next block column on its way from the wave that forms it to the wave that factors it (below), and its flag
+  lds_double* Dt = Land + (32 + WB - NEAR) * TS * TS;
+  lds_int* dflag = (lds_int*)(Cn + 648);
   lds_double* myland = Land + (size_t)wave * 4 * TS * TS;
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;
@@ -625,7 +628,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
       if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = V.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
     }
   }
-  if (tid == 0) ctl->fact_ok = 1;
+  if (tid == 0) { ctl->fact_ok = 1; *dflag = 0; }
   if (tid < 4) hflag[tid] = 0;
 #ifdef SFT_WIDE_TRACE
   lds_double* wtrace = Cn + 580;
@@ -780,7 +783,11 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
           wide_mfma4(xT, xT, t0, t1);
           dt -= t0 + t1;
         }
-        pivot(Ip, dt);
+        // The Cholesky of that tile (1.3 us of dependent operations) is not this wave's: it owns two full rows and was the one every other wave
+        // waited for at the barrier.  The wave of the CURRENT pivot row has the least to do in this column (its first row is eliminated): it
+        // takes the tile through LDS (flag behind the data) and publishes W_{J+1} in front of the barrier.
+        wide_lds_write(Dt, lane, dt);
+        flag_set(dflag, Ip);
         if (J + 1 < nT) {
 #pragma unroll
           for (int t = 0; t < 3; t++) request_tile(t, nI[t], J + 1);
@@ -855,6 +862,10 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, d
         }
         preS = s0 + s1;
       }
+    }
+    if (d == 0 && J + 1 < nT) {   // the pivot chain's last link (see above)
+      flag_wait(dflag, J + 1);
+      pivot(J + 1, wide_lds_read(Dt, lane));
     }
     WT_SEG(4);
     look_for_helper(J);
