@@ -734,6 +734,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     for (int b = 0; b < B; b++) any = any || (c->packed[b].h.split != 0 && c->packed[b].h.wbt >= 12);
     if (any && K > 1 && !c->force_split) {
       while (nh < 3 && (long long)B * K * 2 * (2 + nh) <= c->num_cus) nh++;
+      if (nh == 1) nh = 0;                            // (one helper cannot feed its owner: 8.5 against 7 us per block column -- measured slower than none)
       if (c->opt.helpers >= 0) nh = c->opt.helpers;   // lab builds only
     }
   }
