@@ -732,6 +732,8 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     // C2, 8 tiles: 4.4 against 4.0 ms per frame with helpers)
     bool any = false;
     for (int b = 0; b < B; b++) any = any || (c->packed[b].h.split != 0 && c->packed[b].h.wbt >= 12);
+    for (int b = 0; b < B; b++)   // (the owner's progress word keeps the finished block columns in 16 bits)
+      if (c->packed[b].h.split && std::max(c->packed[b].h.part[0].nT, c->packed[b].h.part[1].nT) >= 60000) any = false;
     if (any && K > 1 && !c->force_split) {
       while (nh < 3 && (long long)B * K * 2 * (2 + nh) <= c->num_cus) nh++;
       if (nh == 1) nh = 0;                            // (one helper cannot feed its owner: 8.5 against 7 us per block column -- measured slower than none)
