@@ -34,7 +34,13 @@ extern "C" {
  *              left-looking wide-tile code as well (C2: 4.1 ms per frame against 4.5 on the register-window solver of one workgroup)
  *              while the launch holds at most num_cus / 20 problems (beyond that the register-window solver wins),
  *              1 = wide bands (128 < kd <= 256) only, 0 = one factorisation of the whole band (the same Cholesky in another
- *              elimination order: trajectories agree, numbers to rounding) */
+ *              elimination order: trajectories agree, numbers to rounding)
+ *   "helpers"  -1 (default) = automatic: two or three helper workgroups per part of a two-sided factorisation of a wide band (at least 12
+ *              sub-diagonal tiles) when the device holds them all (B x lanes x 2 x (1 + helpers) <= CUs); 0..3 = that many -- the results are
+ *              the same bits for every value (sft_wide.h: the owner forms a far sum itself whenever a helper's is not there)
+ *   "tail"     2 (default) = the last problems of a step of the throughput shape -- from two per CU downwards -- are run to their end by
+ *              sftb_tail_kernel (one workgroup per problem); 1..8 = another threshold in problems per CU, 0 = rounds of phase kernels to the end
+ *              (the eight-wavefront solver of the tail kernel rounds differently from the one-wavefront solver: same trajectories, x to 5e-13) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
 /* How problem b of the uploaded batch is solved: out[8] = {two-sided factorisation on?, first separator scalar c0, separator
  * scalars s, scalars of part 1 incl. padding, its padding, workgroups (lanes) per problem, tile mode, wavefronts per workgroup}. */
@@ -60,7 +66,8 @@ int dsh_lab_sft_wave_check(dsh_ctx* ctx, double rel, int launches, int only, dou
  * What bench.py's roofline objects are computed from (sftb_factor_kernel: FP64; sftb_lin_kernel: the Jacobian assembly). */
 int dsh_lab_sft_rounds_timed(dsh_ctx* ctx, double* ms7, int32_t* rounds);
 /* n doubles of a workspace array of problem b: what = 0 L tiles, 1 inverse diagonal tiles, 2 border rows of L, 3 compact H blocks, 4 border rows
- * of H, 5 x, 6 corner of H, 7 debug slots (tuning aid; no bounds check beyond n > 0). */
+ * of H, 5 x, 6 corner of H, 7 debug slots, 8 / 9 the sync words of part 0 / 1 of a two-sided factorisation with helper workgroups (int32: [0] the
+ * owner's progress, [1..4] owner statistics, [5..12] helper statistics; fails when the problem has none) (tuning aid; no bounds check beyond n > 0). */
 int dsh_lab_sft_dump(dsh_ctx* ctx, int b, int what, int64_t n, double* out);
 /* Per-phase device time of problem b in the last run, milliseconds (constant 100 MHz counter read by one lane):
  * out8[1] residuals, [2] normal-equation assembly, [3] H->L copy, [4] panel factorisation, [5] trailing update,
