@@ -48,7 +48,10 @@ struct WideView {
   SFT_G double *Pf, *PfB;            // parts: the far sums of a block column formed by helper workgroups (factor_wide_helper)
   SFT_G int32_t* sync;               // parts: [0] the owner's progress word, [WIDE_SYNC_READY + J] column J's far sums are in Pf / PfB
 };
-__device__ __forceinline__ WideView wide_view(const SftDev& P, int which) {
+__device__ __forceinline__ WideView wide_view(const SftDev& P, int which_) {
+  // (an argument of a non-inlined function arrives in a vector register: without this every field below, selected by branches on it, counts as
+  // divergent -- and every comparison with nT, nS, wb in the callers becomes a vector compare and an exec-mask branch)
+  const int which = __builtin_amdgcn_readfirstlane(which_);
   WideView v;
   const int Dn = uni(P.Dn), Dnp = ((Dn + NB - 1) / NB) * NB;
   if (which < 0) {
@@ -571,7 +574,8 @@ __device__ __forceinline__ void wide_dma_tile(lds_double* dst, const SFT_G doubl
 }
 
 template <int NEAR>
-__device__ __noinline__ void factor_part(const SftDev& P, int which, Ctl* ctl, double* ws, int epoch, int nh) {
+__device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, double* ws, int epoch_, int nh_) {
+  const int which = __builtin_amdgcn_readfirstlane(which_), epoch = __builtin_amdgcn_readfirstlane(epoch_), nh = __builtin_amdgcn_readfirstlane(nh_);   // (arguments arrive in vector registers)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WideView V = wide_view(P, which);
@@ -1018,8 +1022,9 @@ __device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_do
   __syncthreads();                                        // every wave's tiles have arrived
 }
 
-__device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J, lds_double* rowJ) {
+__device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J_, lds_double* rowJ) {
   const WideView V = wide_view(P, which);
+  const int J = __builtin_amdgcn_readfirstlane(J_);
   wide_far_column(V, J, rowJ);
 }
 
@@ -1028,7 +1033,8 @@ __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int 
 // raises its flag.  While it multiplies, the operand tiles of its next column are already on their way when the owner's progress allows
 // (a helper that cannot keep up with its owner is bound by what it multiplies then, not by one memory round trip per step).  It never makes
 // the owner wait: a column the owner has already decided about is skipped, and a helper whose owner shows no progress (or is not there) leaves.
-__device__ __noinline__ void factor_wide_helper(const SftDev& P, int which, int hidx, int nh, int epoch, Ctl* ctl, double* ws) {
+__device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int hidx_, int nh_, int epoch_, Ctl* ctl, double* ws) {
+  const int which = __builtin_amdgcn_readfirstlane(which_), hidx = __builtin_amdgcn_readfirstlane(hidx_), nh = __builtin_amdgcn_readfirstlane(nh_), epoch = __builtin_amdgcn_readfirstlane(epoch_);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const WideView V = wide_view(P, which);
