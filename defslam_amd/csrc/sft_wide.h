@@ -48,10 +48,13 @@ struct WideView {
   SFT_G double *Pf, *PfB;            // parts: the far sums of a block column formed by helper workgroups (factor_wide_helper)
   SFT_G int32_t* sync;               // parts: [0] the owner's progress word, [WIDE_SYNC_READY + J] column J's far sums are in Pf / PfB
 };
+template <bool UNIFORM = true>
 __device__ __forceinline__ WideView wide_view(const SftDev& P, int which_) {
   // (an argument of a non-inlined function arrives in a vector register: without this every field below, selected by branches on it, counts as
-  // divergent -- and every comparison with nT, nS, wb in the callers becomes a vector compare and an exec-mask branch)
-  const int which = __builtin_amdgcn_readfirstlane(which_);
+  // divergent -- and every comparison with nT, nS, wb in the callers becomes a vector compare and an exec-mask branch.  factor_part and the
+  // helpers gain 6 % of a C5 frame from it; factor_wide / backsub_wide, bound by their barriers and tile loads, measured 2-5 % SLOWER with scalar
+  // branches -- the predicated code lets the compiler hoist loads across them -- and keep the vector form: UNIFORM = false)
+  const int which = UNIFORM ? __builtin_amdgcn_readfirstlane(which_) : which_;
   WideView v;
   const int Dn = uni(P.Dn), Dnp = ((Dn + NB - 1) / NB) * NB;
   if (which < 0) {
@@ -235,7 +238,7 @@ __device__ __forceinline__ v4d wide_squares(int n, LD ld) {
 __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, double* ws) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WideView V = wide_view(P, which);
+  const WideView V = wide_view<false>(P, which);
   const int nT = V.nT, nS = V.nS;
   const int tpr = V.tpr, wb = V.wb;
   const int Dnp = TS * nT;
@@ -1141,7 +1144,7 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, 
   if (!ctl->fact_ok) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WideView V = wide_view(P, which);
+  const WideView V = wide_view<false>(P, which);
   const int nT = V.nT, nS = V.nS;
   const int Dnp = TS * nT;
   const int tpr = V.tpr, wb = V.wb;
