@@ -28,12 +28,12 @@ extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, si
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, int tail_below, hipStream_t stream);
 extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
-extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int owner_waves, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 
 // The dynamic LDS size a kernel has been enabled for (hipFuncSetAttribute) is a property of the (device, kernel) pair, not of a context: two
 // contexts on one GPU -- tracking and mapping, say -- must not lower each other's setting.  One high-water mark per device and kernel for the
 // whole process; the launchers only ever raise it, under this lock.
-struct LdsMarks { size_t lm[2] = {0, 0}, sc = 0, spec = 0, cn = 0, b[2] = {0, 0}, tail = 0; };
+struct LdsMarks { size_t lm[2] = {0, 0}, sc = 0, spec[2] = {0, 0}, cn = 0, b[2] = {0, 0}, tail = 0; };
 static LdsMarks g_lds_marks[64];
 static std::mutex g_lds_mu;
 #define LDS_MARKS(c) (g_lds_marks[(c)->device & 63])
@@ -164,7 +164,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = 2; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = 2; int owner_waves = 8; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -393,7 +393,7 @@ int run_once(dsh_ctx* c) {
   // launch.  First group: as many rounds as the previous run of this context needed (tracking is coherent from frame to frame:
   // usually exact), then the done flags are read back and rounds of two are added while a problem still runs.  Launches behind the
   // end of a problem cost a few microseconds each (it leaves at the first instruction); a read-back costs a stream synchronisation.
-  auto launch = [&](int phase) { LDS_LOCK(); return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->spec_nh, c->max_kd, c->jl_doubles, &LDS_MARKS(c).spec, c->stream); };
+  auto launch = [&](int phase) { LDS_LOCK(); return sft_spec_launch(c->d_probs, c->d_spec, B, K, phase, c->spec_nh, c->opt.owner_waves, c->max_kd, c->jl_doubles, LDS_MARKS(c).spec, c->stream); };
   if (c->spec_nh > 0) HIPCHK(c, hipMemsetAsync(c->d_sync, 0, c->sync_bytes, c->stream));   // progress words and column flags of the helper workgroups: epochs count from here
   HIPCHK(c, launch(SFT_SPEC_INIT));
   int rounds = 0, group = std::max(2, std::min(worst, c->spec_hint));
@@ -1348,6 +1348,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "rounds") c->opt.rounds = value != 0;
   else if (k == "streams") { if (value < 0 || value > dsh_ctx::kMaxSub) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: streams is 0 (automatic) or 1..4 sub-batches"); c->opt.streams = value; }
   else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
+  else if (k == "owner_waves") { if (value != 8 && value != 16) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: owner_waves is 8 or 16 (wavefronts of a FACTOR workgroup with helpers)"); c->opt.owner_waves = value; }
   else if (k == "helpers") { if (value < -1 || value > 3) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers is -1 (automatic) or 0..3 workgroups per part"); c->opt.helpers = value; }
   else if (k == "tail") { if (value < 0 || value > 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: tail is 0 (rounds to the end) or the number of problems per CU from which downwards the last problems go to the tail kernel (default 2)"); c->opt.tail = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }

@@ -2792,16 +2792,38 @@ __global__ __launch_bounds__(64 * NW, SFT_WAVES_PER_EU) void sft_spec_kernel(con
     const int red = 2 + fpart;
     const int xl = P.sp_xl;
     const auto x0 = P.part[0].xchg, x1 = P.part[1].xchg, xs = P.part[red].xchg;
-    for (int i = tid; i < xl; i += NT) xs[i] = x0[i] + x1[i];
+#ifdef SFT_SOLVE_TRACE
+    long long st_t[6]; st_t[0] = wall_clock64(); const long long st_c0 = clock64();
+#define ST_MARK(i) st_t[i] = wall_clock64()
+#else
+#define ST_MARK(i) do {} while (0)
+#endif
+    {   // (four independent pairs of loads per thread and trip: the loop is bound by the latency of its loads)
+      int i = tid;
+      for (; i + 3 * NT < xl; i += 4 * NT) {
+        const double a0 = x0[i], a1 = x0[i + NT], a2 = x0[i + 2 * NT], a3 = x0[i + 3 * NT];
+        const double b0 = x1[i], b1 = x1[i + NT], b2 = x1[i + 2 * NT], b3 = x1[i + 3 * NT];
+        xs[i] = a0 + b0; xs[i + NT] = a1 + b1; xs[i + 2 * NT] = a2 + b2; xs[i + 3 * NT] = a3 + b3;
+      }
+      for (; i < xl; i += NT) xs[i] = x0[i] + x1[i];
+    }
     __syncthreads();
+    ST_MARK(1);
     const int nTr = P.part[2].nT;
     const bool parts_ok = xs[(size_t)nTr * P.part[2].tpr * (TS * TS) + (size_t)8 * TS * nTr + 56] == 0.0;
     __syncthreads();
     if (parts_ok) factor_wide(P, red, ctl, panel);
     else if (tid == 0) ctl->fact_ok = 0;
     __syncthreads();
+    ST_MARK(2);
     backsub_wide(P, red, ctl, panel);
+    ST_MARK(3);
     backsub_wide(P, fpart, ctl, panel, red);
+    ST_MARK(4);
+#ifdef SFT_SOLVE_TRACE
+    if (tid == 0 && j == 0) for (int i = 0; i < 4; i++) P.dbg[96 + 8 * fpart + i] = (double)(st_t[i + 1] - st_t[i]);
+    if (tid == 0 && j == 0) P.dbg[96 + 8 * fpart + 4] = (double)(clock64() - st_c0) / (double)(st_t[4] - st_t[0]);   // shader clocks per 10 ns
+#endif
     const int okf = ctl->fact_ok;
     if (okf) {   // this workgroup's share of the solution in the natural ordering
       const int c0 = P.sp_c0, sp = P.sp_s, pad = P.sp_pad, n1p = P.sp_n1p;
@@ -3288,6 +3310,46 @@ extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, in
   return hipGetLastError();
 }
 
+#ifdef DSH_LAB   // an A/B variant (lab option owner_waves 16; measured slower than eight wavefronts: DESIGN 4.2)
+// The FACTOR launch of sft_spec_kernel for parts with helper workgroups, SIXTEEN wavefronts per workgroup (128 registers per lane): the owner
+// of a part keeps one live row per wave (factor_part<NEAR, 16>), a helper one item per wave (FarColumn16).  Same grid layout (role-major), same
+// early exits, same damping as the FACTOR branch of sft_spec_kernel; results bit-identical to it.
+__global__ __launch_bounds__(1024) void sft_part_factor_kernel(const SftDev* __restrict__ probs, SftSpec* __restrict__ specs, int K, int nh) {
+  constexpr int NT = 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int roles = 1 + nh, per_role = gridDim.x / roles;
+  const int role = blockIdx.x / per_role, bid = blockIdx.x % per_role;
+  const int fpart = bid % 2, bx = bid / 2;
+  const int B = per_role / (K * 2), b = bx / K, j = bx % K;
+  const SftDev& P = probs[(size_t)j * B + b];
+  const SftSpec& S = specs[(size_t)j * B + b];
+  Ctl* ctl = reinterpret_cast<Ctl*>(smem);
+  double* red = reinterpret_cast<double*>(smem + 512);
+  double* panel = red + 16 * 27 + 5 + 32;
+  const int tid = threadIdx.x;
+  if (S.done) return;
+  if (!(P.tile_mode == 2 && P.split) || S.need_lin == 1) return;
+  if (S.qbase + j >= 10) return;
+  const int epoch = S.launches + 1;
+  if (role > 0) {
+    factor_wide_helper<16>(P, fpart, role - 1, nh, epoch, ctl, panel);
+    return;
+  }
+  double lam = S.lambda, ni = S.ni;
+  if (S.need_lin == 2 && S.it == 0) {
+    double mx = 0.0;
+    for (int r = tid; r < P.Dn; r += NT) mx = fmax(mx, fabs(h_diag(P, r)));
+    if (tid < 6) mx = fmax(mx, fabs(P.Hcorner[tid * 8]));
+    mx = block_max(mx, red);
+    lam = 1e-5 * mx; ni = 2.0;
+  }
+  for (int t = 0; t < j; t++) { lam *= ni; ni *= 2.0; }
+  if (tid == 0) ctl->lambda = lam;
+  __syncthreads();
+  factor_part<SFT_WIDE_NEAR, 16>(P, fpart, ctl, panel, epoch, nh);
+}
+#endif  // DSH_LAB
+
 // out_a[i] = out_b[i] = a[i] + b[i]: the in-process stand-in of a two-rank all-reduce (dsh_sft_connected_solve_group); in place is fine
 __global__ void sft_vec_sum2_kernel(const double* a, const double* b, double* out_a, double* out_b, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -3301,8 +3363,20 @@ extern "C" hipError_t sft_vec_sum2(const double* a, const double* b, double* out
   return hipGetLastError();
 }
 
-extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
+// configured: two marks (sft_spec_kernel<8>, sft_part_factor_kernel).  owner_waves 16 (lab builds): a FACTOR launch with helpers runs sft_part_factor_kernel
+extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int owner_waves, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream) {
   const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);
+#ifdef DSH_LAB
+  if (phase == SFT_SPEC_FACTOR && nh > 0 && owner_waves == 16) {
+    if (lds > configured[1]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_part_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      configured[1] = lds;
+    }
+    hipLaunchKernelGGL(sft_part_factor_kernel, dim3(B * K * 2 * (1 + nh)), dim3(1024), lds, stream, d_probs, d_spec, K, nh);
+    return hipGetLastError();
+  }
+#endif
   if (lds > *configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sft_spec_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

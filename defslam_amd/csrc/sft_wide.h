@@ -505,7 +505,7 @@ __device__ __noinline__ void factor_wide(const SftDev& P, int which, Ctl* ctl, d
   __syncthreads();
 }
 
-__device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J, lds_double* rowJ);   // (the view is rebuilt there: the caller's stays in registers)
+template <int NW> __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J, lds_double* rowJ);   // (the view is rebuilt there: the caller's stays in registers)
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // The owner of a part when helper workgroups deliver the far sums (latency mode; the arithmetic, order for order, of factor_wide(P, part)
@@ -576,8 +576,17 @@ __device__ __forceinline__ void wide_dma_tile(lds_double* dst, const SFT_G doubl
                  :: "s"(la), "s"(tile), "v"(lane32), "v"(lane32 + 16u) : "memory", "m0");
 }
 
-template <int NEAR>
+// NW: wavefronts of the workgroup.  8: the layout above.  16 (sft_part_factor_kernel, 128 registers per lane): row I on wave I mod 16 -- ONE live
+// row per wave, the pivot wave holds none but the entering one -- so four wavefronts per SIMD interleave where two did: what bounds a column is
+// the latency of its dependent steps, not what the SIMDs could issue.  Same arithmetic, same order: the two are interchangeable bit for bit
+// (the corner's eight partial sums live in LDS there: the border role visits sixteen waves, the partials are numbered by column).
+template <int NEAR, int NW = 8>
 __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, double* ws, int epoch_, int nh_) {
+  static_assert(NW == 8 || NW == 16, "factor_part: 8 or 16 wavefronts");
+  constexpr int RPW = 16 / NW;                       // live rows of a wave (besides the entering one on the pivot wave)
+  constexpr int SE = NW == 16 ? 0 : RPW;             // landing slot of the entering row (16 waves: the pivot wave's row slot is free)
+  constexpr int SX = NW == 16 ? 1 : RPW + 1;         // ... of the diagonal / border tile
+  constexpr int SLOTS = SX + 1;
   const int which = __builtin_amdgcn_readfirstlane(which_), epoch = __builtin_amdgcn_readfirstlane(epoch_), nh = __builtin_amdgcn_readfirstlane(nh_);   // (arguments arrive in vector registers)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -598,7 +607,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
   // the diagonal tile of the next block column on its way from the wave that forms it to the wave that factors it (below), and its flag
   lds_double* Dt = Land + (32 + WB - NEAR) * TS * TS;
   lds_int* dflag = (lds_int*)(Cn + 648);
-  lds_double* myland = Land + (size_t)wave * 4 * TS * TS;
+  lds_double* myland = Land + (size_t)wave * SLOTS * TS * TS;
   const double lambda = ctl->lambda;
   const int crow = lane >> 4, ccol = lane & 15;
   const auto Hg = V.Hb;
@@ -624,8 +633,8 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
     else wide_dma_tile<false>(myland + slot * TS * TS, Hg + wtile_off(tpr, I, I - J), lane32);
   };
   auto request_border = [&](int J) {
-    if (ksplit(J) > max(0, J - wb)) wide_dma_tile<true>(myland + 3 * TS * TS, V.PfB + (size_t)J * TS * TS, lane32);
-    else wide_lds_write(myland + 3 * TS * TS, lane, bord_tile(J));
+    if (ksplit(J) > max(0, J - wb)) wide_dma_tile<true>(myland + SX * TS * TS, V.PfB + (size_t)J * TS * TS, lane32);
+    else wide_lds_write(myland + SX * TS * TS, lane, bord_tile(J));
   };
   v4d cacc = zero4;
   if (wave == 0 && V.corner_from_H) {
@@ -635,11 +644,20 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
       if (r < SFT_BORDER && ccol < SFT_BORDER && ccol <= r) cacc[q] = V.Hcorner[r * 7 + ccol] + ((r == ccol && r < 6) ? lambda : 0.0);
     }
   }
+  if (NW == 16 && wave == 0) {   // the eight partial corners, numbered like the eight waves of the other layout: column J adds to (J + 7) & 7
+#pragma unroll
+    for (int p = 0; p < 8; p++) Cn[64 * p + lane] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[r * 7 + ccol] = cacc[q];
+    }
+  }
   if (tid == 0) { ctl->fact_ok = 1; *dflag = 0; }
   if (tid < 4) hflag[tid] = 0;
 #ifdef SFT_WIDE_TRACE
-  lds_double* wtrace = Cn + 580;
-  if (tid < 64) wtrace[tid] = 0.0;
+  lds_double* wtrace = NW == 16 ? Land + 32 * TS * TS : Cn + 580;   // (16 waves: 128 entries, in the fallback's staging area -- a trace build's numbers are void if the fallback runs)
+  if (tid < 8 * NW) wtrace[tid] = 0.0;
   const long long wt_c0 = clock64(), wt_w0 = wall_clock64();
 #endif
   __syncthreads();
@@ -690,54 +708,72 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
     }
   };
   // ---- prologue: the tiles of column 0 and W_0
-  v4d Lr[2][NEAR];                   // ring of the wave's rows: at column J entry k is X(I, J - NEAR + k)^T
+  v4d Lr[RPW][NEAR];                 // ring of the wave's rows: at column J entry k is X(I, J - NEAR + k)^T
 #pragma unroll
-  for (int s = 0; s < 2; s++)
+  for (int s = 0; s < RPW; s++)
 #pragma unroll
     for (int k = 0; k < NEAR; k++) Lr[s][k] = zero4;
   // Sums over the block columns that were finished before the last barrier are formed a column ahead (pre-products): behind the barrier
   // a row only waits for ONE product -- with the tile of row J received in the column before -- and its TRSM
-  v4d pre0[2] = {zero4, zero4}, pre1[2] = {zero4, zero4}, preS = zero4;
-  request_tile(0, wave, 0);
-  request_tile(1, wave + 8, 0);
-  if (wave == 0) request_tile(2, 16, 0);
-  if (wave == 7) request_border(0);
+  v4d pre0[RPW], pre1[RPW], preS = zero4;
+#pragma unroll
+  for (int s = 0; s < RPW; s++) { pre0[s] = zero4; pre1[s] = zero4; }
+  constexpr int S0 = NW == 16 ? SX : 0;   // where the first diagonal tile lands (16 waves: slot 0 of wave 0 takes the entering row)
+  if (NW == 16 && wave == 0) {
+    request_tile(S0, 0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < RPW; s++) request_tile(s, wave + NW * s, 0);
+  }
+  if (wave == 0) request_tile(SE, 16, 0);
+  if (wave == NW - 1) request_border(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) -- as a builtin: the compiler's own wait counters take note */
-  if (wave == 0) pivot(0, wide_lds_read(myland, lane));
+  if (wave == 0) pivot(0, wide_lds_read(myland + S0 * TS * TS, lane));
   __syncthreads();
 
 #pragma unroll 1
   for (int J = 0; J < nT; J++) {
-    const int d = (wave - J) & 7;
+    const int d = (wave - J) & (NW - 1);
     const int Kend = min(J, nS), Ks = ksplit(J);
     const bool elim = J < nS;
-    const int Irow[3] = {J + d, J + d + 8, d == 0 ? J + 16 : nT};
-    const int nI[3] = {d == 0 ? J + 8 : (d == 1 ? nT : J + d), d == 0 ? J + 16 : J + d + 8, d == 1 ? J + 17 : nT};
+    // rows of this column (the last entry: the row that enters the band, on the pivot wave) and of the next (slot by slot: behind the pivot row
+    // a wave's rows move up one slot)
+    int Irow[RPW + 1], nI[RPW + 1];
+#pragma unroll
+    for (int s = 0; s < RPW; s++) {
+      Irow[s] = J + d + NW * s;
+      nI[s] = d == 0 ? (s + 1 < RPW ? J + NW * (s + 1) : J + 16) : ((d == 1 && s == 0) ? nT : J + d + NW * s);
+    }
+    Irow[RPW] = d == 0 ? J + 16 : nT;
+    nI[RPW] = d == 1 ? J + 17 : nT;
+    auto slot_of = [&](int s) -> int { return s < RPW ? s : SE; };
     WT_T0();
     // (1) a column no helper has delivered (the verdict on column J+1 fell before the last barrier): the workgroup forms it itself, now
-    if (J + 1 < nT && ksplit(J + 1) > max(0, J + 1 - wb) && !uni(hflag[(J + 1) & 3])) wide_far_column_of(P, which, J + 1, Fstage);
+    if (J + 1 < nT && ksplit(J + 1) > max(0, J + 1 - wb) && !uni(hflag[(J + 1) & 3])) wide_far_column_of<NW>(P, which, J + 1, Fstage);
     // (2) the next pivot's diagonal tile: requested now (slot 3), used behind this column's first TRSM
-    if (d == 1 && J + 1 < nT) request_tile(3, J + 1, J + 1);
+    if (d == 1 && J + 1 < nT) request_tile(SX, J + 1, J + 1);
     WT_SEG(0);
     // (3) the last near product (block column J-1: its tile of row J arrived with the barrier), then the row's tile
     const lds_double* Arow = Aring + (size_t)(J % (NEAR + 1)) * NEAR * TS * TS;
-    v4d cur[3] = {zero4, zero4, zero4}, curB = zero4;
+    v4d cur[RPW + 1], curB = zero4;
+#pragma unroll
+    for (int s = 0; s <= RPW; s++) cur[s] = zero4;
     {
       const int K = J - 1;
       const bool kin = K >= 0 && K < Kend;
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
+      for (int s = 0; s <= RPW; s++) {
         const int I = Irow[s];
         if ((s == 0 && d == 0) || I >= nT || I - J > wb) continue;
-        const v4d st = wide_lds_read(myland + s * TS * TS, lane);
-        if (s < 2) {
+        const v4d st = wide_lds_read(myland + slot_of(s) * TS * TS, lane);
+        if (s < RPW) {
           if (kin && K >= max(max(0, I - wb), Ks)) wide_mfma4(wide_lds_read(Arow + (size_t)(K % NEAR) * TS * TS, lane), Lr[s][NEAR - 1], pre0[s], pre1[s]);
           cur[s] = st - (pre0[s] + pre1[s]);
         } else {
           cur[s] = st - zero4;
         }
       }
-      if (d == 7) {   // the border: all of its near products here (the role moves from wave to wave)
+      if (d == NW - 1) {   // the border: all of its near products here (the role moves from wave to wave)
         const int Klo = max(max(0, J - wb), Ks);
         v4d s0 = zero4, s1 = zero4;
 #pragma unroll
@@ -746,13 +782,13 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
           if (Kb >= Klo && Kb < Kend)
             wide_mfma4(wide_lds_read(Arow + (size_t)(Kb % NEAR) * TS * TS, lane), wide_lds_read(Bring + (size_t)(Kb % NEAR) * TS * TS, lane), s0, s1);
         }
-        curB = wide_lds_read(myland + 3 * TS * TS, lane) - (s0 + s1);
+        curB = wide_lds_read(myland + SX * TS * TS, lane) - (s0 + s1);
       }
     }
     // the start tiles of the next column (the landing slots are free again); the wave with the pivot chain asks behind the chain
     if (d != 1 && J + 1 < nT) {
 #pragma unroll
-      for (int s = 0; s < 3; s++) request_tile(s, nI[s], J + 1);
+      for (int s = 0; s <= RPW; s++) request_tile(slot_of(s), nI[s], J + 1);
       if (d == 0) request_border(J + 1);
     }
     WT_SEG(1);
@@ -766,7 +802,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
     }
     v4d newC = zero4;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
+    for (int s = 0; s <= RPW; s++) {
       const int I = Irow[s];
       const bool have = !(s == 0 && d == 0) && I < nT && I - J <= wb;
       v4d xT = zero4, x = zero4;
@@ -783,7 +819,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
         // square of the tile that has just left the TRSM
         const int Ip = J + 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) -- as a builtin: the compiler's own wait counters take note */      // the diagonal tile has landed
-        v4d dt = wide_lds_read(myland + 3 * TS * TS, lane);
+        v4d dt = wide_lds_read(myland + SX * TS * TS, lane);
         dt = dt - preS;
         if (elim) {
           v4d t0 = zero4, t1 = zero4;
@@ -797,7 +833,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
         flag_set(dflag, Ip);
         if (J + 1 < nT) {
 #pragma unroll
-          for (int t = 0; t < 3; t++) request_tile(t, nI[t], J + 1);
+          for (int t = 0; t <= RPW; t++) request_tile(slot_of(t), nI[t], J + 1);
         }
       }
       if (have) {
@@ -809,7 +845,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
           schur_store(I, J, cur[s]);
         }
       }
-      if (s < 2) {
+      if (s < RPW) {
 #pragma unroll
         for (int k = 0; k + 1 < NEAR; k++) Lr[s][k] = Lr[s][k + 1];
         Lr[s][NEAR - 1] = xT;
@@ -819,7 +855,7 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
     }
     WT_SEG(2);
     // (5) the border's TRSM, the corner's update
-    if (d == 7) {
+    if (d == NW - 1) {
       if (elim) {
         v4d xbT = zero4;
 #pragma unroll
@@ -831,8 +867,23 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
 #pragma unroll
           for (int q = 0; q < 4; q++) Lbord[(size_t)ccol * Dnp + TS * J + crow + 4 * q] = xbT[q];
         }
+        lds_double* cp = Cn + 64 * ((J + 7) & 7);
+        if (NW == 16) {   // (the partial this column adds to: last touched eight columns ago, barriers in between)
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const int r = crow + 4 * q;
+            cacc[q] = (r < SFT_BORDER && ccol < SFT_BORDER) ? cp[r * 7 + ccol] : 0.0;
+          }
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xbT[kk], -xbT[kk], cacc, 0, 0, 0);
+        if (NW == 16) {
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const int r = crow + 4 * q;
+            if (r < SFT_BORDER && ccol < SFT_BORDER) cp[r * 7 + ccol] = cacc[q];
+          }
+        }
       } else {
         wide_schur_border_of(P, which, J, curB);
       }
@@ -841,14 +892,18 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
     // (6) the rows move up a slot behind the pivot row
     if (d == 0) {
 #pragma unroll
-      for (int k = 0; k < NEAR; k++) { Lr[0][k] = Lr[1][k]; Lr[1][k] = k + 1 < NEAR ? zero4 : newC; }
+      for (int s = 0; s + 1 < RPW; s++)
+#pragma unroll
+        for (int k = 0; k < NEAR; k++) Lr[s][k] = Lr[s + 1][k];
+#pragma unroll
+      for (int k = 0; k < NEAR; k++) Lr[RPW - 1][k] = k + 1 < NEAR ? zero4 : newC;
     }
     // (7) the pre-products of column J+1: everything but its last block column (ring entry k is block column J + 1 - NEAR + k now)
     {
       const int J1 = J + 1, Kend1 = min(J1, nS), Ks1 = ksplit(J1);
       const lds_double* Arow1 = Aring + (size_t)(J1 % (NEAR + 1)) * NEAR * TS * TS;
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
+      for (int s = 0; s < RPW; s++) {
         pre0[s] = zero4; pre1[s] = zero4;
         const int I = nI[s];
         if (I >= nT || I - J1 > wb) continue;
@@ -885,8 +940,13 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
   }
 #ifdef SFT_WIDE_TRACE
   __syncthreads();
-  if (tid < 64) P.dbg[64 * which + tid] = wtrace[tid];
-  if (tid == 0) { P.dbg[64 * which + 62] = (double)(clock64() - wt_c0); P.dbg[64 * which + 63] = (double)(wall_clock64() - wt_w0); }   // shader clocks, 100 MHz ticks
+  if (NW == 16) {   // part 0 only: 16 roles x 8 segments fill the debug words
+    if (which == 0 && tid < 128) P.dbg[tid] = wtrace[tid];
+    if (which == 0 && tid == 0) { P.dbg[126] = (double)(clock64() - wt_c0); P.dbg[127] = (double)(wall_clock64() - wt_w0); }
+  } else {
+    if (tid < 64) P.dbg[64 * which + tid] = wtrace[tid];
+    if (tid == 0) { P.dbg[64 * which + 62] = (double)(clock64() - wt_c0); P.dbg[64 * which + 63] = (double)(wall_clock64() - wt_w0); }   // shader clocks, 100 MHz ticks
+  }
 #endif
 #ifdef DSH_LAB
   if (helped && tid == 0) {
@@ -894,10 +954,12 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
   }
 #endif
   // ---- corner: partial sums of the eight waves in a fixed order; the part's corner contribution and whether its factorisation failed
+  if (NW == 8) {
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int r = crow + 4 * q;
-    if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[64 * wave + r * 7 + ccol] = cacc[q];
+    for (int q = 0; q < 2; q++) {
+      const int r = crow + 4 * q;
+      if (r < SFT_BORDER && ccol < SFT_BORDER) Cn[64 * wave + r * 7 + ccol] = cacc[q];
+    }
   }
   __syncthreads();
   if (tid < 49) {
@@ -1008,27 +1070,114 @@ struct FarColumn {
   __device__ __forceinline__ void finish2(const WideView& V, int J, int wave, int lane, const lds_double* rowJ) { finish_item<MAXN2>(V, J, 15 - wave, lane, rowJ, bt2, h2, n2, K02); }
 };
 
+// The same column by a workgroup of SIXTEEN wavefronts (128 registers per lane): one item per wave, its operand tiles in chunks of U -- two
+// chunks requested ahead, the third into the first's registers behind its products.  Product for product the order of FarColumn::finish_item.
+struct FarColumn16 {
+  static constexpr int U = 4, MAXN = WB - SFT_WIDE_NEAR;
+  static_assert(MAXN <= 3 * U, "FarColumn16: three chunks of operand tiles");
+  v4d b0[U], b1[U], h, areg;
+  int n, K0, na;
+  __device__ __forceinline__ static void tiles_of(const WideView& V, int item, int I, int K0, __amdgpu_buffer_rsrc_t& r, unsigned& base, unsigned& step) {
+    r = wide_rsrc(item == 0 ? V.LbT : V.Lt);
+    base = item == 0 ? (unsigned)K0 * (TS * TS * 8u) : (unsigned)(wtile_off(V.tpr, K0, I - K0) * 8);
+    step = item == 0 ? (TS * TS * 8u) : (unsigned)(V.tpr - 1) * (TS * TS * 8u);
+  }
+  __device__ __forceinline__ void request(const WideView& V, int J, int wave, int lane) {
+    int I;
+    if (!FarColumn::item_of(V, J, wave, I, K0, n)) return;
+    n = min(n, MAXN);
+    __amdgpu_buffer_rsrc_t r; unsigned base, step;
+    tiles_of(V, wave, I, K0, r, base, step);
+    const unsigned lane32 = 32u * lane;
+#pragma unroll
+    for (int i = 0; i < U; i++) b0[i] = gb_ld<FAR_LD_AUX>(r, lane32, base + (unsigned)min(i, n - 1) * step);
+    if (n > U) {
+#pragma unroll
+      for (int i = 0; i < U; i++) b1[i] = gb_ld<FAR_LD_AUX>(r, lane32, base + (unsigned)min(U + i, n - 1) * step);
+    }
+    if (wave == 0) {
+      const int crow = lane >> 4, ccol = lane & 15;
+      h = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (ccol < SFT_BORDER) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int j = TS * J + crow + 4 * q;
+          const bool in = j >= V.b_lo && j < V.b_hi;
+          const double v = V.Hbord[(size_t)ccol * V.bstride + V.b_base + V.b_sign * (in ? j : V.b_lo)];
+          h[q] = in ? v : 0.0;
+        }
+      }
+    } else {
+      h = *reinterpret_cast<const SFT_G v4d*>(V.Hb + wtile_off(V.tpr, I, I - J) + 4 * lane);
+    }
+  }
+  __device__ __forceinline__ void requestA(const WideView& V, int J, int wave, int lane) {
+    const int Ks = min(V.nS, J - SFT_WIDE_NEAR), K = max(0, J - V.wb) + wave;
+    na = 0;
+    if (K < Ks) { areg = gb_ld<FAR_LD_AUX>(wide_rsrc(V.Lt), 32u * lane, (unsigned)(wtile_off(V.tpr, K, J - K) * 8)); na = 1; }
+  }
+  __device__ __forceinline__ void stageA(const WideView& V, int J, int wave, int lane, lds_double* rowJ) {
+    if (na) wide_lds_write(rowJ + (size_t)(J - (max(0, J - V.wb) + wave) - 1) * TS * TS, lane, areg);
+  }
+  __device__ __forceinline__ void finish(const WideView& V, int J, int wave, int lane, const lds_double* rowJ) {
+    if (n <= 0) return;
+    const bool sq = wave == 1;
+    const int I = wave <= 1 ? J : J + wave - 1;
+    v4d s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < U; i++)
+      if (i < n) wide_mfma4(sq ? b0[i] : wide_lds_read(rowJ + (size_t)(J - (K0 + i) - 1) * TS * TS, lane), b0[i], s0, s1);
+    if (n > 2 * U) {
+      __amdgpu_buffer_rsrc_t r; unsigned base, step;
+      tiles_of(V, wave, I, K0, r, base, step);
+#pragma unroll
+      for (int i = 0; i < U; i++) b0[i] = gb_ld<FAR_LD_AUX>(r, 32u * lane, base + (unsigned)min(2 * U + i, n - 1) * step);
+    }
+#pragma unroll
+    for (int i = 0; i < U; i++)
+      if (U + i < n) wide_mfma4(sq ? b1[i] : wide_lds_read(rowJ + (size_t)(J - (K0 + U + i) - 1) * TS * TS, lane), b1[i], s0, s1);
+#pragma unroll
+    for (int i = 0; i < U; i++)
+      if (2 * U + i < n) wide_mfma4(sq ? b0[i] : wide_lds_read(rowJ + (size_t)(J - (K0 + 2 * U + i) - 1) * TS * TS, lane), b0[i], s0, s1);
+    const v4d t = h - (s0 + s1);
+    if (wave == 0) tile_st_agent(V.PfB + (size_t)J * TS * TS + 4 * lane, t);
+    else tile_st_agent(V.Pf + wtile_off(V.tpr, J, wave == 1 ? 0 : wave - 1) + 4 * lane, t);
+  }
+};
+
+template <int NW>
 __device__ __forceinline__ void wide_far_column(const WideView& V, int J, lds_double* rowJ) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (min(V.nS, J - SFT_WIDE_NEAR) <= max(0, J - V.wb)) return;
-  FarColumn F;
-  F.n1 = F.n2 = 0;
-  F.request1(V, J, wave, lane);
-  F.request2(V, J, wave, lane);
-  F.requestA(V, J, wave, lane);
-  F.stageA(V, J, wave, lane, rowJ);
-  lds_barrier();
-  F.finish1(V, J, wave, lane, rowJ);
-  F.finish2(V, J, wave, lane, rowJ);
+  if constexpr (NW == 16) {
+    FarColumn16 F;
+    F.n = F.na = 0;
+    F.request(V, J, wave, lane);
+    F.requestA(V, J, wave, lane);
+    F.stageA(V, J, wave, lane, rowJ);
+    lds_barrier();
+    F.finish(V, J, wave, lane, rowJ);
+  } else {
+    FarColumn F;
+    F.n1 = F.n2 = 0;
+    F.request1(V, J, wave, lane);
+    F.request2(V, J, wave, lane);
+    F.requestA(V, J, wave, lane);
+    F.stageA(V, J, wave, lane, rowJ);
+    lds_barrier();
+    F.finish1(V, J, wave, lane, rowJ);
+    F.finish2(V, J, wave, lane, rowJ);
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();                                        // every wave's tiles have arrived
 }
 
+template <int NW>
 __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int J_, lds_double* rowJ) {
   const WideView V = wide_view(P, which);
   const int J = __builtin_amdgcn_readfirstlane(J_);
-  wide_far_column(V, J, rowJ);
+  wide_far_column<NW>(V, J, rowJ);
 }
 
 // A helper workgroup of part `which` (see the comment in front of factor_wide): hidx of nh, block columns near + 1 + hidx, + nh, ...
@@ -1036,6 +1185,7 @@ __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int 
 // raises its flag.  While it multiplies, the operand tiles of its next column are already on their way when the owner's progress allows
 // (a helper that cannot keep up with its owner is bound by what it multiplies then, not by one memory round trip per step).  It never makes
 // the owner wait: a column the owner has already decided about is skipped, and a helper whose owner shows no progress (or is not there) leaves.
+template <int NW = 8>
 __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int hidx_, int nh_, int epoch_, Ctl* ctl, double* ws) {
   const int which = __builtin_amdgcn_readfirstlane(which_), hidx = __builtin_amdgcn_readfirstlane(hidx_), nh = __builtin_amdgcn_readfirstlane(nh_), epoch = __builtin_amdgcn_readfirstlane(epoch_);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1054,8 +1204,9 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int
 #else
 #define HT_SEG(i) do {} while (0)
 #endif
-  FarColumn F;
-  F.n1 = F.n2 = F.na = 0;
+  using Far = typename std::conditional<NW == 16, FarColumn16, FarColumn>::type;
+  Far F;
+  if constexpr (NW == 16) { F.n = F.na = 0; } else { F.n1 = F.n2 = F.na = 0; }
   bool have = false;                                    // the tiles of column J have been requested (in the iteration before)
   int J = near + 1 + hidx;
 #pragma unroll 1
@@ -1099,8 +1250,12 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int
     if (go == 0) { J = Jskip; have = false; continue; }
     if (Ks <= K0d) { J += nh; have = false; continue; }
     if (!have) {
-      F.request1(V, J, wave, lane);
-      F.request2(V, J, wave, lane);
+      if constexpr (NW == 16) {
+        F.request(V, J, wave, lane);
+      } else {
+        F.request1(V, J, wave, lane);
+        F.request2(V, J, wave, lane);
+      }
       F.requestA(V, J, wave, lane);
     }
 #ifdef DSH_LAB
@@ -1109,11 +1264,17 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int
     F.stageA(V, J, wave, lane, rowJ);
     lds_barrier();
     HT_SEG(0);
-    F.finish1(V, J, wave, lane, rowJ);                    // (its result is stored at once: done long before the column's flag)
-    if (next_ok) { F.request1(V, Jn, wave, lane); F.requestA(V, Jn, wave, lane); }
-    HT_SEG(1);
-    F.finish2(V, J, wave, lane, rowJ);
-    if (next_ok) F.request2(V, Jn, wave, lane);
+    if constexpr (NW == 16) {
+      F.finish(V, J, wave, lane, rowJ);
+      HT_SEG(1);
+      if (next_ok) { F.request(V, Jn, wave, lane); F.requestA(V, Jn, wave, lane); }
+    } else {
+      F.finish1(V, J, wave, lane, rowJ);                  // (its result is stored at once: done long before the column's flag)
+      if (next_ok) { F.request1(V, Jn, wave, lane); F.requestA(V, Jn, wave, lane); }
+      HT_SEG(1);
+      F.finish2(V, J, wave, lane, rowJ);
+      if (next_ok) F.request2(V, Jn, wave, lane);
+    }
     HT_SEG(2);
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // this column's tiles have arrived (and the next one's operands)
     __syncthreads();
@@ -1134,22 +1295,30 @@ __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int
 #endif
 }
 
-// Back substitution for the wide band: x_J = W_J^T (y_J - sum_{I > J} X(I,J)^T x_I - L_cJ^T x_cam), block columns from the
-// last to the first; wave w forms the partial products of tiles (J + d, J), d = w + 1 and w + 9; wave 0 finishes the block.
+// Back substitution for the wide band: x_J = W_J^T (y_J - sum_{I > J} X(I,J)^T x_I - L_cJ^T x_cam), block columns from the last to the first.
+// The products of a block column with everything but x_{J+1} do not depend on the column before it: waves 1..7 form them ONE COLUMN AHEAD
+// (tiles (J-1+d, J-1), d = 2..16, and the camera rows, while wave 0 finishes column J), wave 0 adds the one product that needs x_{J+1}
+// (tile (J+1, J)), sums in the fixed order camera, d = 1, 2, ..., multiplies by W_J^T and publishes x_J: one barrier per column, and what a
+// column waits for is one tile product, seventeen subtractions and the product with W -- not all of its products.
 // which: see WideView.  A part (0 / 1) starts behind its eliminated columns: the separator rows of its band matrix take the solution of
 // the reduced problem (part 1 in reversed order), the camera update comes from there as well.
 // red: which copy of the reduced problem holds the separator / camera solution a part starts from (2 or 3)
 __device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, double* ws, int red = 2) {
-  constexpr int NW = 8, RPW = WB / NW, RING = 32;
+  constexpr int NW = 8, RING = 32;
+  static_assert(WB == 16, "backsub_wide: the tiles d = 2..16 of a column are dealt to seven waves");
   if (!ctl->fact_ok) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WideView V = wide_view<false>(P, which);
+#ifndef SFT_BS_UNIFORM
+#define SFT_BS_UNIFORM true
+#endif
+  const WideView V = wide_view<SFT_BS_UNIFORM>(P, which);
   const int nT = V.nT, nS = V.nS;
   const int Dnp = TS * nT;
   const int tpr = V.tpr, wb = V.wb;
   lds_double* xw = to_lds(ws);                 // ring of RING x-tiles
-  lds_double* part = xw + TS * RING;           // slot 0: camera rows, slots 1..WB: sub-diagonal tiles
+  lds_double* part = xw + TS * RING;           // [column & 1][slot]: slot 0 camera rows, slots 2..WB sub-diagonal tiles (slot 1: wave 0's own, in registers)
+  constexpr int PSZ = TS * (WB + 1);
   const int crow = lane >> 4, ccol = lane & 15;
   const bool is_part = which == 0 || which == 1;
   const auto xred = is_part ? uni(P.part[red].x) : V.x;        // where the camera update (and, for a part, the separator solution) is
@@ -1162,80 +1331,142 @@ __device__ __noinline__ void backsub_wide(const SftDev& P, int which, Ctl* ctl, 
   const auto Lbord = V.Lbord;
   const auto Linv_g = V.Linv;
   const auto xg = V.x;
-  for (int i = tid; i < TS * (WB + 1); i += 64 * NW) part[i] = 0.0;   // slots beyond wb stay zero
+  for (int i = tid; i < 2 * PSZ; i += 64 * NW) part[i] = 0.0;   // slots beyond wb stay zero
   if (is_part)
     for (int i = tid; i < TS * (nT - nS); i += 64 * NW) {             // separator rows nS .. nT-1 of the part
       const int I = nS + (i >> 4), l = i & 15;
       xw[(I & (RING - 1)) * TS + l] = xred[V.reversed ? sred - 1 - i : i];
     }
   __syncthreads();
-  struct Pre { v4d t[RPW]; double aux[6]; };
-  auto fetch = [&](int J) -> Pre {
-    Pre p;
-#pragma unroll
-    for (int t = 0; t < RPW; t++) p.t[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 6; r++) p.aux[r] = 0.0;
-    if (J < 0) return p;
-#pragma unroll
-    for (int t = 0; t < RPW; t++) {
-      const int d = wave + 1 + NW * t;
-      if (J + d < nT && d <= wb) p.t[t] = *reinterpret_cast<const SFT_G v4d*>(Lg + wtile_off(tpr, J, d) + 4 * lane);
-    }
-    if (wave == 0) {
-      const v4d li = *reinterpret_cast<const SFT_G v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
-#pragma unroll
-      for (int q = 0; q < 4; q++) p.aux[q] = li[q];
-      p.aux[4] = Lbord[(size_t)6 * Dnp + TS * J + ccol];
-    } else if (wave == 1) {
-#pragma unroll
-      for (int r = 0; r < 6; r++) p.aux[r] = Lbord[(size_t)r * Dnp + TS * J + ccol];
-    }
-    return p;
+  // Prefetch: every load of the loops below is UNCONDITIONAL (tiles that do not exist are read from the column's diagonal slot and never used,
+  // columns below zero from column zero) and each role has its own loop: the compiler can then count the loads in flight and wait for the
+  // oldest only -- a conditional load anywhere in the loop makes it wait for ALL of them (vmcnt(0)) once per column, which is the latency
+  // of a trip to memory per column and was what the back substitution took (1 us per column; C5: 196 columns).
+  auto tile_at = [&](int J, int d) -> v4d {
+    const int Jc = uni(max(J, 0)), dd = uni((Jc + d < nT && d <= wb) ? d : 0);   // (scalar address arithmetic)
+    return *reinterpret_cast<const SFT_G v4d*>(uni(Lg + wtile_off(tpr, Jc, dd)) + 4 * lane);
   };
-  constexpr int PF = 4;
-  Pre ring[PF];
+  // sum over the rows of tile (J + d, J) times x_{J+d}: the partial product of one tile, in every lane of its column
+  auto tile_product = [&](const v4d& t, int I) -> double {
+    const lds_double* xi = xw + (I & (RING - 1)) * TS + crow;
+    double p = 0.0;
 #pragma unroll
-  for (int j = 0; j < PF; j++) ring[j] = fetch(nS - 1 - j);
+    for (int q = 0; q < 4; q++) p = fma(t[q], xi[4 * q], p);
+    return sum_rows(p);
+  };
+#ifndef SFT_BS_PF
+#define SFT_BS_PF 2   // columns of look-ahead of the loads (A/B: 2 < 3 < 4 -- the tiles are in L2, the registers are what is short)
+#endif
+  constexpr int PF = SFT_BS_PF;
+  if (wave == 0) {
+    // ---- wave 0 finishes column J: the product with x_{J+1}, the sum, W_J^T
+    struct Pre0 { v4d t, li; double y; };
+    auto fetch0 = [&](int J) -> Pre0 {
+      Pre0 p;
+      const int Jc = uni(max(J, 0));
+      p.t = tile_at(J, 1);
+      p.li = *reinterpret_cast<const SFT_G v4d*>(Linv_g + (size_t)Jc * TS * TS + 4 * lane);
+      p.y = Lbord[(size_t)6 * Dnp + TS * Jc + ccol];
+      return p;
+    };
+    Pre0 ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) ring[j] = fetch0(nS - 1 - j);
+    lds_barrier();
 #pragma unroll 1
-  for (int base = nS - 1; base >= 0; base -= PF) {
+    for (int base = nS - 1; base >= 0; base -= PF) {
 #pragma unroll
-    for (int j = 0; j < PF; j++) {
-      const int J = base - j;
-      if (J < 0) break;
-      const Pre cur = ring[j];
-      ring[j] = fetch(J - PF);
+      for (int j = 0; j < PF; j++) {
+        const int J = base - j;
+        if (J < 0) break;
+        const Pre0 cur = ring[j];
+        ring[j] = fetch0(J - PF);
+        const lds_double* pj = part + (J & 1) * PSZ;
+        const double p1 = (J + 1 < nT && 1 <= wb) ? tile_product(cur.t, J + 1) : 0.0;
+        double v = cur.y;
+        v -= pj[ccol];
+        v -= p1;
 #pragma unroll
-      for (int t = 0; t < RPW; t++) {
-        const int d = wave + 1 + NW * t;
-        const int I = J + d;
-        double p = 0.0;
-        if (I < nT && d <= wb) {
-          const lds_double* xi = xw + (I & (RING - 1)) * TS + crow;
-#pragma unroll
-          for (int q = 0; q < 4; q++) p = fma(cur.t[t][q], xi[4 * q], p);
-          p = sum_rows(p);
-        }
-        if (lane < TS && d <= wb) part[d * TS + lane] = p;
-      }
-      if (wave == 1 && lane < TS) {
+        for (int i = 2; i <= WB; i++) v -= pj[i * TS + ccol];   // (the order of the sum is the order it always had: subtracting the late product last gained nothing, A/B)
         double p = 0.0;
 #pragma unroll
-        for (int r = 0; r < 6; r++) p = fma(cur.aux[r], xcr[r], p);
-        part[lane] = p;
-      }
-      lds_barrier();
-      if (wave == 0) {
-        double v = cur.aux[4];
-#pragma unroll
-        for (int i = 0; i <= WB; i++) v -= part[i * TS + ccol];
-        double p = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
+        for (int q = 0; q < 4; q++) p = fma(cur.li[q], __shfl(v, crow + 4 * q, 64), p);
         p = sum_rows(p);
         if (lane < TS) { xw[(J & (RING - 1)) * TS + lane] = p; xg[TS * J + lane] = p; }
+        lds_barrier();
+      }
+    }
+  } else {
+    // ---- waves 1..7, one column ahead of wave 0: the products of column J - 1 that do not need x_J -- tiles d = wave + 1, wave + 8 and (wave 1) 16;
+    // wave 7 the camera rows as well.  How many of a wave's tiles lie inside the band does not change from column to column: one loop per
+    // count (and with / without the camera rows), each with a fixed number of loads per column.
+    const int d0 = wave + 1, d1 = wave + 8, d2 = wave == 1 ? WB : WB + 1;
+    auto run = [&](auto ntile_c, auto cam_c) {
+      constexpr int NTILE = decltype(ntile_c)::value;
+      constexpr bool CAM = decltype(cam_c)::value;
+      struct Pre1 { v4d t[NTILE > 0 ? NTILE : 1]; double aux[CAM ? 6 : 1]; };
+      auto dof = [&](int t) -> int { return t == 0 ? d0 : (t == 1 ? d1 : d2); };
+      auto fetch1 = [&](int J) -> Pre1 {
+        Pre1 p;
+#pragma unroll
+        for (int t = 0; t < NTILE; t++) p.t[t] = tile_at(J, dof(t));
+        if (CAM) {
+          const int Jc = uni(max(J, 0));
+#pragma unroll
+          for (int r = 0; r < 6; r++) p.aux[r] = Lbord[(size_t)r * Dnp + TS * Jc + ccol];
+        }
+        return p;
+      };
+      auto ahead = [&](int J, const Pre1& cur) {
+        lds_double* pj = part + (J & 1) * PSZ;
+#pragma unroll
+        for (int t = 0; t < NTILE; t++) {
+          const int d = dof(t), I = J + d;
+          const double p = (I < nT) ? tile_product(cur.t[t], I) : 0.0;
+          if (lane < TS) pj[d * TS + lane] = p;
+        }
+        if (CAM && lane < TS) {
+          double p = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) p = fma(cur.aux[r], xcr[r], p);
+          pj[lane] = p;
+        }
+      };
+      Pre1 ring[PF];
+#pragma unroll
+      for (int j = 0; j < PF; j++) ring[j] = fetch1(nS - 1 - j);
+      if (nS > 0) {                                // column nS-1 ahead of the loop
+        const Pre1 cur = ring[0];
+#pragma unroll
+        for (int j = 0; j + 1 < PF; j++) ring[j] = ring[j + 1];
+        ring[PF - 1] = fetch1(nS - 1 - PF);
+        ahead(nS - 1, cur);
       }
       lds_barrier();
+#pragma unroll 1
+      for (int base = nS - 1; base >= 0; base -= PF) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+          const int J = base - j;                   // the column wave 0 finishes
+          if (J < 0) break;
+          const Pre1 cur = ring[j];
+          ring[j] = fetch1(J - 1 - PF);
+          if (J - 1 >= 0) ahead(J - 1, cur);
+          lds_barrier();
+        }
+      }
+    };
+    using std::integral_constant;
+    const int ntile = (d0 <= wb ? 1 : 0) + (d1 <= wb ? 1 : 0) + (d2 <= wb ? 1 : 0);   // (d0 < d1 < d2: the first ntile lie inside the band)
+    if (wave == 7) {
+      if (ntile >= 2) run(integral_constant<int, 2>{}, integral_constant<bool, true>{});
+      else if (ntile == 1) run(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+      else run(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    } else {
+      if (ntile >= 3) run(integral_constant<int, 3>{}, integral_constant<bool, false>{});
+      else if (ntile == 2) run(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+      else if (ntile == 1) run(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+      else run(integral_constant<int, 0>{}, integral_constant<bool, false>{});
     }
   }
   __syncthreads();

@@ -28,6 +28,11 @@ if "--speculate" in args:   # lanes per problem (0: automatic)
     i = args.index("--speculate")
     spec = int(args[i + 1])
     del args[i:i + 2]
+ow = (8,)
+if "--owner-waves" in args:   # wavefronts of a FACTOR workgroup with helpers: 8 (default), 16 or "8,16"
+    i = args.index("--owner-waves")
+    ow = tuple(int(v) for v in args[i + 1].split(","))
+    del args[i:i + 2]
 cfgs = args or ["C5", "C2"]
 ctx = sft.Context(0, lab=True)
 for cfg in cfgs:
@@ -35,8 +40,9 @@ for cfg in cfgs:
     tmpl = synth.make_grid_template(rows, cols)
     ctx.template_build(tmpl.xyz0, tmpl.facets)
     ref = None
-    for nh in (0, -1, 1, 2, 3):
+    for nh, waves in [(0, 8)] + [(h, w) for w in ow for h in (-1, 1, 2, 3)]:
         ctx.set_option("helpers", nh)
+        ctx.set_option("owner_waves", waves)
         ctx.set_option("speculate", spec)
         fs = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(batch)]
         ctx.batch_upload(fs, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
@@ -52,7 +58,7 @@ for cfg in cfgs:
         else:
             same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:] for a, b in zip(ref, res))
         info = ctx.solver_info(0)
-        print(f"{cfg} x{batch} helpers={nh}: {ms:.3f} ms per step, {it} iterations, {tr} trials, two-sided {info['split']}, lanes {info['lanes']}, bit-identical to helpers=0: {same}", flush=True)
+        print(f"{cfg} x{batch} helpers={nh} waves={waves}: {ms:.3f} ms per step, {it} iterations, {tr} trials, two-sided {info['split']}, lanes {info['lanes']}, bit-identical to helpers=0: {same}", flush=True)
         if nh != 0 and info['split']:
             for g in (0, 1):   # statistics of lane 0's part g over the 6 runs since the upload (lab build): owner / helper counters, 100 MHz ticks
                 try:
@@ -64,4 +70,5 @@ for cfg in cfgs:
                     break
                 print(f"   part {g}: owner took {w[1]} columns from helpers, formed {w[2]} itself, {w[3]} polls, {w[4] * 1e-2:.0f} us looking | helpers formed {w[5]} columns, skipped {w[6]}, waited {w[7] * 1e-2:.0f} us, worked {w[8] * 1e-2:.0f} us", flush=True)
 ctx.set_option("helpers", -1)
+ctx.set_option("owner_waves", 8)
 ctx.close()

@@ -23,8 +23,9 @@ rows, cols, m = synth.CONFIGS[cfg]
 tmpl = synth.make_grid_template(rows, cols)
 ctx = sft.Context(0, lab=True)
 ctx.template_build(tmpl.xyz0, tmpl.facets)
-for nh in (0, -1):
+for nh, waves in ((0, 8), (-1, 8), (-1, 16)):
     ctx.set_option("helpers", nh)
+    ctx.set_option("owner_waves", waves)
     f = sft.frame_from_synth(synth.make_frame(tmpl, m, 0))
     ctx.batch_upload([f], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
     ctx.batch_run()
@@ -32,7 +33,15 @@ for nh in (0, -1):
     ms = ctx.lab_run_timed(3) / 3
     info = ctx.solver_info(0)
     d = ctx.dump(0, 7, 128).reshape(2, 8, 8)
-    print(f"{cfg} helpers={nh}: {ms:.3f} ms per frame; two-sided {info['split']}")
+    print(f"{cfg} helpers={nh} waves={waves}: {ms:.3f} ms per frame; two-sided {info['split']}")
+    if waves == 16 and nh != 0:   # part 0 only, 16 roles (the last role's segments 6, 7 hold the clocks)
+        raw = ctx.dump(0, 7, 128)
+        ncol = 204
+        print(f"  part 0: us per column by role and segment; shader clock {raw[126] / raw[127] * 100:.0f} MHz ({raw[127] * 1e-2:.0f} us)")
+        for r in range(16):
+            us = raw[8 * r:8 * r + (6 if r == 15 else 8)] * 1e-2 / ncol
+            print("    role %2d: " % r + " ".join(f"{v:6.2f}" for v in us) + f"   {us.sum():6.2f}")
+        continue
     for g in (0, 1):
         ncol = (info["c0"] if g == 0 else info["n1p"]) // 16 + info["s"] // 16 if "c0" in info else 204
         print(f"  part {g} ({ncol} columns): us per column by role (rows) and segment (columns 0..7), last column: sum")
