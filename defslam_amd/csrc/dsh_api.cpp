@@ -164,7 +164,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = 2; int owner_waves = 8; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = 2; int owner_waves = 8; int helpers_wbt = 12; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -731,7 +731,7 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
     // (only where the far products are most of a block column: bands of at least 12 tiles; a narrow band through this path gains nothing --
     // C2, 8 tiles: 4.4 against 4.0 ms per frame with helpers)
     bool any = false;
-    for (int b = 0; b < B; b++) any = any || (c->packed[b].h.split != 0 && c->packed[b].h.wbt >= 12);
+    for (int b = 0; b < B; b++) any = any || (c->packed[b].h.split != 0 && c->packed[b].h.wbt >= c->opt.helpers_wbt);
     for (int b = 0; b < B; b++)   // (the owner's progress word keeps the finished block columns in 16 bits)
       if (c->packed[b].h.split && std::max(c->packed[b].h.part[0].nT, c->packed[b].h.part[1].nT) >= 60000) any = false;
     if (any && K > 1 && !c->force_split) {
@@ -1348,6 +1348,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "rounds") c->opt.rounds = value != 0;
   else if (k == "streams") { if (value < 0 || value > dsh_ctx::kMaxSub) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: streams is 0 (automatic) or 1..4 sub-batches"); c->opt.streams = value; }
   else if (k == "split") { if (value < 0 || value > 2) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: split is 0 (off), 1 (wide bands only) or 2 (every band long enough)"); c->opt.split = value; }
+  else if (k == "helpers_wbt") { if (value < 1 || value > 16) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers_wbt is 1..16 (tiles of half-bandwidth from which parts get helper workgroups)"); c->opt.helpers_wbt = value; }
   else if (k == "owner_waves") { if (value != 8 && value != 16) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: owner_waves is 8 or 16 (wavefronts of a FACTOR workgroup with helpers)"); c->opt.owner_waves = value; }
   else if (k == "helpers") { if (value < -1 || value > 3) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers is -1 (automatic) or 0..3 workgroups per part"); c->opt.helpers = value; }
   else if (k == "tail") { if (value < 0 || value > 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: tail is 0 (rounds to the end) or the number of problems per CU from which downwards the last problems go to the tail kernel (default 2)"); c->opt.tail = value; }

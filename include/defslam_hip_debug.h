@@ -38,6 +38,9 @@ extern "C" {
  *   "helpers"  -1 (default) = automatic: two or three helper workgroups per part of a two-sided factorisation of a wide band (at least 12
  *              sub-diagonal tiles) when the device holds them all (B x lanes x 2 x (1 + helpers) <= CUs); 0..3 = that many -- the results are
  *              the same bits for every value (sft_wide.h: the owner forms a far sum itself whenever a helper's is not there)
+ *   "helpers_wbt"  12 (default) = the half-bandwidth in tiles from which parts get helpers (C2, 8 tiles, with helpers: 4.0 against 3.8 ms per frame)
+ *   "owner_waves"  8 (default) | 16 = wavefronts of a FACTOR workgroup when there are helpers: 16 runs sft_part_factor_kernel -- one live row
+ *              per wave, four wavefronts per SIMD; the same bits, 31.7 against 24.5 ms per C5 frame: a column is bound by what its waves issue
  *   "tail"     2 (default) = the last problems of a step of the throughput shape -- from two per CU downwards -- are run to their end by
  *              sftb_tail_kernel (one workgroup per problem); 1..8 = another threshold in problems per CU, 0 = rounds of phase kernels to the end
  *              (the eight-wavefront solver of the tail kernel rounds differently from the one-wavefront solver: same trajectories, x to 5e-13) */

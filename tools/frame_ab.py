@@ -28,6 +28,9 @@ if v != "intree":
 from defslam_amd import sft, synth  # noqa: E402
 
 ctx = sft.Context(0, lab=True)
+for kv in filter(None, os.environ.get("WV_OPTS", "").split(",")):   # lab options: WV_OPTS=helpers_wbt=8,helpers=3
+    k, val = kv.split("=")
+    ctx.set_option(k, int(val))
 for cfg in os.environ.get("WV_CFG", "C5").split(","):
     rows, cols, m = synth.CONFIGS[cfg]
     tmpl = synth.make_grid_template(rows, cols)
@@ -39,5 +42,6 @@ for cfg in os.environ.get("WV_CFG", "C5").split(","):
     ms = ctx.lab_run_timed(5) / 5
     ctx.batch_download()
     h = hashlib.sha1(f.nodes_xyz.tobytes() + f.pose7.tobytes()).hexdigest()[:12]
-    print(f"{v:>10} {cfg}: {ms:.3f} ms per frame, {f.iters} iterations, {f.trials} trials, result {h}", flush=True)
+    info = ctx.solver_info(0)
+    print(f"{v:>10} {cfg}: {ms:.3f} ms per frame, {f.iters} iterations, {f.trials} trials, lanes {info['lanes']}, result {h} {os.environ.get('WV_OPTS', '')}", flush=True)
 ctx.close()
