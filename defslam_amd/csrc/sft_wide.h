@@ -98,6 +98,9 @@ __device__ __forceinline__ WideView wide_view(const SftDev& P, int which_) {
 // agent scope (sc1): the L2 of another XCD holds no stale line of it.
 #ifndef SFT_WIDE_NEAR
 #define SFT_WIDE_NEAR 4
+#ifndef SFT_CHAIN_FIRST
+#define SFT_CHAIN_FIRST 1   // the wave of the pivot chain takes its other rows behind the chain (A/B: 22.83 -> 22.69 ms per C5 frame)
+#endif
 #endif
 __device__ __forceinline__ int wide_near(int wb) { return SFT_WIDE_NEAR; }
 #define WIDE_SYNC_READY 16          // sync[WIDE_SYNC_READY + J] == epoch: column J's far sums are stored
@@ -758,21 +761,27 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
     v4d cur[RPW + 1], curB = zero4;
 #pragma unroll
     for (int s = 0; s <= RPW; s++) cur[s] = zero4;
-    {
+#ifdef SFT_CHAIN_PRIO
+    if (d <= 1) __builtin_amdgcn_s_setprio(SFT_CHAIN_PRIO);   // the two waves of the pivot chain go first on their SIMDs (A/B, priority 3: 22.95 against 22.83 ms -- not used)
+#endif
+    auto t3_row = [&](int s) {
       const int K = J - 1;
       const bool kin = K >= 0 && K < Kend;
-#pragma unroll
-      for (int s = 0; s <= RPW; s++) {
-        const int I = Irow[s];
-        if ((s == 0 && d == 0) || I >= nT || I - J > wb) continue;
-        const v4d st = wide_lds_read(myland + slot_of(s) * TS * TS, lane);
-        if (s < RPW) {
-          if (kin && K >= max(max(0, I - wb), Ks)) wide_mfma4(wide_lds_read(Arow + (size_t)(K % NEAR) * TS * TS, lane), Lr[s][NEAR - 1], pre0[s], pre1[s]);
-          cur[s] = st - (pre0[s] + pre1[s]);
-        } else {
-          cur[s] = st - zero4;
-        }
+      const int I = Irow[s];
+      if ((s == 0 && d == 0) || I >= nT || I - J > wb) return;
+      const v4d st = wide_lds_read(myland + slot_of(s) * TS * TS, lane);
+      if (s < RPW) {
+        if (kin && K >= max(max(0, I - wb), Ks)) wide_mfma4(wide_lds_read(Arow + (size_t)(K % NEAR) * TS * TS, lane), Lr[s][NEAR - 1], pre0[s], pre1[s]);
+        cur[s] = st - (pre0[s] + pre1[s]);
+      } else {
+        cur[s] = st - zero4;
       }
+    };
+    {
+      // (the wave of the pivot chain takes its other rows behind the chain: what the column waits for is ITS first row)
+#pragma unroll
+      for (int s = 0; s <= RPW; s++)
+        if (SFT_CHAIN_FIRST == 0 || d != 1 || s == 0) t3_row(s);
       if (d == NW - 1) {   // the border: all of its near products here (the role moves from wave to wave)
         const int Klo = max(max(0, J - wb), Ks);
         v4d s0 = zero4, s1 = zero4;
@@ -831,6 +840,13 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
         // takes the tile through LDS (flag behind the data) and publishes W_{J+1} in front of the barrier.
         wide_lds_write(Dt, lane, dt);
         flag_set(dflag, Ip);
+#ifdef SFT_CHAIN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (SFT_CHAIN_FIRST) {
+#pragma unroll
+          for (int t = 1; t <= RPW; t++) t3_row(t);
+        }
         if (J + 1 < nT) {
 #pragma unroll
           for (int t = 0; t <= RPW; t++) request_tile(slot_of(t), nI[t], J + 1);
@@ -929,6 +945,9 @@ __device__ __noinline__ void factor_part(const SftDev& P, int which_, Ctl* ctl, 
       flag_wait(dflag, J + 1);
       pivot(J + 1, wide_lds_read(Dt, lane));
     }
+#ifdef SFT_CHAIN_PRIO
+    if (d == 0) __builtin_amdgcn_s_setprio(0);
+#endif
     WT_SEG(4);
     look_for_helper(J);
     WT_SEG(5);
