@@ -35,13 +35,15 @@ for cfg in os.environ.get("WV_CFG", "C5").split(","):
     rows, cols, m = synth.CONFIGS[cfg]
     tmpl = synth.make_grid_template(rows, cols)
     ctx.template_build(tmpl.xyz0, tmpl.facets)
-    f = sft.frame_from_synth(synth.make_frame(tmpl, m, 0))
-    ctx.batch_upload([f], synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
+    nb = int(os.environ.get("WV_BATCH", "1"))   # problems per step (WV_BATCH=16: the 16-problem line of the bench)
+    fs = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(nb)]
+    f = fs[0]
+    ctx.batch_upload(fs, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
     ctx.batch_run()
     ctx.synchronize()
     ms = ctx.lab_run_timed(5) / 5
     ctx.batch_download()
     h = hashlib.sha1(f.nodes_xyz.tobytes() + f.pose7.tobytes()).hexdigest()[:12]
     info = ctx.solver_info(0)
-    print(f"{v:>10} {cfg}: {ms:.3f} ms per frame, {f.iters} iterations, {f.trials} trials, lanes {info['lanes']}, result {h} {os.environ.get('WV_OPTS', '')}", flush=True)
+    print(f"{v:>10} {cfg} x{nb}: {ms:.3f} ms per step, {f.iters} iterations, {f.trials} trials, lanes {info['lanes']}, result {h} {os.environ.get('WV_OPTS', '')}", flush=True)
 ctx.close()
