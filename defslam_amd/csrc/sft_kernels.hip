@@ -2221,6 +2221,9 @@ __device__ __noinline__ void factor_tiles_df(const SftDev& P, Ctl* ctl, double* 
 // camera term) only needs x_{J+2} and older: the other products run one block AHEAD of wave 0.  One LDS barrier per block, none
 // on the chain (the version before: two barriers and a partial-sum hand-over on the chain of every block).
 // The L tiles of the next PF blocks are in flight in a register ring (LDS-only barriers keep the loads in flight).
+#ifndef SFT_BT_PF
+#define SFT_BT_PF 6
+#endif
 template <int NW>
 __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws) {
   constexpr int RPW = BT / NW;
@@ -2240,92 +2243,96 @@ __device__ __noinline__ void backsub_tiles(const SftDev& P, Ctl* ctl, double* ws
   const auto Lbord = uni(P.Lbord);
   const auto Linv_g = uni(P.Linv);
   const auto xg = uni(P.x);
-  // aux is wave specific: wave 0 keeps Linv_J (4 doubles) and y_J, wave 1 the six camera rows of the border; one shared
-  // field keeps a ring entry at 8 RPW + 12 registers
-  struct Pre { v4d t[RPW]; double aux[6]; };
-  auto fetch = [&](int J) -> Pre {
-    Pre p;
-#pragma unroll
-    for (int t = 0; t < RPW; t++) p.t[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 6; r++) p.aux[r] = 0.0;
-    if (J < 0 || J >= nT) return p;
-#pragma unroll
-    for (int t = 0; t < RPW; t++) {
-      const int d = wave + 1 + NW * t;
-      if (J + d < nT) p.t[t] = *reinterpret_cast<const v4d*>(Lg + tile_off(J, d) + 4 * lane);   // column-major L: the BT tiles of block column J are contiguous (16 KB)
-    }
-    if (wave == 0) {
-      const v4d li = *reinterpret_cast<const v4d*>(Linv_g + (size_t)J * TS * TS + 4 * lane);
-#pragma unroll
-      for (int q = 0; q < 4; q++) p.aux[q] = li[q];
-      p.aux[4] = Lbord[(size_t)6 * Dnp + TS * J + ccol];
-    } else if (wave == 1) {
-#pragma unroll
-      for (int r = 0; r < 6; r++) p.aux[r] = Lbord[(size_t)r * Dnp + TS * J + ccol];
-    }
-    return p;
-  };
-  // product of the wave's tile t of block J with x_{J+d}: 16 partial sums (replicated in the four 16-lane groups after the shuffles)
-  auto product = [&](const Pre& e, int t, int J) -> double {
-    const int d = wave + 1 + NW * t, I = J + d;
-    double p = 0.0;
-    if (I < nT) {
-      const lds_double* xi = xw + (I & (BT - 1)) * TS + crow;
-#pragma unroll
-      for (int q = 0; q < 4; q++) p = fma(e.t[t][q], xi[4 * q], p);
-      p = sum_rows(p);
-    }
-    return p;
-  };
   // Slot s (s = nT ... 0): wave 0 finishes block s (its own d = 1 product + the partials the others wrote in slot s+1);
   // every wave writes its d >= 2 products (wave 1: + the camera term) of block s-1.  Ring position j holds block (base - j) and
   // is refilled with block (base - j - PF) as soon as it has been taken: PF blocks of look-ahead all the time.
-  constexpr int PF = 6;
-  Pre ring[PF];
+  // Every load is UNCONDITIONAL (a block outside the matrix is read from its nearest column, a tile behind the matrix from its slot of L --
+  // neither is used) and each role has its own loop -- wave 0 (Linv_J, y_J), wave 1 (the six camera rows of the border), the others -- so that
+  // a trip has a fixed number of loads and the compiler waits for the oldest ones only: a load under a condition made it wait for ALL loads in
+  // flight (vmcnt(0)) once per block, the look-ahead was worth nothing (sft_wide.h: backsub_wide, where this was found).
+  auto run = [&](auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+    struct Pre { v4d t[RPW]; double aux[ROLE == 2 ? 1 : 6]; };
+    auto fetch = [&](int J) -> Pre {
+      Pre p;
+      const int Jc = uni(min(max(J, 0), nT - 1));
 #pragma unroll
-  for (int j = 0; j < PF; j++) ring[j] = fetch(nT - j);
+      for (int t = 0; t < RPW; t++) p.t[t] = *reinterpret_cast<const v4d*>(Lg + tile_off(Jc, wave + 1 + NW * t) + 4 * lane);   // column-major L: the BT tiles of block column J are contiguous (16 KB)
+      if constexpr (ROLE == 0) {
+        const v4d li = *reinterpret_cast<const v4d*>(Linv_g + (size_t)Jc * TS * TS + 4 * lane);
+#pragma unroll
+        for (int q = 0; q < 4; q++) p.aux[q] = li[q];
+        p.aux[4] = Lbord[(size_t)6 * Dnp + TS * Jc + ccol];
+        p.aux[5] = 0.0;
+      } else if constexpr (ROLE == 1) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) p.aux[r] = Lbord[(size_t)r * Dnp + TS * Jc + ccol];
+      } else {
+        p.aux[0] = 0.0;
+      }
+      return p;
+    };
+    // product of the wave's tile t of block J with x_{J+d}: 16 partial sums (replicated in the four 16-lane groups after the shuffles)
+    auto product = [&](const Pre& e, int t, int J) -> double {
+      const int d = wave + 1 + NW * t, I = J + d;
+      double p = 0.0;
+      if (I < nT) {
+        const lds_double* xi = xw + (I & (BT - 1)) * TS + crow;
+#pragma unroll
+        for (int q = 0; q < 4; q++) p = fma(e.t[t][q], xi[4 * q], p);
+        p = sum_rows(p);
+      }
+      return p;
+    };
+    constexpr int PF = SFT_BT_PF;
+    Pre ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) ring[j] = fetch(nT - j);
 #pragma unroll 1
-  for (int base = nT; base >= 0; base -= PF) {
+    for (int base = nT; base >= 0; base -= PF) {
 #pragma unroll
-    for (int j = 0; j < PF; j++) {
-      const int s = base - j;
-      if (s < 0) break;
-      const Pre cur = ring[j];            // block s
-      ring[j] = fetch(s - PF);
-      const Pre& nxt = ring[(j + 1) % PF];   // block s - 1 (position 0 was refilled with block base - PF at the start of this chunk)
-      lds_double* part_s = part + (s & 1) * (BT + 1) * TS;
-      lds_double* part_n = part + ((s - 1) & 1) * (BT + 1) * TS;
-      // ---- ahead of wave 0: block s-1, tiles at distance >= 2 and the camera term (x_{s+1} and older are final)
-      if (s >= 1) {
+      for (int j = 0; j < PF; j++) {
+        const int s = base - j;
+        if (s < 0) break;
+        const Pre cur = ring[j];            // block s
+        ring[j] = fetch(s - PF);
+        const Pre& nxt = ring[(j + 1) % PF];   // block s - 1 (position 0 was refilled with block base - PF at the start of this chunk)
+        lds_double* part_s = part + (s & 1) * (BT + 1) * TS;
+        lds_double* part_n = part + ((s - 1) & 1) * (BT + 1) * TS;
+        // ---- ahead of wave 0: block s-1, tiles at distance >= 2 and the camera term (x_{s+1} and older are final)
+        if (s >= 1) {
 #pragma unroll
-        for (int t = 0; t < RPW; t++) {
-          const int d = wave + 1 + NW * t;
-          if (d >= 2) { const double p = product(nxt, t, s - 1); if (lane < TS) part_n[d * TS + lane] = p; }
+          for (int t = 0; t < RPW; t++) {
+            const int d = wave + 1 + NW * t;
+            if (d >= 2) { const double p = product(nxt, t, s - 1); if (lane < TS) part_n[d * TS + lane] = p; }
+          }
+          if (ROLE == 1 && lane < TS) {
+            double p = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) p = fma(nxt.aux[r], xcr[r], p);
+            part_n[lane] = p;
+          }
         }
-        if (wave == 1 && lane < TS) {
+        // ---- wave 0: block s
+        if (ROLE == 0 && s < nT) {
+          double v = cur.aux[4] - product(cur, 0, s);      // y_s - X_{s+1,s}^T x_{s+1}
+          v -= part_s[ccol];                               // camera term
+#pragma unroll
+          for (int i = 2; i <= BT; i++) v -= part_s[i * TS + ccol];
+          // x[c] = sum_r Linv[r][c] v[r]   (v is replicated in every 16-lane group)
           double p = 0.0;
 #pragma unroll
-          for (int r = 0; r < 6; r++) p = fma(nxt.aux[r], xcr[r], p);
-          part_n[lane] = p;
+          for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
+          p = sum_rows(p);
+          if (lane < TS) { xw[(s & (BT - 1)) * TS + lane] = p; xg[TS * s + lane] = p; }
         }
+        lds_barrier();
       }
-      // ---- wave 0: block s
-      if (wave == 0 && s < nT) {
-        double v = cur.aux[4] - product(cur, 0, s);      // y_s - X_{s+1,s}^T x_{s+1}
-        v -= part_s[ccol];                               // camera term
-#pragma unroll
-        for (int i = 2; i <= BT; i++) v -= part_s[i * TS + ccol];
-        // x[c] = sum_r Linv[r][c] v[r]   (v is replicated in every 16-lane group)
-        double p = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) p = fma(cur.aux[q], __shfl(v, crow + 4 * q, 64), p);
-        p = sum_rows(p);
-        if (lane < TS) { xw[(s & (BT - 1)) * TS + lane] = p; xg[TS * s + lane] = p; }
-      }
-      lds_barrier();
     }
-  }
+  };
+  if (wave == 0) run(std::integral_constant<int, 0>{});
+  else if (wave == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 2>{});
   __syncthreads();
 }
 

@@ -11,7 +11,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from defslam_amd import sft, synth  # noqa: E402
 
-sizes = [int(a) for a in sys.argv[1:]] or [512, 2048]
+args = sys.argv[1:]
+if "--lib" in args:      # an A/B build of the lab library (tools/ab_build.sh)
+    i = args.index("--lib")
+    from defslam_amd import _lib
+    _lib.LAB_LIB_PATH = os.path.abspath(args[i + 1])
+    del args[i:i + 2]
+tails = (0, 1, 2, 3, 4, 6)
+if "--tail" in args:     # thresholds to try (default: all)
+    i = args.index("--tail")
+    tails = tuple(int(v) for v in args[i + 1].split(","))
+    del args[i:i + 2]
+sizes = [int(a) for a in args] or [512, 2048]
 rows, cols, m = synth.CONFIGS["C2"]
 tmpl = synth.make_grid_template(rows, cols)
 regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
@@ -20,7 +31,7 @@ ctx.template_build(tmpl.xyz0, tmpl.facets)
 for B in sizes:
     syn = [synth.make_frame(tmpl, m, p) for p in range(B)]
     ref = None
-    for tail in (0, 1, 2, 3, 4, 6):
+    for tail in tails:
         ctx.set_option("tail", tail)
         fs = [sft.frame_from_synth(fr) for fr in syn]
         ctx.batch_upload(fs, *regs, 1, 50)
