@@ -164,7 +164,7 @@ struct dsh_ctx : dsh_ctx_base {
   bool ran = false;
   // Solver selection.  The product library always takes the defaults; libdefslam_hip_lab.so can override them through
   // dsh_lab_set_option (include/defslam_hip_debug.h) for A/B runs.  No environment variables are read.
-  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = 2; int owner_waves = 8; int helpers_wbt = 12; } opt;
+  struct { int waves = 0; int dataflow = 1; int wide_off = 0; int speculate = 0; int split = 2; int rounds = 1; int streams = 0; int helpers = -1; int tail = -1; int owner_waves = 8; int helpers_wbt = 12; } opt;
   bool any_split = false;              // some problem of the batch runs the two-sided factorisation (SftPart): a FACTOR launch precedes every trial launch
 };
 
@@ -331,7 +331,13 @@ int run_rounds_enqueue(dsh_ctx* c) {
   // tail kernel takes 0.5 ms per trial).  WHEN the rounds end is decided on the device, by the first kernel of a round from the count the
   // previous round left -- the results do not depend on how the launches are grouped here; a tail launch in front of the switch, like a round
   // behind it, leaves at its first instruction.
-  const int tail_below = (c->opt.tail && S == 1) ? c->opt.tail * c->num_cus : -1;
+  // The threshold (A/B over batch sizes, tools/tail_ab.py): four problems per CU -- but not more than three quarters of the batch (a batch of
+  // four per CU would run in the tail kernel alone: 234 against 277 k it/s), and a batch of two per CU or less does run there alone.
+  int tail_below = -1;
+  if (S == 1 && c->opt.tail != 0) {
+    if (c->opt.tail > 0) tail_below = c->opt.tail * c->num_cus;                                                    // (lab option: exactly this many per CU)
+    else tail_below = std::min(4 * c->num_cus, std::max(2 * c->num_cus, (int)((long long)3 * B / 4)));
+  }
   auto launch = [&](int s, int phase) {
     const bool ev = c->phase_events && S == 1;
     if (ev) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, c->stream); c->phase_events->push_back(e); c->phase_ids.push_back(phase); } }
@@ -1351,7 +1357,7 @@ int dsh_lab_set_option(dsh_ctx* c, const char* name, int value) {
   else if (k == "helpers_wbt") { if (value < 1 || value > 16) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers_wbt is 1..16 (tiles of half-bandwidth from which parts get helper workgroups)"); c->opt.helpers_wbt = value; }
   else if (k == "owner_waves") { if (value != 8 && value != 16) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: owner_waves is 8 or 16 (wavefronts of a FACTOR workgroup with helpers)"); c->opt.owner_waves = value; }
   else if (k == "helpers") { if (value < -1 || value > 3) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: helpers is -1 (automatic) or 0..3 workgroups per part"); c->opt.helpers = value; }
-  else if (k == "tail") { if (value < 0 || value > 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: tail is 0 (rounds to the end) or the number of problems per CU from which downwards the last problems go to the tail kernel (default 2)"); c->opt.tail = value; }
+  else if (k == "tail") { if (value < -1 || value > 8) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: tail is -1 (automatic), 0 (rounds to the end) or the number of problems per CU from which downwards the last problems go to the tail kernel"); c->opt.tail = value; }
   else if (k == "speculate") { if (value < 0 || value > SFT_SPEC_MAXK) return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: speculate is 0 (automatic) or 1..4 lanes"); c->opt.speculate = value; }
   else return fail(c, DSH_ERR_ARG, "dsh_lab_set_option: unknown option " + k);
   return DSH_OK;

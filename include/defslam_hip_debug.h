@@ -41,8 +41,9 @@ extern "C" {
  *   "helpers_wbt"  12 (default) = the half-bandwidth in tiles from which parts get helpers (C2, 8 tiles, with helpers: 4.0 against 3.8 ms per frame)
  *   "owner_waves"  8 (default) | 16 = wavefronts of a FACTOR workgroup when there are helpers: 16 runs sft_part_factor_kernel -- one live row
  *              per wave, four wavefronts per SIMD; the same bits, 31.7 against 24.5 ms per C5 frame: a column is bound by what its waves issue
- *   "tail"     2 (default) = the last problems of a step of the throughput shape -- from two per CU downwards -- are run to their end by
- *              sftb_tail_kernel (one workgroup per problem); 1..8 = another threshold in problems per CU, 0 = rounds of phase kernels to the end
+ *   "tail"     -1 (default) = automatic: the last problems of a step of the throughput shape -- from four per CU downwards, at most three quarters of
+ *              the batch, a batch of two per CU or less as a whole -- are run to their end by sftb_tail_kernel (one workgroup per problem);
+ *              1..8 = exactly that many problems per CU, 0 = rounds of phase kernels to the end
  *              (the eight-wavefront solver of the tail kernel rounds differently from the one-wavefront solver: same trajectories, x to 5e-13) */
 int dsh_lab_set_option(dsh_ctx* ctx, const char* name, int value);
 /* How problem b of the uploaded batch is solved: out[8] = {two-sided factorisation on?, first separator scalar c0, separator

@@ -151,7 +151,7 @@ def rounds_ctx(lab_ctx):
     what test_benched_shape_matches_oracle_under_load runs.)"""
     lab_ctx.set_option("tail", 0)
     yield lab_ctx
-    lab_ctx.set_option("tail", 2)
+    lab_ctx.set_option("tail", -1)
 
 
 def test_tail_kernel_finishes_what_the_rounds_leave_like_the_rounds_would(lab_ctx, oracle_mod):
@@ -187,7 +187,7 @@ def test_tail_kernel_finishes_what_the_rounds_leave_like_the_rounds_would(lab_ct
         if tail:
             ph, nr = lab_ctx.rounds_timed()
             assert ph["tail"] > 0.0 and nr >= 1, (ph, nr)            # both parts of the step ran
-    lab_ctx.set_option("tail", 2)
+    lab_ctx.set_option("tail", -1)
     fr_r, in_r = runs["rounds"]
     fr_t, in_t = runs["tail"]
     fr_u, in_u = runs["tail2"]

@@ -52,5 +52,5 @@ for B in sizes:
             same = sum(a[1:3] == b[1:3] and np.array_equal(a[3], b[3]) for a, b in zip(ref, res))
             msg = f"; max vertex difference to tail=0 {dv:.2e}, {same} of {B} problems with the same iterations / trials / outliers"
         print(f"C2 x{B} tail={tail}: {ms:.2f} ms per step, {it / ms * 1e3:.0f} it/s, {it} iterations, {tr} trials, {nr} rounds, phases {ph}{msg}", flush=True)
-ctx.set_option("tail", 2)
+ctx.set_option("tail", -1)
 ctx.close()
