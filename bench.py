@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector == matrix peak
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def kernel_source_hash() -> str:
@@ -89,6 +89,36 @@ def cpu_baseline(tmpl, m, budget_s, gpu_frames=None):
                      f"D={D}; oracle/sft_oracle.c ldlt_mode=0 (Eigen-style pivoted dense LDLT), 1 thread, timing build {oracle.FAST_FLAGS} "
                      f"(reference binary not buildable: Eigen/OpenCV absent)",
            "lm_trials_per_s": trials / med, "frames_per_s": 1.0 / med}
+    # ---- the reference's own default problem size (e2e.reference_default): the same frames, the same restatement, one thread
+    try:
+        rt, rm, rn, rseq = reference_default_frames()
+        rtc = oracle.template_build(rt.xyz0, rt.facets)
+
+        def rsolve(fr):
+            return oracle.sft_solve(rtc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, max_iters=50, ldlt_mode=0, fast=True)
+        rf0 = synth.make_frame(rt, rm, 0)
+        rr = rsolve(rf0)
+        rts = []
+        for _ in range(9):
+            t0 = time.perf_counter()
+            rr = rsolve(rf0)
+            rts.append(time.perf_counter() - t0)
+        rmed = float(np.median(rts))
+        T, x = np.eye(4, dtype=np.float32), rt.xyz0.copy()
+        rtot, rit = 0.0, 0
+        for k in range(rn):
+            fr = synth.make_sequence_frame(rt, rm, k, rn, rseq, init_xyz=x, init_Tcw=T)
+            t0 = time.perf_counter()
+            ro = rsolve(fr)
+            rtot += time.perf_counter() - t0
+            rit += ro.iters
+            T, x = ro.Tcw, ro.xyz
+        out["reference_default"] = {"single_frame": {"ms_per_frame_median": 1e3 * rmed, "frames_per_s": 1.0 / rmed, "iters": int(rr.iters), "trials": int(rr.trials), "runs": len(rts)},
+                                    "seq100": {"frames": rn, "frames_per_s": rn / rtot, "ms_per_frame_mean": 1e3 * rtot / rn, "iters_per_frame": rit / rn},
+                                    "cores": 1, "kind": "port", "dim": int(rr.dims[0]),
+                                    "what": "oracle/sft_oracle.c (dense pivoted LDLT, timing build), one thread, the frames of e2e.reference_default (warm start through its own results)"}
+    except Exception as e:  # noqa: BLE001
+        out["reference_default"] = {"error": f"{type(e).__name__}: {e}"}
     parity = None
     if gpu_frames:
         # ---- parity of the benched launch: the oracle's PARITY build (-O2 -ffp-contract=off) on the same ids
@@ -261,7 +291,56 @@ def e2e_legs(ctx, tmpl, m, frames, regs):
     c2 = dict(synth.SEQMAP)
     c2["mesh"] = (20, 25)
     out["seq_mapping_c2_template"] = seq_leg(c2, "the same sequence on the 500-node template of BASELINE configs[1] (20 x 25 grid)")
+    out["reference_default"] = reference_default_leg(ctx, regs)
     return out
+
+
+def reference_default_frames():
+    """The problem the reference's one performance claim is about ("real-time ... i7", README.md:4,30): the hard-coded 10 x 10 = 100-node template
+    (Modules/Template/TriangularMesh.cc:63-64), 1200 ORB features per frame (scripts/stereo0_template.yaml) of which 450 are matched to the
+    template here, the Mandala regularisers: D = 306.  One frame from rest, and a 100-frame sequence (smooth bend + camera loop)."""
+    from defslam_amd import synth
+    rows, cols, m = synth.CONFIGS["REF"]
+    tmpl = synth.make_grid_template(rows, cols)
+    return tmpl, m, 100, 3
+
+
+def reference_default_leg(ctx, regs):
+    """GPU side of `e2e.reference_default`: dsh_sft_solve wall clock (host buffers in and out), one frame repeated and the warm-started sequence;
+    the CPU restatement on the same frames is timed by cpu_baseline() and attached as `cpu_restatement`."""
+    from defslam_amd import sft, synth
+    tmpl, m, n_frames, seq_id = reference_default_frames()
+    ctx.template_build(tmpl.xyz0, tmpl.facets)
+    call = ctx.prepare_solve(sft.frame_from_synth(synth.make_frame(tmpl, m, 0)), *regs, 1, 50)
+    call()
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    f0 = call.frame
+    T, x = np.eye(4, dtype=np.float32), tmpl.xyz0.copy()
+    tot, iters, trials, last = 0.0, 0, 0, None
+    for k in range(n_frames):
+        fr = synth.make_sequence_frame(tmpl, m, k, n_frames, seq_id, init_xyz=x, init_Tcw=T)
+        call = ctx.prepare_solve(sft.frame_from_synth(fr), *regs, 1, 50)
+        t0 = time.perf_counter()
+        call()
+        tot += time.perf_counter() - t0
+        f = call.frame
+        iters += f.iters
+        trials += f.trials
+        last = float(np.abs(f.nodes_xyz - fr.gt_xyz).max())
+        T, x = f.Tcw, f.nodes_xyz
+    return {"template_nodes": tmpl.n, "matches": m, "n_frame_keypoints": synth.N_FRAME_KEYPOINTS, "dim": int(f0.dim), "half_bandwidth": int(f0.half_bandwidth),
+            "single_frame": {"ms_per_frame_median": 1e3 * med, "frames_per_s": 1.0 / med, "iters": int(f0.iters), "trials": int(f0.trials), "iters_per_s": f0.iters / med, "runs": 30},
+            "seq100": {"frames": n_frames, "frames_per_s": n_frames / tot, "ms_per_frame_mean": 1e3 * tot / n_frames, "iters_per_frame": iters / n_frames,
+                       "trials_per_frame": trials / n_frames, "max_vertex_error_vs_gt_last_frame": last},
+            "what": "the reference's own default problem size (10 x 10 template, TriangularMesh.cc:63-64; 1200 features per frame, scripts/stereo0_template.yaml; "
+                    "450 matches; Mandala regularisers): dsh_sft_solve wall clock, host buffers in and out -- one frame from rest repeated (median of 30), and a "
+                    "100-frame synthetic sequence warm-started frame to frame (sum of the call times; frame synthesis excluded).  One problem on one GPU: "
+                    "the latency mode (speculative damping lanes), where a 306 x 306 dense LDLT on a CPU core is cheap -- the least flattering comparison"}
 
 
 def shared_camera_leg(ctx, tmpl, m, regs, rank, world, dist, torch):
@@ -566,18 +645,25 @@ def main():
             # the same batch, HIP events on its stream (3 steps after a warm-up step); the rounds per step are added from the lab build below
             curve = {"what": "product library, prefixes of the benched batch, HIP events on dsh_stream(), 3 timed steps after one warm-up; rounds_per_step = "
                              "rounds of LIN / FACTOR / TRIAL launches one step takes (from the lab build's per-launch events on the same batches)", "points": []}
-            for Bc in [b for b in (512, 1024, 2048, 4096) if b < args.batch] + [args.batch]:
+            for Bc in [b for b in (1, 8, 32, 128, 256, 512, 1024, 2048, 4096) if b < args.batch] + [args.batch]:
                 ctx.batch_upload(frames[:Bc], *regs, 1, 50)
                 ctx.batch_run()
                 ctx.synchronize()
-                ms_c = ctx.batch_run_timed(3) / 3
+                nrep = 5 if Bc <= 512 else 3
+                ms_c = ctx.batch_run_timed(nrep) / nrep
                 it_c, tr_c = ctx.batch_counts()
                 _, cc = ctx.problem_info(0)
-                curve["points"].append({"problems": Bc, "iters_per_s": it_c / (ms_c * 1e-3), "ms_per_step": ms_c, "iters": int(it_c), "trials": int(tr_c),
-                                        "wavefronts_per_problem": int(cc[7]), "rounds_per_step": None})
+                # launch shape (include/defslam_hip.h): latency mode with K speculative lanes below half a problem per CU, then the throughput shape
+                # (tail kernel alone up to two problems per CU, rounds + tail above)
+                shape = (f"latency mode, {min(4, num_cus // Bc)} lanes per problem" if 2 * Bc <= num_cus else
+                         ("tail kernel alone" if int(cc[7]) == 1 and Bc <= 2 * num_cus else ("rounds + tail kernel" if int(cc[7]) == 1 else f"persistent kernel, {int(cc[7])} wavefronts per problem")))
+                curve["points"].append({"problems": Bc, "iters_per_s": it_c / (ms_c * 1e-3), "ms_per_step": ms_c, "us_per_problem": 1e3 * ms_c / Bc, "iters": int(it_c), "trials": int(tr_c),
+                                        "wavefronts_per_problem": int(cc[7]), "shape": shape, "rounds_per_step": None})
             full = curve["points"][-1]["iters_per_s"]
             for pt in curve["points"]:
                 pt["fraction_of_full_batch_rate"] = pt["iters_per_s"] / full
+            rates = [pt["iters_per_s"] for pt in curve["points"]]
+            curve["monotone"] = bool(all(b >= a for a, b in zip(rates, rates[1:])))
             out["batch_curve"] = curve
         if not args.no_extra_legs and not shared_hung:   # (a context stuck in a hung collective cannot run the other legs)
             # single-problem latency leg (the >=200 iters/s target of BASELINE.json is for ONE problem on one GPU)
@@ -603,7 +689,7 @@ def main():
             lab.template_build(tmpl.xyz0, tmpl.facets)
             if curve is not None:   # rounds per step of the smaller batches of the curve
                 for pt in curve["points"][:-1]:
-                    if pt["wavefronts_per_problem"] != 1:
+                    if pt["wavefronts_per_problem"] != 1 or pt["problems"] <= 2 * num_cus:
                         continue
                     lab.batch_upload(frames[:pt["problems"]], *regs, 1, 50)
                     lab.batch_run()
@@ -643,6 +729,7 @@ def main():
                                       "traffic": traffic_phase.get("lin"), "traffic_over_algorithmic": (traffic_phase["lin"] / bytes_lin) if "lin" in traffic_phase else None,
                                       "what": "every linearisation of a step (residuals + records + normal equations of the problems that start an iteration), "
                                               "algorithmic bytes over the kernel's own time"}
+                out["hbm_assembly"] = {k: rf["hbm_assembly"][k] for k in ("kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "linearisations_in_rounds")}   # (the production number at the top level of the line as well)
                 fs = (stream_trial * float(n_fact)) / (ph["factor"] * 1e-3) / 1e9
                 rf["hbm_solver_stream"] = {"kernel": "sftb_factor_kernel", "achieved": fs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fs / HBM_PEAK_GBS,
                                            "bytes_per_trial": stream_trial, "achievable_stream_GBps_this_box": 5400.0,
@@ -658,6 +745,13 @@ def main():
             out["cpu_baseline"], parity = cpu_baseline(tmpl, m, args.cpu_seconds, gpu_sample)
             if parity is not None:
                 out["parity_check"] = parity
+            ref_cpu = out["cpu_baseline"].pop("reference_default", None)
+            if ref_cpu is not None and "reference_default" in out.get("e2e", {}):
+                rd = out["e2e"]["reference_default"]
+                rd["cpu_restatement"] = ref_cpu
+                if "single_frame" in ref_cpu:
+                    rd["gpu_over_cpu"] = {"single_frame": rd["single_frame"]["frames_per_s"] / ref_cpu["single_frame"]["frames_per_s"],
+                                          "seq100": rd["seq100"]["frames_per_s"] / ref_cpu["seq100"]["frames_per_s"]}
         flush_c_stdio()
         print(json.dumps(out), flush=True)
     if shared_hung:

@@ -27,7 +27,7 @@
 extern "C" hipError_t sft_lm_launch(const SftDev* d_probs, int B, int max_kd, size_t jl_doubles, int nw, size_t* configured, hipStream_t stream);
 extern "C" size_t sft_lm_kernel_lds_bytes(int kd, size_t jl_doubles);
 extern "C" hipError_t sftb_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int* d_list, int B, int phase, size_t jl_doubles, size_t xyz_doubles, size_t* configured, int num_cus, int tail_below, hipStream_t stream);
-extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream);
+extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, int tail_below, hipStream_t stream);
 extern "C" hipError_t sft_spec_launch(const SftDev* d_probs, SftSpec* d_spec, int B, int K, int phase, int nh, int owner_waves, int max_kd, size_t jl_doubles, size_t* configured, hipStream_t stream);
 
 // The dynamic LDS size a kernel has been enabled for (hipFuncSetAttribute) is a property of the (device, kernel) pair, not of a context: two
@@ -344,7 +344,7 @@ int run_rounds_enqueue(dsh_ctx* c) {
     hipError_t r;
     {
       LDS_LOCK();
-      if (phase == SFTB_PH_TAIL) r = sftb_tail_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, b0[s + 1] - b0[s], c->max_kd, c->jl_doubles, &LDS_MARKS(c).tail, c->num_cus, c->sub_stream[s]);
+      if (phase == SFTB_PH_TAIL) r = sftb_tail_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, b0[s + 1] - b0[s], c->max_kd, c->jl_doubles, &LDS_MARKS(c).tail, c->num_cus, tail_below, c->sub_stream[s]);
       else r = sftb_launch(c->d_probs + b0[s], c->d_runs + b0[s], c->d_counters + 16 * s, c->d_linlist + b0[s], b0[s + 1] - b0[s], phase, c->jl_doubles, c->xyz_doubles, LDS_MARKS(c).b,
                            c->num_cus, tail_below, c->sub_stream[s]);
     }
@@ -609,7 +609,11 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   {
     bool all_tiles = true;
     for (int b = 0; b < B; b++) all_tiles = all_tiles && c->packed[b].h.tile_mode == 1;
-    if (all_tiles && B >= 2 * c->num_cus) nw = 4;   // measured break-even on MI355X: about two problems per CU
+    // More problems than the latency mode takes (half a problem per CU): the throughput shape.  From two problems per CU upwards that is rounds of
+    // phase kernels + the tail kernel; below, the tail threshold (run_rounds_enqueue) covers the whole batch and the step is the tail kernel
+    // alone -- one persistent workgroup per CU pulling problems, with the LIN kernel's record placement: 12 against 14 ms per problem for the
+    // one-workgroup-per-problem kernel that ran these sizes until r06 (tools/batch_curve.py: 256 problems 13.97 -> 11.9 ms per step)
+    if (all_tiles && 2 * B > c->num_cus) nw = 4;
     if ((c->opt.waves == 4 && all_tiles) || c->opt.waves == 8) nw = c->opt.waves;   // lab builds only (dsh_lab_set_option)
     if (c->force_waves == 8) nw = 8;
     // From two problems per CU upwards the batch runs as rounds of phase kernels with one wavefront per factorisation (sft_batch.h)
@@ -630,12 +634,19 @@ int dsh_sft_batch_upload(dsh_ctx* c, int B, const dsh_sft_frame* frames) {
   // Latency mode: while CUs would idle anyway, every problem gets K of them and tries K dampings per iteration at once.
   int K = 1;
   if (nw == 8 && !c->force_waves && !c->host_only) {
-    K = (4 * B <= c->num_cus) ? 4 : ((2 * B <= c->num_cus) ? 2 : 1);
+    K = (4 * B <= c->num_cus) ? 4 : ((3 * B <= c->num_cus) ? 3 : ((2 * B <= c->num_cus) ? 2 : 1));   // as many lanes as the device holds at once
     // Wide bands (two-sided factorisation with helper workgroups, sft_wide.h): a part's helpers are worth more than the third and fourth lane when
     // the device cannot hold both -- two lanes with three helpers per part against four lanes without (C5 x 16: 47.2 against 51.0 ms per step)
+    // (the predicate is the one that grants helpers below: the problem IS cut in two parts -- wide tile mode, room for two parts of four tile
+    // columns -- and its band has at least helpers_wbt tiles; a wide band that stays undivided keeps its four lanes)
     {
-      bool wide = c->opt.split != 0;
-      for (int b = 0; b < B; b++) wide = wide && c->packed[b].h.kd > kTS * 11;
+      bool wide = c->opt.split != 0 && c->opt.helpers != 0;
+      for (int b = 0; b < B; b++) {
+        const SftDev& hh = c->packed[b].h;
+        const int sT = (hh.kd + kTS - 1) / kTS, sp = kTS * sT;
+        const int c0 = ((hh.Dn - sp) / 2 / kTS) * kTS, n1 = hh.Dn - sp - c0;
+        wide = wide && hh.tile_mode == 2 && sT >= c->opt.helpers_wbt && sT >= 2 && c0 >= 4 * kTS && n1 >= 4 * kTS;
+      }
       if (wide && K == 4 && (long long)B * 4 * 2 * 3 > c->num_cus && (long long)B * 2 * 2 * 3 <= c->num_cus) K = 2;
     }
     if (c->opt.speculate >= 1 && c->opt.speculate <= SFT_SPEC_MAXK) K = c->opt.speculate;   // lab builds only

@@ -279,13 +279,21 @@ __device__ __noinline__ void sftb_solve8(const SftDev& P, unsigned ctl_off, unsi
 // the end from its SftRun record: linearisations and trials are the code of LIN and TRIAL (same bits), the factorisation is the eight-wavefront
 // register-window solver of the persistent kernel (0.35 ms per trial; its x agrees with the one-wavefront solver's to 5e-13).  Persistent
 // workgroups pull problem indices from counters[5].
-__global__ __launch_bounds__(64 * SFTB_NW, SFT_WAVES_PER_EU) void sftb_tail_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int B) {
+__global__ __launch_bounds__(64 * SFTB_NW, SFT_WAVES_PER_EU) void sftb_tail_kernel(const SftDev* __restrict__ probs, SftRun* __restrict__ runs, int* __restrict__ counters, int B, int tail_below) {
   constexpr int NW = SFTB_NW, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Ctl* ctl; double *red, *out, *panel;
   sftb_ctl_lds(smem, ctl, red, out, panel);
   const int tid = threadIdx.x;
-  if (!counters[6]) return;   // not yet: the rounds go on
+  // The same test the LIN kernel of the next round would make, on the count the last TRIAL launch left: few enough problems -> this launch takes
+  // them (and says so for launches enqueued behind it); otherwise the rounds go on.  While the test fails nobody changes counters[0] (every
+  // workgroup of this launch leaves); once it holds the count only grows -- all workgroups decide alike.  (Until r06 only LIN raised the flag:
+  // the tail launch behind exactly as many rounds as the previous step had needed left at once, and the host paid a read-back, two empty rounds
+  // and a second tail launch per step.)
+  if (!counters[6]) {
+    if (B - counters[0] > tail_below) return;
+    if (blockIdx.x == 0 && tid == 0) counters[6] = 1;
+  }
   while (true) {
     __syncthreads();
     if (tid == 0) ctl->it = atomicAdd(&counters[5], 1);

@@ -3306,14 +3306,14 @@ extern "C" hipError_t sft_cn_launch(const SftDev* d_probs, SftSc* d_sc, int phas
   return hipGetLastError();
 }
 
-extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, hipStream_t stream) {
+extern "C" hipError_t sftb_tail_launch(const SftDev* d_probs, SftRun* d_runs, int* d_counters, int B, int max_kd, size_t jl_doubles, size_t* configured, int num_cus, int tail_below, hipStream_t stream) {
   const size_t lds = sft_lm_kernel_lds_bytes(max_kd, jl_doubles);   // the larger of the linearisation's records and the solver's workspace
   if (lds > *configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sftb_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     *configured = lds;
   }
-  hipLaunchKernelGGL(sftb_tail_kernel, dim3(std::min(B, num_cus)), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs, d_counters, B);
+  hipLaunchKernelGGL(sftb_tail_kernel, dim3(std::min(B, num_cus)), dim3(64 * SFTB_NW), lds, stream, d_probs, d_runs, d_counters, B, tail_below);
   return hipGetLastError();
 }
 

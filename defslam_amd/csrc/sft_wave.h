@@ -22,7 +22,18 @@
 //   TRSM    Y_i = X(k+i,k)^T = W D(k+i,k)            A = acc(W^T)[q]   B = acc(D)[q]
 //   update  D(k+i,k+j) -= Y_j^T Y_i                  A = acc(Y_j)[q]   B = acc(Y_i)[q]     (NEG bit on A: no negation on the VALU)
 // take every operand as it lies in registers -- no LDS round trip, no lane shuffle; only W^T is transposed through LDS once per step.
-// The 7 camera / right-hand-side rows ride along as border tiles Bd(J)^T (16 x 7) with the same two formulas, the corner as Yb^T Yb.
+// The 7 camera / right-hand-side rows ride along as border tiles Bd(J)^T (16 x 8) with the same two formulas, the corner as Yb^T Yb.
+//
+// The border on v_mfma_f64_4x4x4_4b_f64 (r06).  A 16 x 16 x 4 MFMA spends half its 64 cycles on the eight columns a border tile does not have.
+// The 4 x 4 x 4 instruction (four independent 4 x 4 blocks, 16 cycles: the same flop rate -- tools/probes/mfma4x4_probe.hip) has the operand
+// layout A_b[i][k] lane i + 4 b + 16 k, B_b[k][j] lane j + 4 b + 16 k, D_b[i][j] lane j + 4 b + 16 i, i.e. register q of a tile in accumulator
+// order IS its A operand for the k-chunk q with block b = row block b of the tile.  So D = Y_j^T Yb (16 x 8) is, per k-chunk q and column block
+// nb = 0, 1, one instruction with A = Y_j[q] as it lies and B = Yb's rows 4q..4q+3, columns 4nb..4nb+3 replicated over the four blocks:
+//   QL (result / storage layout of a border tile T, 16 x 8): two registers, reg nb lane (g, c) = T[4 (c >> 2) + g][4 nb + (c & 3)]
+//   OL (operand layout):  reg (q, nb) lane (g, c) = T[4 q + g][4 nb + (c & 3)]  =  QL reg nb of lane (g, 4 q + (c & 3))
+// A border tile lives in LDS in QL (element (lane, nb) at 2 lane + nb: one 16-byte access per lane) and is read back in OL by four 16-byte
+// reads per lane (q = 0..3; lanes c, c + 4, c + 8, c + 12 read the same address: a broadcast).  8 instead of 4 MFMAs per border product, at a
+// quarter of the cycles each.
 #pragma once
 
 // Section timers of a factorisation (shader clock, accumulated over the steps of problem; lab builds with EXTRA=-DWV_STEP_TRACE): P.dbg[40 + e],
@@ -164,22 +175,53 @@ __device__ __forceinline__ void wv_lds_store(lds_double* tile, int lane, const v
   p[lane] = (v2d_w){v[0], v[1]};
   p[64 + lane] = (v2d_w){v[2], v[3]};
 }
-// border tiles: 7 columns (+ a zero one) carry data.  The LDS image keeps the 32 lanes c < 8 -- half the bytes, which is what makes room for
-// the landing buffer -- and the lanes c >= 8 MIRROR the lanes c - 8 (same address): every lane holds finite numbers without a zero fill or
-// an execution mask, the duplicate columns ride through TRSM and update untouched by anything that is read (corner: rows / columns < 7;
-// back substitution: multiplied by xb = 0), and the duplicate lanes store the same values to the same place.
-__device__ __forceinline__ v4d wv_bord_load(const lds_double* tile, int lane) {
-  const int li = (lane >> 4) * 8 + (lane & 7);
-  const lds_v2d* p = reinterpret_cast<const lds_v2d*>(tile);
-  const v2d_w a = p[li], b = p[32 + li];
-  return (v4d){a.x, a.y, b.x, b.y};
+// border tiles (16 x 8: 7 rows of the border + a zero one) in the quad layout QL of the 4 x 4 x 4 MFMA (head of the file)
+struct WvB2 { double n0, n1; };                 // QL: reg nb = columns 4 nb .. 4 nb + 3
+struct WvBO { double v[4][2]; };                // OL: [q][nb]
+__device__ __forceinline__ WvB2 wv_bq_load(const lds_double* tile, int lane) {
+  const v2d_w a = reinterpret_cast<const lds_v2d*>(tile)[lane];
+  return WvB2{a.x, a.y};
 }
-__device__ __forceinline__ void wv_bord_store(lds_double* tile, int lane, const v4d& v) {
-  const int li = (lane >> 4) * 8 + (lane & 7);
-  lds_v2d* p = reinterpret_cast<lds_v2d*>(tile);
-  p[li] = (v2d_w){v[0], v[1]};
-  p[32 + li] = (v2d_w){v[2], v[3]};
+__device__ __forceinline__ void wv_bq_store(lds_double* tile, int lane, const WvB2& v) {
+  reinterpret_cast<lds_v2d*>(tile)[lane] = (v2d_w){v.n0, v.n1};
 }
+// the lane's OL source lane for q = 0: (g, c & 3); q adds 4 lanes = 4 v2d
+__device__ __forceinline__ int wv_bo_lane(int lane) { return (lane & 0x30) | (lane & 3); }
+__device__ __forceinline__ void wv_bo_load(const lds_double* tile, int lane, WvBO& o) {
+  const lds_v2d* p = reinterpret_cast<const lds_v2d*>(tile) + wv_bo_lane(lane);
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const v2d_w a = p[4 * q]; o.v[q][0] = a.x; o.v[q][1] = a.y; }
+}
+// C (QL) -= A^T-chunks x B (OL): 8 MFMAs of 16 cycles, the two column blocks alternate (independent accumulators)
+__device__ __forceinline__ void wv_upd_b4(WvB2& C, const v4d& A, const WvBO& B, int q0 = 0) {
+#define WV_MF(q) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %2, %3, %0 neg:[1,0,0]\n\tv_mfma_f64_4x4x4_4b_f64 %1, %2, %4, %1 neg:[1,0,0]" \
+                              : "+v"(C.n0), "+v"(C.n1) : "v"(A[q]), "v"(B.v[q][0]), "v"(B.v[q][1]) : "memory")
+  asm volatile("s_nop 1" : "+v"(C.n0), "+v"(C.n1));
+  if (q0 <= 0) WV_MF(0);
+  if (q0 <= 1) WV_MF(1);
+  if (q0 <= 2) WV_MF(2);
+  WV_MF(3);
+#undef WV_MF
+}
+// Yb (QL) = W Bd(k)^T: A = acc(W^T)[q], B = Bd(k)^T in OL
+__device__ __forceinline__ void wv_trsm_b4(WvB2& Y, const v4d& Wt, const WvBO& B) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %2, %6, 0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %1, %2, %7, 0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %3, %8, %0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %1, %3, %9, %1\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %4, %10, %0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %1, %4, %11, %1\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %5, %12, %0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %1, %5, %13, %1"
+               : "=&v"(Y.n0), "=&v"(Y.n1)
+               : "v"(Wt[0]), "v"(Wt[1]), "v"(Wt[2]), "v"(Wt[3]), "v"(B.v[0][0]), "v"(B.v[0][1]), "v"(B.v[1][0]), "v"(B.v[1][1]), "v"(B.v[2][0]), "v"(B.v[2][1]),
+                 "v"(B.v[3][0]), "v"(B.v[3][1])
+               : "memory");
+}
+// a QL tile (LDS image or landing buffer) read as the tile in ACCUMULATOR order restricted to its 8 columns: lane (g, c), register q =
+// T[g + 4 q][c & 7] (the lanes c >= 8 mirror c - 8: finite numbers everywhere): element at 2 (16 g + 4 q + (c & 3)) + ((c >> 2) & 1)
+__device__ __forceinline__ int wv_bstd_index(int lane) { return 2 * wv_bo_lane(lane) + ((lane >> 2) & 1); }
 
 // ---- 16 x 16 Cholesky + inverse, every MFMA as asm on VGPR tiles (tile_chol.h: chol_inv_blocked is the compiler-scheduled original) --
 // A lane's value moved along its 16-lane row.  row_ror reads a valid lane for every lane, so the destination's previous content never shows --
@@ -200,28 +242,29 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
 #pragma unroll
   for (int J = 0; J < 4; J++) {
     const double aJ = a[J];
-    const double sel = chol4_inverse_operand(aJ, J, g, c, plast);   // (tile_chol.h: the chain of dependent operations of a block step)
+    const double sel = chol4_inverse_operand(aJ, J, g, c & 3, plast);   // (tile_chol.h: the chain of dependent operations of a block step; M replicated over the quads)
     const double wJ = w[J];
-    v4d zw, z;
+    double zw, lp;
     if (J < 3) {
+      // Zw = M W[4J..4J+3, :] and Z = M A[4J..4J+3, :]: 4 x 16 results, one 4 x 4 x 4 MFMA each (tile_chol.h); six wait states before a vector
+      // instruction may read a 4-pass result
       asm volatile("s_nop 1\n\t"
-                   "v_mfma_f64_16x16x4_f64 %0, %2, %3, 0\n\t"
-                   "v_mfma_f64_16x16x4_f64 %1, %2, %4, 0\n\t" WV_NOP_MFMA_RESULT
-                   : "=&v"(zw), "=&v"(z)
+                   "v_mfma_f64_4x4x4_4b_f64 %0, %2, %3, 0\n\t"
+                   "v_mfma_f64_4x4x4_4b_f64 %1, %2, %4, 0\n\t"
+                   "s_nop 7"
+                   : "=&v"(zw), "=&v"(lp)
                    : "v"(sel), "v"(wJ), "v"(aJ));
-      const double lp = z[0];
       const double nlp = -lp;
       const double below = (c >= 4 * J + 4) ? nlp : 0.0;
-      const double zw0 = zw[0];
       asm volatile("s_nop 1\n\t"
                    "v_mfma_f64_16x16x4_f64 %0, %2, %3, %0\n\t"
                    "v_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\t" WV_NOP_MFMA_RESULT
                    : "+v"(a), "+v"(w)
-                   : "v"(nlp), "v"(lp), "v"(below), "v"(zw0));
-      w[J] = zw0;
+                   : "v"(nlp), "v"(lp), "v"(below), "v"(zw));
+      w[J] = zw;
     } else {
-      asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0\n\t" WV_NOP_MFMA_RESULT : "=&v"(zw) : "v"(sel), "v"(wJ));
-      w[J] = zw[0];
+      asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0\n\ts_nop 7" : "=&v"(zw) : "v"(sel), "v"(wJ));
+      w[J] = zw;
     }
   }
   return plast > 0.0;
@@ -231,7 +274,7 @@ __device__ __forceinline__ bool wv_chol_inv(v4d& a, v4d& w) {
 struct WvProb {
   int Dn, Dnp, nT, q8;                    // q8: leading row chunks of the d = 8 corner tile that are structurally zero (kd = 122: 1)
   double lambda, lam_corner;
-  unsigned bofs;                          // per lane: c * Dnp + g, the lane's element of a border tile relative to column 16 J (doubles)
+  unsigned bofs;                          // per lane: (c & 3) * Dnp + 4 (c >> 2) + g, the lane's QL element (nb = 0) of a border tile relative to column 16 J (doubles); nb = 1: + 4 Dnp
   const SFT_G double* Hc;
   const SFT_G uint32_t* hgl;              // the TRANSPOSED gather lists (SftDev::hgatherT): 16 bytes per lane and tile
   const SFT_G double* Hbord;
@@ -253,13 +296,12 @@ __device__ __forceinline__ v4d wv_gather_vgpr(const WvProb& W, const unsigned (&
   for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const SFT_G double*>(b8 + o[q]);
   return v;
 }
-// border tile Bd(J)^T from the 8-row border of H (rows 0-5 camera, 6 right-hand side, 7 zero): lane (g, c), register q = Hbord[c][16 J + g + 4q]
-__device__ __forceinline__ v4d wv_border_fresh(const WvProb& W, int J, int lane) {
-  v4d v;
-  const SFT_G double* p = W.Hbord + TS * (J < W.nT ? J : W.nT);   // (behind the matrix, J >= nT: the row pitch is Dnp, so what is read there is finite data of the NEXT border row -- never consumed: those ring slots are never a pivot column and their Y operands are zero; lanes c >= 8 mirror c - 8)
-#pragma unroll
-  for (int q = 0; q < 4; q++) v[q] = p[W.bofs + 4 * q];
-  return v;
+// border tile Bd(J)^T (QL) from the 8-row border of H (rows 0-5 camera, 6 right-hand side, 7 zero): lane (g, c), register nb =
+// Hbord[4 nb + (c & 3)][16 J + 4 (c >> 2) + g]
+__device__ __forceinline__ WvB2 wv_border_fresh(const WvProb& W, int J, int lane) {
+  const SFT_G double* p = W.Hbord + TS * (J < W.nT ? J : W.nT);   // (behind the matrix, J >= nT: the row pitch is Dnp, so what is read there is finite data of the NEXT border row -- never consumed: those ring slots are never a pivot column and their Y operands are zero)
+  (void)lane;
+  return WvB2{p[W.bofs], p[W.bofs + 4 * (unsigned)W.Dnp]};
 }
 
 // Lists of the eight tiles (I, d), d = 0..7, of a row that enters the window: 32 offsets per lane, requested a step ahead.
@@ -312,9 +354,8 @@ __device__ __forceinline__ void wv_bs_column(const WvPrev& Q, int J, const lds_d
   const lds_v2d* t2 = reinterpret_cast<const lds_v2d*>(land) + 2 * lane;   // the lane's 32 bytes of tile 0; tile i: + 128 * i
   double s[4];
   {
-    const lds_v2d* tb = reinterpret_cast<const lds_v2d*>(land) + 2 * ((lane >> 4) * 8 + (lane & 7));   // Yb: 32 kept lanes, the others mirror c - 8
-    const v2d_w a = tb[0], b = tb[1];
-    s[0] = a.x * Q.xb; s[1] = a.y * Q.xb; s[2] = b.x * Q.xb; s[3] = b.y * Q.xb;
+    const lds_double* tb = land + wv_bstd_index(lane);   // Yb is stored in QL (1 KB): element [g + 4 q][c & 7]; the lanes c >= 8 mirror c - 8 (times xb = 0)
+    s[0] = tb[0] * Q.xb; s[1] = tb[8] * Q.xb; s[2] = tb[16] * Q.xb; s[3] = tb[24] * Q.xb;
   }
 #pragma unroll
   for (int d = 1; d <= 8; d++) {
@@ -360,7 +401,10 @@ __device__ __forceinline__ void wv_backsub_now(const WvPrev& Q, int lane) {
       const SFT_G double* col = Q.Lg + ((size_t)J * (BT + 1)) * 256 + 4 * lane;
 #pragma unroll
       for (int i = 1; i <= 8; i++) C.t[i] = (J + i < Q.nT) ? *reinterpret_cast<const SFT_G v4d*>(col + 256 * i) : (v4d){0.0, 0.0, 0.0, 0.0};
-      C.t[0] = *reinterpret_cast<const SFT_G v4d*>(col - 4 * lane + 4 * ((lane >> 4) * 8 + (lane & 7)));   // Yb: stored as its 32 lanes c < 8
+      {   // Yb: stored in QL (1 KB)
+        const SFT_G double* tb = col - 4 * lane + wv_bstd_index(lane);
+        C.t[0] = (v4d){tb[0], tb[8], tb[16], tb[24]};
+      }
       C.t[9] = *reinterpret_cast<const SFT_G v4d*>(Q.Linv + (size_t)J * 256 + 4 * lane);
     } else {
 #pragma unroll
@@ -408,29 +452,30 @@ __device__ __forceinline__ void wv_backsub_now(const WvPrev& Q, int lane) {
 
 // ---- one factor step, ring phase PH = k mod 8 ------------------------------------------------------------------------------------------
 struct WvState {
-  v4d Y[9];          // Y[i], i = 1..8: X(k+i,k)^T; Y[0]: the border tile Xb^T of column k
-  v4d corner;        // 7 x 7 camera corner (+ right-hand side row), accumulator order, lower triangle meaningful
+  v4d Y[9];          // Y[i], i = 1..8: X(k+i,k)^T ([0] is not used: the border tile Xb^T of column k is Yq / Yo)
+  WvB2 Yq;           // Xb^T of column k in QL, as its TRSM leaves it: stored to L behind the first update tile
+  WvBO Yo;           // ... and in OL (through the W scratch in LDS): the B operand of the border updates
+  double corner;     // 7 x 7 camera corner (+ right-hand side row) as the four blocks of a 4 x 4 x 4 MFMA: lane (g, c) = [4 (c >> 3) + g][4 ((c >> 2) & 1) + (c & 3)]; lower triangle meaningful
   v4d araw;          // raw tile (k+8, k)^T of this step's column (the d = 8 corner of the band): requested at the head of the step
-  v4d bnext;         // raw border tile of column k+8 (enters the ring this step): requested at the head of the step
+  WvB2 bnext;        // raw border tile of column k+8 (QL; enters the ring this step): requested at the head of the step
   WvRowList rl;      // gather lists of the row that enters the window this step (row k+8): requested at the head of the step
   unsigned al[4];    // gather list of tile (k+9, k+1), the next step's araw -- the only request that is carried across the update
-  unsigned off_lane, off_bord;   // byte offsets of the lane inside a 2 KB tile slot of L (32 l) and inside the compact border tile
+  unsigned off_lane, off_bord;   // byte offsets of the lane inside a 2 KB tile slot of L (32 l) and inside the 1 KB border tile (QL: 16 l)
   int ok;
 };
 
-template <int PH, int I>
-__device__ __forceinline__ void wv_trsm_cols(WvState& S, const v4d& Wt, int k, int nT, const lds_double* ldsw, int lane) {
-  if constexpr (I <= 7) {
+template <int PH, int I, int IEND>
+__device__ __forceinline__ void wv_trsm_cols(WvState& S, const v4d& Wt, int k, int nT, const v4d& D4, int lane) {
+  if constexpr (I <= IEND) {
     // unconditional: behind the matrix the window tiles are the zeros they were gathered as (list row nT), W 0 = 0 -- a branch per tile made
     // the compiler write zeros into all nine Y tiles in front of it, every step (28 register moves), to save 36 tile products per factorisation
     (void)k; (void)nT;
     if constexpr (I == 4) {
-      const v4d D = wv_lds_load(ldsw + 256 * (wv_phys((PH + 4) & 7, 4) - WV_AGPR_TILES), lane);
-      wv_trsm_vgpr(S.Y[4], Wt, D);
+      wv_trsm_vgpr(S.Y[4], Wt, D4);   // (the LDS-resident d = 4 tile of the column: requested in front of the W transposition)
     } else {
       wv_trsm_agpr<wv_phys((PH + I) & 7, I)>(S.Y[I], Wt);
     }
-    wv_trsm_cols<PH, I + 1>(S, Wt, k, nT, ldsw, lane);
+    wv_trsm_cols<PH, I + 1, IEND>(S, Wt, k, nT, D4, lane);
   }
 }
 
@@ -465,15 +510,15 @@ __device__ __forceinline__ void wv_update_tiles(const WvProb& W, WvState& S, int
       if constexpr (I <= 7) {
         constexpr int n = wv_tile_index(I, J);
         if constexpr (n < 18) {   // half (n & 1) of tile n / 2: lanes' registers 2 (n & 1), 2 (n & 1) + 1
-          const v4d& y = S.Y[n >> 1];
           // scalar base (the slot of the tile, wave-uniform: SALU) + the lane's 32-bit offset + immediate: as a pointer expression every
           // store cost one or two 64-bit vector adds for its address (35 vector instructions per step on the one FP64 pipe)
-          const v2d_w half = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
           const SFT_G double* slot = col + 256 * (n >> 1);
-          if constexpr (n < 2) {   // the border tile Yb: only its 32 lanes c < 8 carry data (the others mirror them) -- 1 KB instead of 2
-            const int ln = threadIdx.x & 63;
-            if ((ln & 15) < 8) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3" :: "v"(S.off_bord), "v"(half), "s"(slot), "n"(16 * (n & 1)) : "memory");
-          } else {
+          if constexpr (n == 0) {   // the border tile Yb in QL: 16 bytes per lane, 1 KB, one store (n == 1: its slot has no second half)
+            const v2d_w yb = (v2d_w){S.Yq.n0, S.Yq.n1};
+            asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(S.off_bord), "v"(yb), "s"(slot) : "memory");
+          } else if constexpr (n >= 2) {
+            const v4d& y = S.Y[n >> 1];
+            const v2d_w half = (v2d_w){y[2 * (n & 1)], y[2 * (n & 1) + 1]};
             asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3" :: "v"(S.off_lane), "v"(half), "s"(slot), "n"(16 * (n & 1)) : "memory");
           }
         }
@@ -504,28 +549,30 @@ __device__ __forceinline__ lds_double* wv_task_tile(lds_double* lds) {
   else if constexpr (T == 10) return lds + WV_L_BORD + 128 * (PH & 7);                                        // column k+8: ring slot k mod 8
   else return lds + WV_L_WIN + 256 * (wv_phys(PH & 7, 4) - WV_AGPR_TILES);                                     // row 8: ring row k mod 8
 }
+template <int T> struct WvTaskTile { using type = typename std::conditional<(T < 7 || T == 10), WvB2, v4d>::type; };   // border tiles: QL, two registers
+template <int T> using wv_task_t = typename WvTaskTile<T>::type;
 template <int PH, int T>
-__device__ __forceinline__ v4d wv_task_load(lds_double* lds, int lane) {
-  if constexpr (T < 7 || T == 10) return wv_bord_load(wv_task_tile<PH, T>(lds), lane);
+__device__ __forceinline__ wv_task_t<T> wv_task_load(lds_double* lds, int lane) {
+  if constexpr (T < 7 || T == 10) return wv_bq_load(wv_task_tile<PH, T>(lds), lane);
   else return wv_lds_load(wv_task_tile<PH, T>(lds), lane);
 }
 template <int PH, int T>
-__device__ __forceinline__ void wv_task_store(lds_double* lds, int lane, const v4d& C) {
-  if constexpr (T < 7 || T == 10) wv_bord_store(wv_task_tile<PH, T>(lds), lane, C);
+__device__ __forceinline__ void wv_task_store(lds_double* lds, int lane, const wv_task_t<T>& C) {
+  if constexpr (T < 7 || T == 10) wv_bq_store(wv_task_tile<PH, T>(lds), lane, C);
   else wv_lds_store(wv_task_tile<PH, T>(lds), lane, C);
 }
 template <int T>
-__device__ __forceinline__ void wv_task_mfma(v4d& C, const WvState& S, int q8) {
-  if constexpr (T < 7) wv_upd_vgpr(C, S.Y[T + 1], S.Y[0]);
+__device__ __forceinline__ void wv_task_mfma(wv_task_t<T>& C, const WvState& S, int q8) {
+  if constexpr (T < 7) wv_upd_b4(C, S.Y[T + 1], S.Yo);
   else if constexpr (T < 10) wv_upd_vgpr(C, S.Y[T - 6], S.Y[T - 2]);   // (I, J) = (5, 1), (6, 2), (7, 3)
-  else if constexpr (T == 10) wv_upd_vgpr(C, S.Y[8], S.Y[0], q8);
+  else if constexpr (T == 10) wv_upd_b4(C, S.Y[8], S.Yo, q8);
   else wv_upd_vgpr(C, S.Y[4], S.Y[8], q8);
 }
 // C: tile T, already loaded; Cprev: tile T-1, its MFMAs issued.  The load of tile T+1 is requested in front of T's MFMAs.
 template <int PH, int T, int TEND>
-__device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_double* lds, int lane, v4d& C, const v4d& Cprev) {
+__device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_double* lds, int lane, wv_task_t<T>& C, const wv_task_t<T - 1>& Cprev) {
   if constexpr (T < TEND) {
-    v4d Cn = wv_task_load<PH, T + 1>(lds, lane);
+    wv_task_t<T + 1> Cn = wv_task_load<PH, T + 1>(lds, lane);
     wv_task_mfma<T>(C, S, q8);
     wv_task_store<PH, T - 1>(lds, lane, Cprev);
     wv_lds_pipe_next<PH, T + 1, TEND>(S, q8, lds, lane, Cn, C);
@@ -538,8 +585,8 @@ __device__ __forceinline__ void wv_lds_pipe_next(const WvState& S, int q8, lds_d
 }
 template <int PH, int T0, int TEND>
 __device__ __forceinline__ void wv_lds_pipe(const WvState& S, int q8, lds_double* lds, int lane) {
-  v4d C = wv_task_load<PH, T0>(lds, lane);
-  v4d Cn = wv_task_load<PH, T0 + 1>(lds, lane);
+  wv_task_t<T0> C = wv_task_load<PH, T0>(lds, lane);
+  wv_task_t<T0 + 1> Cn = wv_task_load<PH, T0 + 1>(lds, lane);
   wv_task_mfma<T0>(C, S, q8);
   wv_lds_pipe_next<PH, T0 + 1, TEND>(S, q8, lds, lane, Cn, C);
 }
@@ -557,17 +604,47 @@ __device__ __forceinline__ v4d wv_step_diag(const WvProb& W, int k, int lane) {
 
 // Part B (behind the tile Cholesky): TRSM of block column k, the row that enters the window, the trailing update.
 template <int PH, bool TAIL>
-__device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& Wt, int k, lds_double* lds, int lane, const WvPrev& Q WV_T_ARG) {
+__device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const v4d& w, int k, lds_double* lds, int lane, const WvPrev& Q WV_T_ARG) {
   lds_double* ldsw = lds + WV_L_WIN;
   lds_double* ldsb = lds + WV_L_BORD;
+  lds_double* wscr = lds + WV_L_WSCR;
   const int nT = W.nT;
-  // ---- block column k: Y_i = W D(k+i, k), border Yb = W Bd(k)^T
-  wv_trsm_cols<PH, 1>(S, Wt, k, nT, ldsw, lane);
-  wv_trsm_vgpr(S.Y[8], Wt, S.araw, W.q8);
+  // The two LDS-resident operands of the TRSM -- the border tile of column k (OL) and the d = 4 window tile -- are requested in FRONT of the
+  // W transposition: they travel while W goes through LDS, and the TRSM starts with everything in registers (requested right in front of
+  // their first use they cost a full LDS round trip each, ~250 cycles per step, with the matrix pipe idle).
+  WvBO Bk;
+  wv_bo_load(ldsb + 128 * PH, lane, Bk);
+  const v4d D4 = wv_lds_load(ldsw + 256 * (wv_phys((PH + 4) & 7, 4) - WV_AGPR_TILES), lane);
+  // W^T in accumulator order: through LDS (element [row][col] at row * 17 + col)
+  v4d Wt;
   {
-    const v4d Bk = wv_bord_load(ldsb + 128 * PH, lane);
-    wv_trsm_vgpr(S.Y[0], Wt, Bk);
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; q++) wscr[(g + 4 * q) * 17 + c] = w[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) Wt[q] = wscr[c * 17 + g + 4 * q];
   }
+  WV_T(2);
+  // ---- block column k: border Yb = W Bd(k)^T (4 x 4 x 4 MFMAs; first, so that its trip through LDS into the operand layout lies behind
+  // the window's TRSMs), Y_i = W D(k+i, k)
+  wv_trsm_b4(S.Yq, Wt, Bk);
+  wv_trsm_cols<PH, 1, 2>(S, Wt, k, nT, D4, lane);   // (W^T has been read from the scratch: LDS instructions of a wave complete in order)
+  wv_bq_store(wscr, lane, S.Yq);        // (8 MFMAs behind its own: complete)
+  wv_trsm_cols<PH, 3, 4>(S, Wt, k, nT, D4, lane);
+  // ... and back in the operand layouts while the other sixteen MFMAs of the TRSM run: OL for the border updates; for the corner product
+  // Yb^T Yb (8 x 8 = the four blocks of ONE 4 x 4 x 4 MFMA per k-chunk, block b = (row block b >> 1, column block b & 1)) the A operand
+  // (columns 4 (c >> 3) + (c & 3)) and the B operand (columns c & 7: the tile in accumulator order)
+  wv_bo_load(wscr, lane, S.Yo);
+  v4d yba, ybs;
+  {
+    const lds_double* t = wscr + 2 * wv_bo_lane(lane);
+    const lds_double* ta = t + (lane >> 3 & 1);
+    const lds_double* tb = t + (lane >> 2 & 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { yba[q] = ta[8 * q]; ybs[q] = tb[8 * q]; }
+  }
+  wv_trsm_cols<PH, 5, 7>(S, Wt, k, nT, D4, lane);
+  wv_trsm_vgpr(S.Y[8], Wt, S.araw, W.q8);
   wv_mfma_fence();
   WV_T(3);
   // L leaves from the registers it was computed in: block column k = [Yb | Y_1 .. Y_8] at slots (k, 0..8), 2 KB each (lane l: 32 bytes at
@@ -578,19 +655,29 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
   v4d fresh4 = wv_gather_vgpr(W, S.rl.o[4]);   // (the accumulator-file tiles of the row: wv_update_tiles)
   // A value that is only loaded and stored may be allocated to the accumulator file by the compiler (memory instructions address it) --
   // onto a window tile.  Naming it as a VGPR operand where it is consumed keeps it out (tools/wave_audit.py checks the ISA for such accesses).
-  asm volatile("" : "+v"(S.bnext));
-  wv_bord_store(ldsb + 128 * PH, lane, S.bnext);
+  asm volatile("" : "+v"(S.bnext.n0), "+v"(S.bnext.n1));
+  wv_bq_store(ldsb + 128 * PH, lane, S.bnext);
   WV_T(4);
   // ---- trailing update: corner, rows 1..7, the LDS tiles of the first half; then (everything requested has landed) the deferred back
   // substitution's column, row 8 and the LDS tiles of the second half
-  wv_upd_vgpr(S.corner, S.Y[0], S.Y[0]);
+  // (ONE accumulator: a 4 x 4 x 4 MFMA that accumulates into the result of the instruction right in front of it needs four wait states -- the
+  // hardware does not hold it back long enough (tools/probes/mfma4x4_probe.hip, r06: without them three launches of the benched batch were not
+  // bit-identical); the border tiles alternate two accumulators, which puts a whole instruction between the dependent ones)
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %1, %5, %0 neg:[1,0,0]\n\ts_nop 3\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %2, %6, %0 neg:[1,0,0]\n\ts_nop 3\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %3, %7, %0 neg:[1,0,0]\n\ts_nop 3\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %4, %8, %0 neg:[1,0,0]"
+               : "+v"(S.corner)
+               : "v"(yba[0]), "v"(yba[1]), "v"(yba[2]), "v"(yba[3]), "v"(ybs[0]), "v"(ybs[1]), "v"(ybs[2]), "v"(ybs[3])
+               : "memory");
   wv_update_rows<PH, TAIL, 1, 7>(W, S, k, nT, W.q8, col);
   wv_lds_pipe<PH, 0, 9>(S, W.q8, lds, lane);
   WV_T(5);
   wv_wait_vm();
   WV_T(6);
   {   // second half: border tile Bd(k+8)^T and window tile (k+8, k+4) -- the latter straight from the registers it was fetched into
-    v4d C10 = wv_task_load<PH, 10>(lds, lane);
+    WvB2 C10 = wv_task_load<PH, 10>(lds, lane);
     wv_update_rows<PH, TAIL, 8, 8>(W, S, k, nT, W.q8, col);
     wv_task_mfma<10>(C10, S, W.q8);
     wv_task_mfma<11>(fresh4, S, W.q8);
@@ -634,18 +721,18 @@ __device__ __forceinline__ void wv_prologue_gathers(const WvProb& W, WvTriList& 
   }
 }
 template <int PH>
-__device__ __forceinline__ void wv_prologue_store(lds_double* lds, int lane, v4d& f4, v4d& bd) {
+__device__ __forceinline__ void wv_prologue_store(lds_double* lds, int lane, v4d& f4, WvB2& bd) {
   if constexpr (PH >= 4) {
     asm volatile("" : "+v"(f4));   // (VGPR operands where they are consumed: see S.bnext in wv_step_rest)
     wv_lds_store(lds + WV_L_WIN + 256 * (wv_phys(PH, 4) - WV_AGPR_TILES), lane, f4);
   }
-  asm volatile("" : "+v"(bd));
-  wv_bord_store(lds + WV_L_BORD + 128 * PH, lane, bd);
+  asm volatile("" : "+v"(bd.n0), "+v"(bd.n1));
+  wv_bq_store(lds + WV_L_BORD + 128 * PH, lane, bd);
 }
 
 // ---- the factorisation of one problem by one wavefront (+ the deferred back substitution of the wave's previous problem) ----------------------
 // lds: WV_LDS_DOUBLES doubles of this wave.  Returns the "all pivots positive" flag and, per lane c < 6, the camera solution x_cam[c];
-// L = block columns [Yb (1 KB: the lanes c < 8) | Y_1 .. Y_8 (slots of 2 KB)] in P.Lb + W tiles in P.Linv.  When it returns, Q's back substitution is complete (Q.x written).
+// L = block columns [Yb (1 KB, QL) | Y_1 .. Y_8 (slots of 2 KB)] in P.Lb + W tiles in P.Linv.  When it returns, Q's back substitution is complete (Q.x written).
 __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double lam_corner, lds_double* lds, const WvPrev& Q, double& xcam_out) {
   asm volatile("" ::: "a0", "a255");   // the accumulator file is ours (the kernel descriptor allocates all of it)
   const int lane = threadIdx.x & 63;
@@ -657,7 +744,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   W.q8 = min(3, max(0, (TS * BT - uni(P.kd)) / 4));
   W.lambda = lambda;
   W.lam_corner = lam_corner;
-  W.bofs = (unsigned)((c & 7) * W.Dnp + g);
+  W.bofs = (unsigned)((c & 3) * W.Dnp + 4 * (c >> 2) + g);
   W.Hc = uni(P.Hc); W.hgl = uni(P.hgatherT); W.Hbord = uni(P.Hbord); W.Lg = uni(P.Lb); W.Linv = uni(P.Linv);
   lds_double* wscr = lds + WV_L_WSCR;
   lds_double* Cn = lds + WV_L_CN;
@@ -668,16 +755,14 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   WvState S;
 #pragma unroll
   for (int i = 0; i < 9; i++) S.Y[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-  S.corner = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int r = g + 4 * q;
-    if (r < SFT_BORDER && c < SFT_BORDER && c <= r) S.corner[q] = P.Hcorner[r * 7 + c] + ((r == c && r < 6) ? lam_corner : 0.0);
-  }
+  const int cr = 4 * (c >> 3) + g, cc = 4 * ((c >> 2) & 1) + (c & 3);   // the lane's element of the corner
+  S.corner = 0.0;
+  if (cr < SFT_BORDER && cc < SFT_BORDER && cc <= cr) S.corner = P.Hcorner[cr * 7 + cc] + ((cr == cc && cr < 6) ? lam_corner : 0.0);
   S.ok = 1;
   {
     WvTriList T;
-    v4d f4[8], bd[8];
+    v4d f4[8];
+    WvB2 bd[8];
     wv_prologue_lists<0, 0>(W, lane, T);
     wv_prologue_gathers<0, 0>(W, T, f4);
 #pragma unroll
@@ -702,8 +787,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
     // the lanes' byte offsets inside a 2 KB tile slot of L / inside the compact border tile: computed every step by statements the compiler
     // cannot hoist -- as loop invariants such registers were parked in the accumulator file, on a window tile (tools/wave_audit.py)
     asm volatile("v_lshlrev_b32 %0, 5, %1" : "=v"(S.off_lane) : "v"(lane));
-    // 32 ((l >> 4) 8 + (l & 7)) = ((32 l >> 1) & 0x300) | (32 l & 0xe0)
-    asm volatile("v_lshrrev_b32 %0, 1, %1\n\tv_and_b32 %0, 0x300, %0\n\tv_bfi_b32 %0, %2, %1, %0" : "=&v"(S.off_bord) : "v"(S.off_lane), "s"(0xe0));
+    asm volatile("v_lshlrev_b32 %0, 4, %1" : "=v"(S.off_bord) : "v"(lane));
     S.araw = wv_gather_vgpr(W, S.al);            // tile (k+8, k)^T through the list that came a step ahead
     // The next list right behind it, in FRONT of the other requests: the wait that consumes them (behind the TRSM) covers it as well, so the
     // compiler's wait in front of the gather above is s_waitcnt vmcnt(14) instead of vmcnt(0) (the list was the youngest load crossing the back
@@ -745,32 +829,24 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
       const v2d_w w01 = (v2d_w){w[0], w[1]}, w23 = (v2d_w){w[2], w[3]};
       asm volatile("global_store_dwordx4 %0, %1, %3\n\tglobal_store_dwordx4 %0, %2, %3 offset:16" :: "v"(S.off_lane), "v"(w01), "v"(w23), "s"(slot) : "memory");
     }
-    // W^T in accumulator order: through LDS (element [row][col] at row * 17 + col)
-    v4d Wt;
-    {
-#pragma unroll
-      for (int q = 0; q < 4; q++) wscr[(g + 4 * q) * 17 + c] = w[q];
-#pragma unroll
-      for (int q = 0; q < 4; q++) Wt[q] = wscr[c * 17 + g + 4 * q];
-    }
-    WV_T(2);
+    // (W^T in accumulator order -- through LDS -- is formed inside wv_step_rest, behind the requests of the TRSM's LDS-resident operands)
     switch (ph + ((k + 8 >= W.nT) ? 8 : 0)) {
-      case 0: wv_step_rest<0, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 1: wv_step_rest<1, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 2: wv_step_rest<2, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 3: wv_step_rest<3, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 4: wv_step_rest<4, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 5: wv_step_rest<5, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 6: wv_step_rest<6, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 7: wv_step_rest<7, false>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 8: wv_step_rest<0, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 9: wv_step_rest<1, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 10: wv_step_rest<2, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 11: wv_step_rest<3, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 12: wv_step_rest<4, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 13: wv_step_rest<5, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      case 14: wv_step_rest<6, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
-      default: wv_step_rest<7, true>(W, S, Wt, k, lds, lane, Q WV_T_PASS); break;
+      case 0: wv_step_rest<0, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 1: wv_step_rest<1, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 2: wv_step_rest<2, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 3: wv_step_rest<3, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 4: wv_step_rest<4, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 5: wv_step_rest<5, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 6: wv_step_rest<6, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 7: wv_step_rest<7, false>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 8: wv_step_rest<0, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 9: wv_step_rest<1, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 10: wv_step_rest<2, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 11: wv_step_rest<3, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 12: wv_step_rest<4, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 13: wv_step_rest<5, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      case 14: wv_step_rest<6, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
+      default: wv_step_rest<7, true>(W, S, w, k, lds, lane, Q WV_T_PASS); break;
     }
   }
   WV_T_DUMP(P);
@@ -783,11 +859,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
 #endif
   // ---- camera corner: 6 x 6 Cholesky of the Schur complement, forward solve of its right-hand side, x_cam (one lane; 7 x 7 in LDS)
   wv_mfma_fence();
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int r = g + 4 * q;
-    if (r < SFT_BORDER && c < SFT_BORDER) Cn[r * 7 + c] = S.corner[q];
-  }
+  if (cr < SFT_BORDER && cc < SFT_BORDER) Cn[cr * 7 + cc] = S.corner;
   double xcam = 0.0;
   {
     int okc = 1;

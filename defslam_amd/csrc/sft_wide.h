@@ -1204,6 +1204,24 @@ __device__ __noinline__ void wide_far_column_of(const SftDev& P, int which, int 
 // raises its flag.  While it multiplies, the operand tiles of its next column are already on their way when the owner's progress allows
 // (a helper that cannot keep up with its owner is bound by what it multiplies then, not by one memory round trip per step).  It never makes
 // the owner wait: a column the owner has already decided about is skipped, and a helper whose owner shows no progress (or is not there) leaves.
+//
+// What the owner <-> helper hand-over relies on (gfx950; NOT what the HIP memory model promises for relaxed atomics, so it is pinned to this
+// target by the static_assert below instead of being paid for with a release / acquire pair per block column -- an agent-scope acquire is
+// `buffer_inv sc1`, which would also throw the finished L tiles out of the helper's L2, each of them an operand of up to twelve columns):
+//   1. data that crosses CUs (Pf / PfB tiles, L tiles the helper reads) is written with sc1 stores = written through to memory past the
+//      writer's XCD L2, and the writer's `s_waitcnt vmcnt(0)` + workgroup barrier sit between those stores and the flag / progress store;
+//      on gfx9 a store has left the L2 write path when vmcnt counts it done, and one wave's stores to one address space are not reordered
+//      past a completed s_waitcnt;
+//   2. flags and progress words are agent-scope atomics (performed at memory, never cached in a non-coherent L2 line);
+//   3. a reader's XCD L2 holds no stale copy of a tile: every tile is written exactly once per launch, before any reader can learn (through
+//      2.) that it exists, a kernel starts with its L2 invalidated for non-coherent lines, and nothing prefetches neighbouring lines
+//      (tiles are 2 KB aligned and whole);
+//   4. the compiler does not move the plain loads of a tile above the atomic load that allowed them: the poll loop ends in a branch on the
+//      loaded value and the loads sit behind `__builtin_amdgcn_s_waitcnt` / barrier intrinsics, which hipcc treats as memory barriers for
+//      scheduling.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "sft_wide.h: the owner / helper hand-over (relaxed agent-scope flags + sc1 write-through) is validated for gfx950 only -- see the comment above factor_wide_helper"
+#endif
 template <int NW = 8>
 __device__ __noinline__ void factor_wide_helper(const SftDev& P, int which_, int hidx_, int nh_, int epoch_, Ctl* ctl, double* ws) {
   const int which = __builtin_amdgcn_readfirstlane(which_), hidx = __builtin_amdgcn_readfirstlane(hidx_), nh = __builtin_amdgcn_readfirstlane(nh_), epoch = __builtin_amdgcn_readfirstlane(epoch_);

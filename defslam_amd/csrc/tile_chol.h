@@ -55,7 +55,8 @@ __device__ __forceinline__ double rsqrt_only(double d) {
 }
 
 // Block step J of the 16 x 16 factorisation, the part every lane computes on broadcast scalars: Cholesky Ld Ld^T of the 4 x 4 diagonal block
-// of `aJ` (register J of the tile) and the A operand of the products with M = Ld^-1 -- lane (g, c) needs M[c][g] for c < 4.  This is a CHAIN of
+// of `aJ` (register J of the tile) and the A operand of the products with M = Ld^-1 -- lane (g, c) gets M[c][g] for c < 4 and 0 otherwise (callers that
+// multiply with the 4 x 4 x 4 MFMA pass c & 3: M replicated over the four blocks).  This is a CHAIN of
 // dependent FP64 operations (four pivots: 1/sqrt, scale, update), the pipe mostly waits for its own results, so what counts is the length of
 // the critical path, not the instruction count:
 //   * every lane solves Ld x = e_g -- its own column of the inverse -- by four steps of forward substitution and keeps x_c (22 instructions;
@@ -90,35 +91,37 @@ __device__ __forceinline__ double chol4_inverse_operand(double aJ, int J, int g,
   return sel;
 }
 
-// Cholesky A = L L^T of a symmetric 16x16 tile and W = L^-1, blocked by 4 (13 MFMAs, 4 dependent block steps), one wavefront.
+// Cholesky A = L L^T of a symmetric 16x16 tile and W = L^-1, blocked by 4 (13 MFMAs -- seven of them 4 x 4 x 4 --, 4 dependent block steps), one wavefront.
 // Block step J (rows/columns 4J..4J+3 live in register J of lane groups g = 0..3):
 //   1. the 10 entries of the symmetric 4x4 diagonal block are broadcast to every lane; every lane factors it and inverts
 //      the factor redundantly (uniform scalars): D = Ld Ld^T, M = Ld^-1
-//   2. Z  = Mpad * A[4J..4J+3, :]   one MFMA, B operand = register J of `a` as it is; Z[g][c] = L[c][4J+g] comes out
+//   2. Z  = M * A[4J..4J+3, :]   one MFMA, B operand = register J of `a` as it is; Z[g][c] = L[c][4J+g] comes out
 //      in exactly the lane layout the rank-4 update needs for both of its operands
-//      Zw = Mpad * W[4J..4J+3, :]   the new rows 4J..4J+3 of W = L^-1
+//      Zw = M * W[4J..4J+3, :]   the new rows 4J..4J+3 of W = L^-1
+//      (r06: both are 4 x 16 results = the four 4 x 4 blocks of ONE v_mfma_f64_4x4x4_4b_f64 -- A_b[i][k] lane i + 4 b + 16 k = M[i][k] for
+//      every block b, i.e. the operand of chol4_inverse_operand replicated over the four quads of a 16-lane row (c & 3 instead of c);
+//      B_b[k][j] lane j + 4 b + 16 k = register J of the tile as it lies; D lane j + 4 b + 16 i = register 0 of the 16 x 16 result the padded
+//      16 x 16 x 4 product used to deliver.  16 cycles instead of 64, and a quarter of the result latency on the chain of dependent operations)
 //   3. a -= Z^T Z (rank 4),  W[rows below] -= L[rows below, 4J..4J+3] * Zw,  W[4J..4J+3, :] = Zw
 // Returns false when a pivot is not positive.
 __device__ __forceinline__ bool chol_inv_blocked(v4d& a, v4d& w) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, c = lane & 15;
   w = (v4d){(g == c) ? 1.0 : 0.0, (g + 4 == c) ? 1.0 : 0.0, (g + 8 == c) ? 1.0 : 0.0, (g + 12 == c) ? 1.0 : 0.0};
-  const v4d zero = {0.0, 0.0, 0.0, 0.0};
   double plast = 1.0;
 #pragma unroll
   for (int J = 0; J < 4; J++) {
     const double aJ = a[J];
-    const double sel = chol4_inverse_operand(aJ, J, g, c, plast);
-    const v4d zw = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, w[J], zero, 0, 0, 0);
+    const double sel = chol4_inverse_operand(aJ, J, g, c & 3, plast);
+    const double zw = __builtin_amdgcn_mfma_f64_4x4x4f64(sel, w[J], 0.0, 0, 0, 0);
     if (J < 3) {
-      const v4d z = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, aJ, zero, 0, 0, 0);
-      const double lp = z[0];                       // L[c][4J+g]
+      const double lp = __builtin_amdgcn_mfma_f64_4x4x4f64(sel, aJ, 0.0, 0, 0, 0);   // L[c][4J+g]
       const double nlp = -lp;
       a = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, lp, a, 0, 0, 0);
       const double below = (c >= 4 * J + 4) ? nlp : 0.0;
-      w = __builtin_amdgcn_mfma_f64_16x16x4f64(below, zw[0], w, 0, 0, 0);
+      w = __builtin_amdgcn_mfma_f64_16x16x4f64(below, zw, w, 0, 0, 0);
     }
-    w[J] = zw[0];
+    w[J] = zw;
   }
   return plast > 0.0;
 }

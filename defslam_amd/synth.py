@@ -25,6 +25,7 @@ CAMERA_K = (500.0, 500.0, 320.0, 240.0)  # fx, fy, cx, cy for a 640x480 frame
 CONFIGS = {
     # name: (rows, cols, matches)
     "smoke": (10, 10, 300),
+    "REF": (10, 10, 450),   # the reference's own default size: 10 x 10 template (TriangularMesh.cc:63-64), 1200 features per frame of which a few hundred match
     "C2": (25, 20, 1000),   # 500-node template, 1000 matches (BASELINE.json configs[1])
     "C5": (50, 40, 4000),   # 2000-node template, 4000 matches (configs[4], per problem)
     "W12": (8, 30, 500),    # small wide-band cases for oracle-sized parity runs: half-bandwidth 182 (12 sub-diagonal tiles) ...
@@ -200,8 +201,9 @@ def _homography_derivs(Hm, u, v):
     return eta, d1, d2
 
 
-def make_normals_scene(n_points: int = 200, n_views: int = 4, seed: int = 7, nonref_frac: float = 0.3):
-    """Returns a dict with the flat arrays of dsh_normals_estimate plus the ground-truth (k1,k2) per point."""
+def make_normals_scene(n_points: int = 200, n_views: int = 4, seed: int = 7, nonref_frac: float = 0.3, min_views: int = 1):
+    """Returns a dict with the flat arrays of dsh_normals_estimate plus the ground-truth (k1,k2) per point.
+    Every point gets between min_views and n_views records (the reference puts no limit on them, NormalEstimator.cc:77-118)."""
     rng = np.random.default_rng(seed)
     recs, is_ref, first_n, has_first_n, rec_ptr = [], [], [], [], [0]
     x0, has_x0, ref_uv, truth = [], [], [], []
@@ -211,7 +213,7 @@ def make_normals_scene(n_points: int = 200, n_views: int = 4, seed: int = 7, non
         N = n / rng.uniform(0.8, 1.5)
         u, v = rng.uniform(-0.4, 0.4, size=2)
         k_true = N[:2] / (N @ np.array([u, v, 1.0]))
-        nv = int(rng.integers(1, n_views + 1))
+        nv = int(rng.integers(min_views, n_views + 1))
         for _ in range(nv):
             w = rng.normal(size=3)
             w *= rng.uniform(0.03, 0.15) / np.linalg.norm(w)

@@ -112,21 +112,30 @@ int dsh_sft_solve(dsh_ctx* ctx, const dsh_sft_frame* frame, dsh_sft_result* resu
  *                         (the frame buffers may be reused as soon as it returns),
  *   dsh_sft_batch_run     launches the solve on dsh_stream; may be called repeatedly -- every run restarts from the uploaded
  *                         initial state.  The launch shape is chosen at upload from the batch and the device:
- *                           - at least two problems per compute unit, every half-bandwidth <= 128: rounds of three phase
- *                             kernels (linearise / factor + solve, one wavefront per problem / trial + controller) over the
- *                             whole batch; the call enqueues rounds and returns when every problem has terminated;
- *                           - more than num_cus/2 problems otherwise: one persistent kernel, one workgroup per problem;
- *                             the call returns at once;
- *                           - smaller batches (a tracked frame) run in latency mode: several workgroups per problem try
- *                             consecutive dampings of a Levenberg-Marquardt iteration side by side, one launch per round,
+ *                           - more than num_cus/2 problems, every half-bandwidth <= 128: the throughput shape.  From two problems
+ *                             per compute unit upwards a step is rounds of three phase kernels over the whole batch (linearise /
+ *                             factor + solve with ONE wavefront per problem / trial + controller) and, once no more than
+ *                             T = min(4 num_cus, max(2 num_cus, 3 B / 4)) problems are still running, ONE launch of a tail kernel
+ *                             in which every remaining problem gets a workgroup of eight wavefronts that runs it to its end (the
+ *                             switch is decided on the device from the count of finished problems).  A batch of T problems or
+ *                             fewer is run by the tail kernel alone.  The call enqueues launches and returns when every problem
+ *                             has terminated;
+ *                           - more than num_cus/2 problems with a wider band among them: one persistent kernel, one workgroup per
+ *                             problem; the call returns at once;
+ *                           - smaller batches (a tracked frame) run in latency mode: min(4, num_cus / B) workgroups per problem
+ *                             try consecutive dampings of a Levenberg-Marquardt iteration side by side, one launch per round,
  *                             and the call returns when the problems have terminated; while the launch holds at most
  *                             num_cus/20 problems, a band of more than one tile that is long enough is cut in two parts
  *                             factored by two workgroups.
  *                         All shapes run the same Levenberg-Marquardt controller on the same normal equations; they differ
  *                         in the elimination order of the Cholesky factorisation, so the SAME frame solved in batches of
  *                         different size, or on devices with a different number of compute units, agrees to rounding
- *                         (vertices to ~1e-12 relative on the test templates), not bit for bit.  A fixed (batch, device)
- *                         reproduces itself bit for bit.  Problems that end in terminal stagnation (an iteration of >= 8
+ *                         (vertices to ~1e-12 relative on the test templates), not bit for bit.  This holds INSIDE the
+ *                         throughput shape as well: the tail kernel's eight-wavefront solver sums in another order than the
+ *                         one-wavefront solver of the rounds (x of one damped system agrees to ~5e-13 relative), and which of
+ *                         the two finishes a problem depends on B, on num_cus and on how many trials the OTHER problems of the
+ *                         batch need -- the result bits of a problem depend on the batch it is solved in.  A fixed (batch,
+ *                         device) reproduces itself bit for bit.  Problems that end in terminal stagnation (an iteration of >= 8
  *                         rejected dampings in a row: the steps are below one ulp of the state) may differ between shapes
  *                         in the number of rejected trials of that last iteration; the state returned agrees as above,
  *   dsh_sft_batch_download brings every result of the batch back with ONE copy (outlier classification, inlier count,

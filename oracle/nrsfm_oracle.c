@@ -20,6 +20,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define NREC_F 18 /* floats per DiffProp record: I1u I1v I2u I2v J12a J12b J12c J12d J21a J21b J21c J21d H12uux H12uuy H12uvx H12uvy H12vvx H12vvy */
@@ -190,9 +191,11 @@ void nrsfm_oracle_normals(int P, const int32_t* rec_ptr, const float* rec, const
                           int32_t* iters, int32_t* term) {
   for (int p = 0; p < P; p++) {
     const int r0 = rec_ptr[p], r1 = rec_ptr[p + 1];
-    double Q[20 * 64];
+    /* one residual block per record whose first keyframe is the reference keyframe -- no upper limit (NormalEstimator.cc:77-118 adds
+     * a block per such record, however many there are) */
+    double* Q = (double*)malloc(sizeof(double) * 20 * (size_t)(r1 > r0 ? r1 - r0 : 1));
     int K = 0;
-    for (int r = r0; r < r1 && K < 64; r++)
+    for (int r = r0; r < r1; r++)
       if (rec_is_ref[r]) { nrsfm_oracle_record_coeffs(rec + NREC_F * r, Q + 20 * K, Q + 20 * K + 10); K++; }
     double x[2] = {0.0, -0.0};
     status[p] = 1; iters[p] = 0; term[p] = 0;
@@ -207,7 +210,7 @@ void nrsfm_oracle_normals(int P, const int32_t* rec_ptr, const float* rec, const
       double disc = sqrt(fmax(0.0, 0.25 * tr * tr - det));
       double lmax = 0.5 * tr + disc, lmin = det / lmax;
       k1k2[2 * p] = x[0]; k1k2[2 * p + 1] = x[1];
-      if (!(lmax > 0) || !(lmin / lmax >= 1e-14)) { status[p] = 2; continue; }
+      if (!(lmax > 0) || !(lmin / lmax >= 1e-14)) { status[p] = 2; free(Q); continue; }
       cov[4 * p] = A[2] / det; cov[4 * p + 1] = -A[1] / det; cov[4 * p + 2] = -A[1] / det; cov[4 * p + 3] = A[0] / det;
       float I1u = ref_uv[2 * p], I1v = ref_uv[2 * p + 1];
       normal_ref[3 * p] = (float)x[0];
@@ -235,5 +238,6 @@ void nrsfm_oracle_normals(int P, const int32_t* rec_ptr, const float* rec, const
       normal_rec[3 * r + 2] = (float)(1 - k1 * I2u - k2 * I2v);
       rec_written[r] = 1;
     }
+    free(Q);
   }
 }

@@ -81,6 +81,26 @@ def test_normals_match_oracle(gpu_ctx, oracle_mod, n_points, n_views, seed):
     np.testing.assert_allclose(g.normal_rec[wr], o["normal_rec"][wr], rtol=0, atol=1e-6)
 
 
+def test_normals_points_with_more_than_a_hundred_reference_records(gpu_ctx, oracle_mod):
+    """NormalEstimator.cc:77-118 adds one residual block per record of the reference keyframe, however many: neither side may cap them."""
+    from defslam_amd import nrsfm, synth
+    sc = synth.make_normals_scene(12, 170, 3, nonref_frac=0.3, min_views=150)
+    nref = np.add.reduceat(sc["rec_is_ref"].astype(np.int64), sc["rec_ptr"][:-1])
+    assert nref.min() >= 100
+    keys = ["rec_ptr", "recs", "rec_is_ref", "rec_first_normal", "rec_has_first_normal", "x0", "has_x0", "ref_uv"]
+    o = oracle_mod.normals(*[sc[k] for k in keys])
+    g = nrsfm.ObtainK1K2(gpu_ctx, *[sc[k] for k in keys])
+    np.testing.assert_array_equal(g.status, o["status"])
+    np.testing.assert_array_equal(g.rec_written, o["rec_written"])
+    np.testing.assert_array_equal(g.iters, o["iters"])
+    assert (o["status"] == 0).all()
+    np.testing.assert_allclose(g.k1k2, o["k1k2"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g.cov, o["cov"], rtol=1e-7)
+    np.testing.assert_allclose(g.normal_ref, o["normal_ref"], rtol=0, atol=1e-6)
+    wr = o["rec_written"].astype(bool)
+    np.testing.assert_allclose(g.normal_rec[wr], o["normal_rec"][wr], rtol=0, atol=1e-6)
+
+
 def test_normals_degenerate_inputs(gpu_ctx, oracle_mod):
     from defslam_amd import nrsfm
     # point 0: no records at all; point 1: rank-deficient (identity warp); point 2: only non-reference records

@@ -107,6 +107,34 @@ def test_normals_oracle_reaches_the_same_minimum_as_scipy(oracle_mod):
     assert checked > 80      # different LM flavours may pick different basins for a few points
 
 
+def test_normals_oracle_uses_every_reference_record_of_a_point(oracle_mod):
+    """No cap on the residual blocks of a point (NormalEstimator.cc:77-118; the oracle used to stop at 64): the answer is stationary for the
+    sum over ALL reference records, and it is not the answer of the first 64."""
+    from defslam_amd import synth
+    sc = synth.make_normals_scene(6, 170, 3, nonref_frac=0.3, min_views=150)
+    keys = ["rec_ptr", "recs", "rec_is_ref", "rec_first_normal", "rec_has_first_normal", "x0", "has_x0", "ref_uv"]
+    o = oracle_mod.normals(*[sc[k] for k in keys])
+    differs = 0
+    for p in range(6):
+        rr = [r for r in range(sc["rec_ptr"][p], sc["rec_ptr"][p + 1]) if sc["rec_is_ref"][r]]
+        assert len(rr) >= 100 and o["status"][p] == 0
+        Q = [oracle_mod.record_coeffs(sc["recs"][r]) for r in rr]
+        xs = o["k1k2"][p]
+
+        def grad(QQ):
+            J = np.vstack([oracle_mod.poly_eval(q1, q2, xs)[1] for q1, q2 in QQ])
+            f = np.concatenate([oracle_mod.poly_eval(q1, q2, xs)[0] for q1, q2 in QQ])
+            return J.T @ f, np.abs(J).max() ** 2
+        g_all, sc_all = grad(Q)
+        assert np.abs(g_all).max() < 1e-6 * max(1.0, sc_all) * len(Q)
+        g_64, _ = grad(Q[:64])
+        differs += int(np.abs(g_64).max() > 100 * np.abs(g_all).max())
+        # the covariance is the inverse of J^T J over all blocks
+        J = np.vstack([oracle_mod.poly_eval(q1, q2, xs)[1] for q1, q2 in Q])
+        np.testing.assert_allclose(o["cov"][p].reshape(2, 2), np.linalg.inv(J.T @ J), rtol=1e-8)
+    assert differs >= 4
+
+
 def test_normals_status_codes_and_propagation(oracle_mod):
     from defslam_amd import synth
     sc = synth.make_normals_scene(60, 3, 9)

@@ -143,13 +143,13 @@ def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
         assert frames[p].trials == r.trials
 
 
-@pytest.fixture
-def rounds_ctx(lab_ctx):
-    """The rounds of phase kernels run to the END of every problem (lab option tail = 0): since r05 the product hands the last problems of a step
-    -- from two per CU downwards, i.e. all of a 512-problem batch -- to sftb_tail_kernel, and these tests are about the one-wavefront solver of the
-    rounds on small, ragged, failing and budgeted problems.  (The tail kernel has its own test below; the product's default, rounds + tail, is
-    what test_benched_shape_matches_oracle_under_load runs.)"""
-    lab_ctx.set_option("tail", 0)
+@pytest.fixture(params=[0, -1], ids=["rounds_to_the_end", "product_default_tail"])
+def rounds_ctx(request, lab_ctx):
+    """Both ways the throughput shape ends a step.  tail = 0: the rounds of phase kernels run to the END of every problem (the one-wavefront
+    solver of the rounds on small, ragged, failing and budgeted problems).  tail = -1: the PRODUCT default -- the last problems of a step, from
+    the automatic threshold downwards (on a 256-CU device ALL of a 512-problem batch), go to sftb_tail_kernel: the same edge cases through the
+    eight-wavefront solver, the tail kernel's own linearisation / trial loop and its budget and failure exits."""
+    lab_ctx.set_option("tail", request.param)
     yield lab_ctx
     lab_ctx.set_option("tail", -1)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the cycles of a one-wavefront factor step go (sft_wave.h section timers): build the lab variant with
-   tools/ab_build.sh wvtrace "-DWV_STEP_TRACE"   and run   python tools/wave_sections.py [B]
+   tools/ab_build.sh wvtrace "-DWV_STEP_TRACE"   and run   python tools/wave_sections.py [B] [variant = wvtrace]
 Prints, for the LAST factorisation of a sample of problems of a full batched run (deferred back substitution riding along), the mean
 shader-clock cycles per factor step of every section."""
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from defslam_amd import _lib  # noqa: E402
 
-_lib.LAB_LIB_PATH = os.path.join(ROOT, "tools", "_ab", "wvtrace.so")
+_lib.LAB_LIB_PATH = os.path.join(ROOT, "tools", "_ab", (sys.argv[2] if len(sys.argv) > 2 else "wvtrace") + ".so")
 from defslam_amd import sft, synth  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -25,6 +25,7 @@ ctx.batch_upload(frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
 ctx.batch_run()
 ctx.synchronize()
 d = np.array([ctx.dump(b, 7, 64) for b in range(0, B, max(1, B // 48))])
+print(os.path.basename(_lib.LAB_LIB_PATH))
 names = ["head requests + diag read", "tile Cholesky", "W transposition", "TRSM", "L stores + row fetch", "corner + rows 1-7 + LDS run 1",
          "wait for memory", "deferred back substitution", "row 8 + LDS run 2"]
 nT = 94
