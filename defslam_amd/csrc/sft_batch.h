@@ -135,8 +135,12 @@ __global__ __launch_bounds__(64, 1) void sftb_factor_kernel(const SftDev* __rest
     Q = wv_prev_of(P, ok, xcam, lane);
     n_done++;
   }
-  if (Q.active) wv_backsub_now(Q, lane);
-  if (lane == 0 && n_done) atomicAdd(&counters[8], n_done);   // factorisations of this kernel over the step (the tail kernel's are not among them)
+  // (the lane index formed afresh: as a value that lives from the top of the kernel to this point the compiler parked it -- and two offsets derived
+  // from it -- in accumulator registers across the factorisations, i.e. on a window tile; tools/wave_audit.py rule 1)
+  int lane_now;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_now));
+  if (Q.active) wv_backsub_now(Q, lane_now);
+  if (lane_now == 0 && n_done) atomicAdd(&counters[8], n_done);   // factorisations of this kernel over the step (the tail kernel's are not among them)
 }
 
 // One damping trial behind its factorisation (TRIAL, and the tail kernel below): push, x applied, scale, chi2 at the trial state, the

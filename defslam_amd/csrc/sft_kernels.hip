@@ -3251,7 +3251,9 @@ __global__ __launch_bounds__(64, 1) void sft_wave_solve_kernel(const SftDev* __r
   const SftDev& P = probs[blockIdx.x];
   const double lambda = P.dbg[1];
   const int ok = wv_factor_solve(P, lambda, lambda, to_lds(reinterpret_cast<double*>(smem)));
-  if (threadIdx.x == 0) P.dbg[2] = ok;
+  int lane_now;   // (not threadIdx.x: a value that lives across the factorisation may be parked on a window tile -- sft_wave.h, wv_factor)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_now));
+  if (lane_now == 0) P.dbg[2] = ok;
 }
 #endif  // DSH_LAB
 

@@ -127,6 +127,62 @@ __device__ __forceinline__ void wv_trsm_vgpr(v4d& Y, const v4d& Wt, const v4d& D
     if (q0 <= 1) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(Y) : "v"(Wt[1]), "v"(D[1]) : "memory");
   }
 }
+// Y = W D with the 4 x 4 x 4 MFMA (r06).  W is LOWER TRIANGULAR: of the sixteen 4 x 4 blocks of the product only the ten with k <= q
+// contribute, Y[row block q] = sum_{k <= q} W(q, k) D[row block k] -- ten instructions of 16 cycles where the 16 x 16 x 4 form spends four of
+// 64 on a full matrix.  A_b[i][kk] = W[4q + i][4k + kk] is the same for the four blocks b (column blocks of D): `WvTri::a[q (q + 1) / 2 + k]`,
+// read from the W scratch in LDS as lane (g, c) = W[4q + (c & 3)][4k + g]; B = register k of D as it lies; the result is register q of Y.
+// Order of issue: the accumulations into one register are never adjacent (a dependent 4 x 4 x 4 pair needs four wait states; one instruction
+// between them provides them): (3,0) (2,0) (3,1) (2,1) (3,2) (2,2) (3,3) (1,0) (0,0) (1,1).
+struct WvTri { double a[10]; };
+__device__ __forceinline__ void wv_tri_load(const lds_double* wscr, int lane, WvTri& A) {   // wscr: W as [row][col] at row * 17 + col
+  const lds_double* p = wscr + (lane & 3) * 17 + (lane >> 4);
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k <= q; k++) A.a[q * (q + 1) / 2 + k] = p[68 * q + 4 * k];
+}
+#define WV_TRI_BODY(D0, D1, D2, D3)                          \
+  "v_mfma_f64_4x4x4_4b_f64 %3, %10, " D0 ", 0\n\t"  /* (3,0) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %2, %7, " D0 ", 0\n\t"   /* (2,0) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %3, %11, " D1 ", %3\n\t" /* (3,1) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %2, %8, " D1 ", %2\n\t"  /* (2,1) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %3, %12, " D2 ", %3\n\t" /* (3,2) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %2, %9, " D2 ", %2\n\t"  /* (2,2) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %3, %13, " D3 ", %3\n\t" /* (3,3) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %1, %5, " D0 ", 0\n\t"   /* (1,0) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %0, %4, " D0 ", 0\n\t"   /* (0,0) */ \
+  "v_mfma_f64_4x4x4_4b_f64 %1, %6, " D1 ", %1"        /* (1,1) */
+template <int T>
+__device__ __forceinline__ void wv_trsm4_agpr(v4d& Y, const WvTri& A) {   // D = accumulator tile T
+  asm volatile(WV_TRI_BODY("a[%c14:%c15]", "a[%c16:%c17]", "a[%c18:%c19]", "a[%c20:%c21]")
+               : "=&v"(Y[0]), "=&v"(Y[1]), "=&v"(Y[2]), "=&v"(Y[3])
+               : "v"(A.a[0]), "v"(A.a[1]), "v"(A.a[2]), "v"(A.a[3]), "v"(A.a[4]), "v"(A.a[5]), "v"(A.a[6]), "v"(A.a[7]), "v"(A.a[8]), "v"(A.a[9]),
+                 "i"(8 * T), "i"(8 * T + 1), "i"(8 * T + 2), "i"(8 * T + 3), "i"(8 * T + 4), "i"(8 * T + 5), "i"(8 * T + 6), "i"(8 * T + 7)
+               : "memory");
+}
+__device__ __forceinline__ void wv_trsm4_vgpr(v4d& Y, const WvTri& A, const v4d& D) {
+  asm volatile("s_nop 1\n\t" WV_TRI_BODY("%14", "%15", "%16", "%17")
+               : "=&v"(Y[0]), "=&v"(Y[1]), "=&v"(Y[2]), "=&v"(Y[3])
+               : "v"(A.a[0]), "v"(A.a[1]), "v"(A.a[2]), "v"(A.a[3]), "v"(A.a[4]), "v"(A.a[5]), "v"(A.a[6]), "v"(A.a[7]), "v"(A.a[8]), "v"(A.a[9]),
+                 "v"(D[0]), "v"(D[1]), "v"(D[2]), "v"(D[3])
+               : "memory");
+}
+// the d = 8 corner tile of a band whose leading row chunk is structurally zero (q8 == 1, e.g. kd = 122): D[0] = 0, so the terms k = 0 drop out and
+// row block 0 of Y is zero -- six instructions: (3,1) (2,1) (3,2) (2,2) (3,3) (1,1)
+__device__ __forceinline__ void wv_trsm4_vgpr_q1(v4d& Y, const WvTri& A, const v4d& D) {
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %2, %6, %9, 0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %1, %4, %9, 0\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %2, %7, %10, %2\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %1, %5, %10, %1\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %2, %8, %11, %2\n\t"
+               "v_mfma_f64_4x4x4_4b_f64 %0, %3, %9, 0"
+               : "=&v"(Y[1]), "=&v"(Y[2]), "=&v"(Y[3])
+               : "v"(A.a[2]), "v"(A.a[4]), "v"(A.a[5]), "v"(A.a[7]), "v"(A.a[8]), "v"(A.a[9]), "v"(D[1]), "v"(D[2]), "v"(D[3])
+               : "memory");
+  Y[0] = 0.0;
+}
+#undef WV_TRI_BODY
 // the values of MFMA-written VGPRs may be read by compiler code behind this statement
 __device__ __forceinline__ void wv_mfma_fence() { asm volatile(WV_NOP_MFMA_RESULT ::: "memory"); }
 
@@ -336,17 +392,46 @@ struct WvPrev {
   int nT, active;
   double xb;                  // per lane: x_cam[c] for c < 6, -1 for c == 6 (the right-hand side column of the border), else 0
 };
+// (r06: the requests as asm -- scalar base + the lane's 32-bit offset + an immediate that advances the global AND the LDS address alike (the
+// slots are 1 KB apart on both sides), M0 = the LDS slot of each group of four.  Through the builtin every request cost a 64-bit vector add for
+// its address and a v_readlane for its LDS base out of the SGPR spill register: 38 vector instructions per step on the one FP64 pipe.)
 __device__ __forceinline__ void wv_bs_request(const WvPrev& Q, int J, lds_double* land, int lane) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  const SFT_G char* col = reinterpret_cast<const SFT_G char*>(Q.Lg + ((size_t)J * (BT + 1)) * 256) + 16 * lane;
+  const unsigned voff = 16u * (unsigned)lane;
+  const SFT_G char* col = reinterpret_cast<const SFT_G char*>(Q.Lg + ((size_t)J * (BT + 1)) * 256);    // wave-uniform
+  const SFT_G char* w = reinterpret_cast<const SFT_G char*>(Q.Linv + (size_t)J * 256);
+  const unsigned l0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)land);                        // LDS byte address of the landing buffer
+  // slot 0: Yb (1 KB; the second KB of the slot is not used), slots 1..8: Y_1 .. Y_8 = KB 2..17
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:3072"
+               :: "v"(voff), "s"(col), "s"(l0) : "memory", "m0");
 #pragma unroll
-  for (int i = 0; i < 18; i++)
-    if (i != 1)   // (the second KB of slot 0 is not used: the border tile is stored as its 32 lanes c < 8)
-      __builtin_amdgcn_global_load_lds((const SFT_G void*)(col + 1024 * i), (lds_void*)(land + 128 * i), 16, 0, WV_DMA_AUX);
-  const SFT_G char* w = reinterpret_cast<const SFT_G char*>(Q.Linv + (size_t)J * 256) + 16 * lane;
-#pragma unroll
-  for (int i = 0; i < 2; i++) __builtin_amdgcn_global_load_lds((const SFT_G void*)(w + 1024 * i), (lds_void*)(land + 128 * (18 + i)), 16, 0, WV_DMA_AUX);
+  for (int grp = 1; grp < 5; grp++) {
+    const SFT_G char* cg = col + 4096 * grp;
+    const unsigned lg = l0 + 4096u * grp;
+    if (grp < 4)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:3072"
+                   :: "v"(voff), "s"(cg), "s"(lg) : "memory", "m0");
+    else   // KB 16, 17
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %1\n\t"
+                   "global_load_lds_dwordx4 %0, %1 offset:1024"
+                   :: "v"(voff), "s"(cg), "s"(lg) : "memory", "m0");
+  }
+  // W: 2 KB behind the eighteen of the column
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %1 offset:1024"
+               :: "v"(voff), "s"(w), "s"(l0 + 18u * 1024u) : "memory", "m0");
 }
+// (Measured and dropped, r06: the nineteen requests issued one at a time behind the first tiles of the trailing update instead of as a burst
+// here -- profiles/r06/ab/phases_ab_v7_dma_spread.log: FACTOR 264.4 against 261.2 ms per step; the 1.5-2.0 k cycles the deferred column costs
+// per step under a full batch are the latency of its own chains of dependent operations, not the issue of its requests.)
 // Column J from the landing buffer: S_q = sum_d Y_d[q] x_{J+d}[c] + Yb[q] xb[c], summed over the 16 lanes of a row, is (L^T x)_tail + the
 // camera term - y at index g + 4q; x_J[c] = sum_r W[r][c] (-S[r]).  The border tile is a ninth tile whose "x" is (x_cam, -1, 0, ...).
 __device__ __forceinline__ void wv_bs_column(const WvPrev& Q, int J, const lds_double* land, lds_double* xring, int lane) {
@@ -465,15 +550,15 @@ struct WvState {
 };
 
 template <int PH, int I, int IEND>
-__device__ __forceinline__ void wv_trsm_cols(WvState& S, const v4d& Wt, int k, int nT, const v4d& D4, int lane) {
+__device__ __forceinline__ void wv_trsm_cols(WvState& S, const WvTri& Wt, int k, int nT, const v4d& D4, int lane) {
   if constexpr (I <= IEND) {
     // unconditional: behind the matrix the window tiles are the zeros they were gathered as (list row nT), W 0 = 0 -- a branch per tile made
     // the compiler write zeros into all nine Y tiles in front of it, every step (28 register moves), to save 36 tile products per factorisation
     (void)k; (void)nT;
     if constexpr (I == 4) {
-      wv_trsm_vgpr(S.Y[4], Wt, D4);   // (the LDS-resident d = 4 tile of the column: requested in front of the W transposition)
+      wv_trsm4_vgpr(S.Y[4], Wt, D4);   // (the LDS-resident d = 4 tile of the column: requested in front of the W transposition)
     } else {
-      wv_trsm_agpr<wv_phys((PH + I) & 7, I)>(S.Y[I], Wt);
+      wv_trsm4_agpr<wv_phys((PH + I) & 7, I)>(S.Y[I], Wt);
     }
     wv_trsm_cols<PH, I + 1, IEND>(S, Wt, k, nT, D4, lane);
   }
@@ -624,13 +709,15 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
 #pragma unroll
     for (int q = 0; q < 4; q++) Wt[q] = wscr[c * 17 + g + 4 * q];
   }
+  WvTri Wq;   // the ten non-zero 4 x 4 blocks of W as operands of the 4 x 4 x 4 TRSM
+  wv_tri_load(wscr, lane, Wq);
   WV_T(2);
   // ---- block column k: border Yb = W Bd(k)^T (4 x 4 x 4 MFMAs; first, so that its trip through LDS into the operand layout lies behind
   // the window's TRSMs), Y_i = W D(k+i, k)
   wv_trsm_b4(S.Yq, Wt, Bk);
-  wv_trsm_cols<PH, 1, 2>(S, Wt, k, nT, D4, lane);   // (W^T has been read from the scratch: LDS instructions of a wave complete in order)
+  wv_trsm_cols<PH, 1, 2>(S, Wq, k, nT, D4, lane);   // (W^T has been read from the scratch: LDS instructions of a wave complete in order)
   wv_bq_store(wscr, lane, S.Yq);        // (8 MFMAs behind its own: complete)
-  wv_trsm_cols<PH, 3, 4>(S, Wt, k, nT, D4, lane);
+  wv_trsm_cols<PH, 3, 4>(S, Wq, k, nT, D4, lane);
   // ... and back in the operand layouts while the other sixteen MFMAs of the TRSM run: OL for the border updates; for the corner product
   // Yb^T Yb (8 x 8 = the four blocks of ONE 4 x 4 x 4 MFMA per k-chunk, block b = (row block b >> 1, column block b & 1)) the A operand
   // (columns 4 (c >> 3) + (c & 3)) and the B operand (columns c & 7: the tile in accumulator order)
@@ -643,8 +730,12 @@ __device__ __forceinline__ void wv_step_rest(const WvProb& W, WvState& S, const 
 #pragma unroll
     for (int q = 0; q < 4; q++) { yba[q] = ta[8 * q]; ybs[q] = tb[8 * q]; }
   }
-  wv_trsm_cols<PH, 5, 7>(S, Wt, k, nT, D4, lane);
-  wv_trsm_vgpr(S.Y[8], Wt, S.araw, W.q8);
+  // (D4 was the B operand of the ten MFMAs right in front of these loads: named here, its registers are not the ones the loads land in --
+  // tools/wave_audit.py rule 5)
+  asm volatile("" :: "v"(D4[0]), "v"(D4[1]), "v"(D4[2]), "v"(D4[3]));
+  wv_trsm_cols<PH, 5, 7>(S, Wq, k, nT, D4, lane);
+  if (W.q8 == 1) wv_trsm4_vgpr_q1(S.Y[8], Wq, S.araw);   // (wave-uniform)
+  else wv_trsm_vgpr(S.Y[8], Wt, S.araw, W.q8);
   wv_mfma_fence();
   WV_T(3);
   // L leaves from the registers it was computed in: block column k = [Yb | Y_1 .. Y_8] at slots (k, 0..8), 2 KB each (lane l: 32 bytes at
@@ -735,7 +826,12 @@ __device__ __forceinline__ void wv_prologue_store(lds_double* lds, int lane, v4d
 // L = block columns [Yb (1 KB, QL) | Y_1 .. Y_8 (slots of 2 KB)] in P.Lb + W tiles in P.Linv.  When it returns, Q's back substitution is complete (Q.x written).
 __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double lam_corner, lds_double* lds, const WvPrev& Q, double& xcam_out) {
   asm volatile("" ::: "a0", "a255");   // the accumulator file is ours (the kernel descriptor allocates all of it)
-  const int lane = threadIdx.x & 63;
+  // The lane index is formed HERE, by a statement the compiler can neither hoist nor merge with another one: derived from threadIdx.x, the
+  // lane-dependent offsets of this function are invariants of the persistent kernel's problem loop, and under register pressure the compiler
+  // parked some of them in accumulator registers across the factorisations -- on a window tile (tools/wave_audit.py rule 1 found three builds
+  // of r06 that did; the values came back as whatever the window had left there).
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
   const int g = lane >> 4, c = lane & 15;
   WvProb W;
   W.Dn = uni(P.Dn);
@@ -776,6 +872,7 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   asm volatile("" : "+v"(S.al[0]), "+v"(S.al[1]), "+v"(S.al[2]), "+v"(S.al[3]));   // (consumed here as far as the compiler is concerned: see the step head)
 #ifdef DSH_LAB
   const long long wv_t1 = clock64();
+  const long long wv_w1 = wall_clock64();   // 100 MHz, constant: the shader clock the loop actually ran at = cycles / wall time
 #endif
 
   WV_T_DECL;
@@ -856,10 +953,18 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   }
 #ifdef DSH_LAB
   const long long wv_t2 = clock64();
+  const long long wv_w2 = wall_clock64();
 #endif
   // ---- camera corner: 6 x 6 Cholesky of the Schur complement, forward solve of its right-hand side, x_cam (one lane; 7 x 7 in LDS)
   wv_mfma_fence();
-  if (cr < SFT_BORDER && cc < SFT_BORDER) Cn[cr * 7 + cc] = S.corner;
+  {   // (the lane's corner element from a lane index formed afresh: hoisted to the top of the kernel as a loop invariant, this address was parked in an
+      // accumulator register -- on a window tile -- across the factorisation; tools/wave_audit.py rule 1)
+    int l2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+    const int g2 = l2 >> 4, c2 = l2 & 15;
+    const int cr2 = 4 * (c2 >> 3) + g2, cc2 = 4 * ((c2 >> 2) & 1) + (c2 & 3);
+    if (cr2 < SFT_BORDER && cc2 < SFT_BORDER) Cn[cr2 * 7 + cc2] = S.corner;
+  }
   double xcam = 0.0;
   {
     int okc = 1;
@@ -892,14 +997,17 @@ __device__ __forceinline__ int wv_factor(const SftDev& P, double lambda, double 
   }
   xcam_out = xcam;
 #ifdef DSH_LAB
-  if (lane == 0) { P.dbg[5] = (double)(wv_t1 - wv_t0); P.dbg[6] = (double)(wv_t2 - wv_t1); }
+  if (lane == 0) { P.dbg[5] = (double)(wv_t1 - wv_t0); P.dbg[6] = (double)(wv_t2 - wv_t1); P.dbg[4] = (double)(wv_w2 - wv_w1); }
 #endif
   return __builtin_amdgcn_readfirstlane(S.ok);
 }
 
 // what a finished factorisation hands to its (deferred or immediate) back substitution; like g2o, x keeps its previous content when the
 // factorisation failed (ok == 0: nothing is written)
-__device__ __forceinline__ WvPrev wv_prev_of(const SftDev& P, int ok, double xcam, int lane) {
+__device__ __forceinline__ WvPrev wv_prev_of(const SftDev& P, int ok, double xcam, int lane_) {
+  (void)lane_;
+  int lane;   // (formed afresh: see wv_factor)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
   const int c = lane & 15;
   WvPrev Q;
   const int Dn = uni(P.Dn), Dnp = ((Dn + NB - 1) / NB) * NB;
@@ -913,11 +1021,12 @@ __device__ __forceinline__ WvPrev wv_prev_of(const SftDev& P, int ok, double xca
 
 // factorisation + back substitution of one problem right away (lab A/B kernel)
 __device__ __forceinline__ int wv_factor_solve(const SftDev& P, double lambda, double lam_corner, lds_double* lds) {
-  const int lane = threadIdx.x & 63;
   WvPrev none;
   none.Lg = nullptr; none.Linv = nullptr; none.x = nullptr; none.nT = 0; none.active = 0; none.xb = 0.0;
   double xcam;
   const int ok = wv_factor(P, lambda, lam_corner, lds, none, xcam);
+  int lane;   // (formed behind the factorisation: see wv_factor)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
   const WvPrev Q = wv_prev_of(P, ok, xcam, lane);
 #ifdef DSH_LAB
   const long long t2 = clock64();

@@ -128,6 +128,27 @@ __global__ void kb(const double* A, double* out, int n, long long* t, double* Wo
   { v4d a = a0; if (NEW) chol_inv_blocked(a, w); else chol_inv_blocked_r03(a, w); for (int q = 0; q < 4; q++) Wout[((l >> 4) + 4 * q) * 16 + (l & 15)] = w[q]; }
   if (l == 0) t[3 + NEW] = (t1 - t0) / n;
 }
+// r06, the look-ahead question: how much of the tile Cholesky is a chain that WAITS for its own results (and could be hidden behind independent
+// work of the same wave) and how much is instructions that have to issue anyway?  Two independent tiles per iteration, interleaved by the
+// compiler: cycles per PAIR against cycles per single tile.  pair == 2 x single: issue-bound, nothing to hide; pair == single: all latency.
+__global__ void kb_pair(const double* A, double* out, int n, long long* t) {
+  const int l = threadIdx.x;
+  v4d a0;
+  for (int q = 0; q < 4; q++) a0[q] = A[((l >> 4) + 4 * q) * 16 + (l & 15)];
+  v4d w, w2, acc = {0, 0, 0, 0};
+  long long t0 = clock64();
+  for (int i = 0; i < n; i++) {
+    v4d a = a0, a2 = a0;
+    a[0] += 1e-9 * i;
+    a2[0] += 2e-9 * i;
+    chol_inv_blocked(a, w);
+    chol_inv_blocked(a2, w2);
+    acc += w + a + w2 + a2;
+  }
+  long long t1 = clock64();
+  for (int q = 0; q < 4; q++) out[l * 4 + q] = acc[q];
+  if (l == 0) t[5] = (t1 - t0) / n;
+}
 template <int VARIANT>
 __global__ void k(const double* A, double* out, int n, long long* t) {
   const int l = threadIdx.x;
@@ -148,7 +169,7 @@ __global__ void k(const double* A, double* out, int n, long long* t) {
 int main() {
   double hA[256];
   for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) hA[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + i + j);
-  double *dA, *out; long long* t; long long h[5]; double* dW; double hW[256];
+  double *dA, *out; long long* t; long long h[6]; double* dW; double hW[256];
   hipMalloc(&dA, 2048); hipMalloc(&out, 4096); hipMalloc(&t, 64); hipMalloc(&dW, 2048);
   hipMemcpy(dA, hA, 2048, hipMemcpyHostToDevice);
   k<0><<<1, 64>>>(dA, out, 2000, t); k<1><<<1, 64>>>(dA, out, 2000, t); k<2><<<1, 64>>>(dA, out, 2000, t);
@@ -169,9 +190,13 @@ int main() {
   kb<1><<<1, 64>>>(dA, out, 2000, t, dW);
   hipDeviceSynchronize();
   const double e_new = check();
-  hipMemcpy(h, t, 40, hipMemcpyDeviceToHost);
+  kb_pair<<<1, 64>>>(dA, out, 2000, t);
+  hipDeviceSynchronize();
+  hipMemcpy(h, t, 48, hipMemcpyDeviceToHost);
   printf("chol+inv (2 MFMA/step): %lld cycles per tile; chol only (1 MFMA/step): %lld; no MFMA (chain only): %lld\n", h[0], h[1], h[2]);
   printf("blocked chol+inv, r03 code:            %lld cycles per tile, max |W A W^T - I| = %.3e\n", h[3], e_old);
   printf("blocked chol+inv, product (tile_chol.h): %lld cycles per tile, max |W A W^T - I| = %.3e\n", h[4], e_new);
+  printf("look-ahead bound (r06): TWO independent tiles interleaved by the compiler: %lld cycles per pair = %.2f x one tile (2.00 = issue-bound: nothing to hide "
+         "behind other work of the same wave; 1.00 = all of it the latency of dependent operations)\n", h[5], (double)h[5] / (double)h[4]);
   return 0;
 }

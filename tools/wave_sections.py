@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the cycles of a one-wavefront factor step go (sft_wave.h section timers): build the lab variant with
-   tools/ab_build.sh wvtrace "-DWV_STEP_TRACE"   and run   python tools/wave_sections.py [B] [variant = wvtrace]
+   tools/ab_build.sh wvtrace "-DWV_STEP_TRACE"   and run   python tools/wave_sections.py [B] [variant = wvtrace] [tail option]
 Prints, for the LAST factorisation of a sample of problems of a full batched run (deferred back substitution riding along), the mean
 shader-clock cycles per factor step of every section."""
 import os
@@ -21,6 +21,8 @@ tmpl = synth.make_grid_template(rows, cols)
 ctx = sft.Context(0, lab=True)
 ctx.template_build(tmpl.xyz0, tmpl.facets)
 frames = [sft.frame_from_synth(synth.make_frame(tmpl, m, p)) for p in range(B)]
+if len(sys.argv) > 3:
+    ctx.set_option("tail", int(sys.argv[3]))     # 0: rounds to the end (small batches: the factor kernel at a fraction of the device)
 ctx.batch_upload(frames, synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP, 1, 50)
 ctx.batch_run()
 ctx.synchronize()
@@ -35,4 +37,7 @@ for e, n in enumerate(names):
     tot += v
     print(f"  {n:34s} {v:8.0f} cycles per step")
 print(f"  {'sum':34s} {tot:8.0f} cycles per step; prologue {d[:, 5].mean() / 1e3:.1f} k, loop {d[:, 6].mean() / 1e3:.1f} k cycles")
+if d[:, 4].mean() > 0:
+    us = d[:, 4].mean() / 100.0     # wall_clock64 ticks at 100 MHz
+    print(f"  the factor loop took {us:.1f} us of wall time: shader clock {d[:, 6].mean() / us / 1e3:.3f} GHz while it ran")
 ctx.close()
