@@ -21,14 +21,18 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-args = [a for a in sys.argv[1:] if a != "--product"]
+args = [a for a in sys.argv[1:] if a not in ("--product", "--keep")]
 product = "--product" in sys.argv[1:]      # audit the code of libdefslam_hip.so (no -DDSH_LAB) instead of the lab build
 want = args[0] if args else ("sftb_factor_kernel" if product else "sft_wave_solve_kernel")
 extra = args[1:]
-out = os.path.join(tempfile.gettempdir(), "wave_audit.s")
+out = os.path.join(tempfile.gettempdir(), f"wave_audit_{os.getpid()}.s")     # (build() runs three audits side by side)
 subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-w", "--offload-arch=gfx950"] + ([] if product else ["-DDSH_LAB"]) +
                       ["--cuda-device-only", "-S", os.path.join(ROOT, "defslam_amd", "csrc", "sft_kernels.hip"), "-o", out] + extra)
 txt = open(out).read().split("\n")
+if "--keep" in sys.argv[1:]:
+    print("assembly kept:", out)
+else:
+    os.remove(out)
 start = next(i for i, l in enumerate(txt) if re.match(r"^_Z\S*" + re.escape(want) + r"\S*:", l))
 end = next(i for i in range(start, len(txt)) if ".end_amdhsa_kernel" in txt[i])
 body = txt[start:end]
