@@ -143,6 +143,43 @@ def test_benched_shape_matches_oracle_under_load(gpu_ctx, oracle_mod):
         assert frames[p].trials == r.trials
 
 
+@pytest.mark.parametrize("B,waves", [(65, 8), (86, 8), (129, 1), (300, 1)])
+def test_launch_shapes_between_latency_mode_and_rounds(gpu_ctx, oracle_mod, B, waves):
+    """The hand-over points of r06 in the PRODUCT library (DESIGN 4.0, 256 CUs): 65 problems = three speculative lanes per problem (the device
+    holds 3 x 65 workgroups, not 4 x), 86 = two lanes, 129 and 300 = the throughput shape with the tail kernel alone (until r05: one workgroup
+    per problem of the persistent kernel).  A ragged batch on the 9 x 14 mesh, sampled ids against the oracle, two runs bit-identical."""
+    from defslam_amd import sft, synth
+    tmpl = synth.make_grid_template(9, 14)
+    gpu_ctx.template_build(tmpl.xyz0, tmpl.facets)
+    regs = (synth.REG_LAP, synth.REG_INEX, synth.REG_TEMP)
+    syn = []
+    for p in range(B):
+        fr = synth.make_frame(tmpl, 380 + 10 * (p % 5), p)
+        if p % 4 == 2:   # a partial view: another active set, another dimension in the same batch
+            keep = [c + 14 * r for r in range(9) for c in range(13)]
+            sel = np.all(np.isin(fr.obs_nodes, keep), axis=1)
+            for k in ["obs_nodes", "obs_bary", "obs_uv", "obs_invsig2"]:
+                setattr(fr, k, getattr(fr, k)[sel])
+        syn.append(fr)
+    frames = [sft.frame_from_synth(fr) for fr in syn]
+    gpu_ctx.batch_upload(frames, *regs, 1, 50)
+    assert int(gpu_ctx.problem_info(0)[1][7]) == waves
+    snaps = []
+    for _ in range(2):
+        gpu_ctx.batch_run()
+        inl = gpu_ctx.batch_download()
+        snaps.append([(int(i), f.iters, f.trials, f.nodes_xyz.copy(), f.pose7.copy()) for i, f in zip(inl, frames)])
+    for a, b in zip(*snaps):
+        assert a[:3] == b[:3]
+        np.testing.assert_array_equal(a[3], b[3])
+        np.testing.assert_array_equal(a[4], b[4])
+    tc = oracle_mod.template_build(tmpl.xyz0, tmpl.facets)
+    for p in (0, 1, 2, B // 2, B - 2, B - 1):
+        fr = syn[p]
+        r = oracle_mod.sft_solve(tc, fr.Tcw, fr.K, fr.n_frame, fr.obs_nodes, fr.obs_bary, fr.obs_uv, fr.obs_invsig2, fr.xyz, *regs, ldlt_mode=1)
+        _compare(frames[p], snaps[1][p][0], r.xyz, r.pose7, r.trace, r.outlier, r.rep_error, r.ret)
+
+
 @pytest.fixture(params=[0, -1], ids=["rounds_to_the_end", "product_default_tail"])
 def rounds_ctx(request, lab_ctx):
     """Both ways the throughput shape ends a step.  tail = 0: the rounds of phase kernels run to the END of every problem (the one-wavefront

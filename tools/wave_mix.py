@@ -1,14 +1,15 @@
 #!/usr/bin/env python
-"""Static instruction mix of the factor kernel's step loop (the ISA tools/wave_audit.py leaves in $TMP/wave_audit.s): instructions between the
-first and the last MFMA of the kernel by class, per ring phase (the step body exists 8 times).  Usage: python tools/wave_audit.py --product; python tools/wave_mix.py"""
+"""Static instruction mix of the factor kernel's step loop (the assembly `tools/wave_audit.py --product --keep` leaves behind and names):
+instructions between the first and the last MFMA of the kernel by class, per ring phase (the step body exists 8 times).
+Usage: python tools/wave_audit.py --product --keep; python tools/wave_mix.py <that .s file> [kernel]"""
 import collections
 import os
 import re
 import sys
 import tempfile
 
-want = sys.argv[1] if len(sys.argv) > 1 else "sftb_factor_kernel"
-txt = open(os.path.join(tempfile.gettempdir(), "wave_audit.s")).read().split("\n")
+want = sys.argv[2] if len(sys.argv) > 2 else "sftb_factor_kernel"
+txt = open(sys.argv[1]).read().split("\n")
 start = next(i for i, l in enumerate(txt) if re.match(r"^_Z\S*" + re.escape(want) + r"\S*:", l))
 end = next(i for i in range(start, len(txt)) if ".end_amdhsa_kernel" in txt[i])
 ins = [l.strip() for l in txt[start:end] if l.strip() and l.strip()[0] not in ";." and not l.strip().endswith(":")]
